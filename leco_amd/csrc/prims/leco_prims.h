@@ -1,0 +1,43 @@
+// Device primitives for the gfx950 (CDNA4, wave64) kernels: raw-bit bf16 helpers, the MFMA
+// tile op, wave shuffles.  Kernel sources include this as <leco_prims.h>; the host-emulation
+// test harness (tests/emu/) substitutes its own header of the same name at build time so the
+// kernel sources themselves stay pure HIP.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace leco {
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 hw_bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+// round-to-nearest-even; NaN stays NaN (quiet)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// D(16x16,f32) = A(16x32,bf16) * B(32x16,bf16) + C   -- v_mfma_f32_16x16x32_bf16.
+// Lane l supplies A[l&15][8*(l>>4)+t] and B[8*(l>>4)+t][l&15], t=0..7, and holds
+// C/D[4*(l>>4)+r][l&15], r=0..3 (cdna_hip_programming.md section 3).
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(hw_bf16x8, a),
+                                                   __builtin_bit_cast(hw_bf16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+__device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+__device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+}  // namespace leco

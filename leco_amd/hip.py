@@ -1,0 +1,158 @@
+"""ctypes binding of ``libleco_hip.so`` (C ABI declared in ``include/leco_hip.h``).
+
+The shared object is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is
+no CPU fallback: if the library is missing this module raises, and every op below goes
+through it.  (``tests/emu`` can point the loader at a host-emulated build of the *same kernel
+sources* via ``_use_library`` -- a kernel-debugging harness, never used by the product path.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libleco_hip.so")
+
+A_PLAIN, A_CONV3_S1, A_CONV3_S2, A_CONV3_UP2, A_CONV3_TR2 = range(5)
+ACT_NONE, ACT_SILU = 0, 1
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ("a0", C.c_void_p), ("a1", C.c_void_p), ("lda0", C.c_int64), ("lda1", C.c_int64),
+        ("k_split", C.c_int32), ("a_mode", C.c_int32),
+        ("batch", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32), ("h_in", C.c_int32),
+        ("w_in", C.c_int32),
+        ("w", C.c_void_p), ("ldw", C.c_int64),
+        ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
+        ("a_ext", C.c_void_p), ("ld_aext", C.c_int64), ("w_ext", C.c_void_p), ("ld_wext", C.c_int64),
+        ("ext_k", C.c_int32),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("rows_per_group", C.c_int32),
+        ("residual", C.c_void_p), ("ldr", C.c_int64),
+        ("act", C.c_int32),
+        ("c", C.c_void_p), ("ldc", C.c_int64), ("c_f32", C.c_void_p), ("ldc32", C.c_int64),
+    ]
+
+
+class LoraSite(C.Structure):
+    _fields_ = [
+        ("down", C.c_void_p * 3), ("up", C.c_void_p * 3),
+        ("groups", C.c_int32), ("r", C.c_int32), ("k", C.c_int32), ("n", C.c_int32),
+        ("scale", C.c_float), ("_pad", C.c_int32),
+        ("dn_s", C.c_void_p), ("up_p", C.c_void_p), ("up_t", C.c_void_p), ("dn_p", C.c_void_p),
+    ]
+
+
+_lib: Optional[C.CDLL] = None
+_lib_path: Optional[str] = None
+
+
+def _declare(lib: C.CDLL) -> None:
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sig = {
+        "leco_version": ([], C.c_int),
+        "leco_last_error": ([], C.c_char_p),
+        "leco_gemm": ([C.POINTER(GemmArgs), vp], C.c_int),
+        "leco_gemm_tile": ([C.POINTER(GemmArgs), C.c_int, vp], C.c_int),
+    }
+    for name, (args, res) in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = res
+    # remaining entry points are declared by the modules that use them via declare()
+
+
+def declare(name: str, argtypes, restype=C.c_int):
+    fn = getattr(lib(), name)
+    fn.argtypes = argtypes
+    fn.restype = restype
+    return fn
+
+
+def lib() -> C.CDLL:
+    global _lib, _lib_path
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"leco_amd: HIP extension {LIB_PATH} is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback.")
+        _lib = C.CDLL(LIB_PATH)
+        _lib_path = LIB_PATH
+        _declare(_lib)
+    return _lib
+
+
+def _use_library(path: str) -> None:
+    """Test hook: bind to another build of the same C ABI (the host emulator)."""
+    global _lib, _lib_path
+    _lib = C.CDLL(path)
+    _lib_path = path
+    _declare(_lib)
+
+
+def is_emulated() -> bool:
+    lib()
+    return _lib_path != LIB_PATH
+
+
+class LecoError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().leco_last_error()
+        raise LecoError(f"{what} failed rc={rc}: {msg.decode() if msg else ''}")
+
+
+def stream_ptr(t: Optional[torch.Tensor] = None) -> Optional[int]:
+    """hipStream_t of torch's current stream (None on the emulator / CPU tensors)."""
+    if t is not None and t.device.type != "cuda":
+        return None
+    if not torch.cuda.is_available():
+        return None
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, m: int, n: int, k: int,
+              lda: Optional[int] = None, a1: Optional[torch.Tensor] = None, lda1: int = 0, k_split: int = 0,
+              a_mode: int = A_PLAIN, conv=None, ldw: Optional[int] = None,
+              a_ext: Optional[torch.Tensor] = None, w_ext: Optional[torch.Tensor] = None, ext_k: int = 0,
+              ld_aext: int = 0, ld_wext: int = 0,
+              bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
+              rows_per_group: int = 0, residual: Optional[torch.Tensor] = None, ldr: int = 0,
+              act: int = ACT_NONE, ldc: Optional[int] = None, out_f32: Optional[torch.Tensor] = None,
+              ldc32: int = 0) -> GemmArgs:
+    """Build the argument block for leco_gemm.  ``conv`` = (batch, h_out, w_out, h_in, w_in)."""
+    g = GemmArgs()
+    g.a0 = ptr(a)
+    g.a1 = ptr(a1)
+    g.lda0 = k if lda is None else lda
+    g.lda1 = lda1
+    g.k_split = k_split
+    g.a_mode = a_mode
+    if conv is not None:
+        g.batch, g.h_out, g.w_out, g.h_in, g.w_in = conv
+    g.w = ptr(w)
+    g.ldw = k if ldw is None else ldw
+    g.m, g.n, g.k = m, n, k
+    g.a_ext, g.w_ext, g.ext_k = ptr(a_ext), ptr(w_ext), ext_k
+    g.ld_aext, g.ld_wext = ld_aext or ext_k, ld_wext or ext_k
+    g.bias, g.rowbias, g.rows_per_group = ptr(bias), ptr(rowbias), rows_per_group
+    g.residual, g.ldr = ptr(residual), ldr or n
+    g.act = act
+    g.c, g.ldc = ptr(out), (n if ldc is None else ldc)
+    g.c_f32, g.ldc32 = ptr(out_f32), ldc32 or n
+    return g
+
+
+def gemm(args: GemmArgs, stream=None, tile: int = 0) -> None:
+    check(lib().leco_gemm_tile(C.byref(args), tile, stream), "leco_gemm")

@@ -1,0 +1,62 @@
+"""TEST INFRASTRUCTURE ONLY -- builds tests/emu/_build/libleco_emu.so: the *same* kernel
+sources as libleco_hip.so (leco_amd/csrc/*.hip), compiled for the host with ROCm's clang++
+against the fiber emulator in this directory, so kernel logic can be checked on a CPU."""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+CSRC = os.path.join(ROOT, "leco_amd", "csrc")
+OUT = os.path.join(HERE, "_build")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def sources():
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
+            if f.endswith(".hip") and f != "runtime.hip"]
+    srcs += [os.path.join(CSRC, "common.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
+    return srcs
+
+
+def _digest(path):
+    h = hashlib.sha1()
+    deps = [path, os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "leco_prims.h"),
+            os.path.join(ROOT, "include", "leco_hip.h"), os.path.join(CSRC, "common.h")]
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build(verbose=False):
+    os.makedirs(OUT, exist_ok=True)
+    flags = ["-std=c++17", "-O2", "-fPIC", "-pthread", "-Wno-unknown-attributes", "-Wno-unused-value",
+             "-Wno-unknown-pragmas", "-Wno-pass-failed",
+             "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+
+    def one(src):
+        obj = os.path.join(OUT, os.path.basename(src) + "." + _digest(src) + ".o")
+        if not os.path.exists(obj):
+            cmd = [CLANG, "-x", "c++", *flags, "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.run(cmd, check=True)
+        return obj
+
+    with ThreadPoolExecutor(8) as ex:
+        objs = list(ex.map(one, sources()))
+    lib = os.path.join(OUT, "libleco_emu.so")
+    stamp = os.path.join(OUT, "link.stamp")
+    key = " ".join(objs)
+    if not os.path.exists(lib) or not os.path.exists(stamp) or open(stamp).read() != key:
+        subprocess.run([CLANG, "-shared", "-pthread", "-o", lib, *objs], check=True)
+        with open(stamp, "w") as f:
+            f.write(key)
+    return lib
+
+
+if __name__ == "__main__":
+    print(build(verbose="-v" in sys.argv))

@@ -1,0 +1,197 @@
+// TEST INFRASTRUCTURE ONLY -- fiber scheduler behind tests/emu/hip/hip_runtime.h.
+#include <hip/hip_runtime.h>
+
+#include <sys/mman.h>
+#include <ucontext.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+namespace emu {
+thread_local emu_uint3 t_idx, b_idx;
+thread_local dim3 b_dim, g_dim;
+
+namespace {
+constexpr size_t kStack = 256 * 1024;
+constexpr int kMaxThreads = 1024;
+
+struct Fiber {
+    ucontext_t ctx;
+    bool done;
+};
+
+struct Runner {
+    ucontext_t sched;
+    Fiber fibers[kMaxThreads];
+    char* stacks = nullptr;
+    int n = 0, cur = 0;
+    int block_arrived = 0;
+    unsigned block_gen = 0;
+    int wave_arrived[kMaxThreads / 64] = {};
+    unsigned wave_gen[kMaxThreads / 64] = {};
+    unsigned char* slots = nullptr;  // [waves][2][64*kSlot]
+    const std::function<void()>* body = nullptr;
+    dim3 bdim;
+
+    void ensure() {
+        if (!stacks) {
+            stacks = (char*)mmap(nullptr, kStack * kMaxThreads, PROT_READ | PROT_WRITE,
+                                 MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+            slots = (unsigned char*)calloc((kMaxThreads / 64) * 2 * 64 * kSlot, 1);
+            if (stacks == MAP_FAILED || !slots) { perror("emu alloc"); abort(); }
+        }
+    }
+};
+thread_local Runner* tl_runner = nullptr;
+
+void trampoline() {
+    Runner* r = tl_runner;
+    (*r->body)();
+    r->fibers[r->cur].done = true;
+    // returns to uc_link (scheduler)
+}
+
+void set_tid(Runner* r, int i) {
+    t_idx.x = i % r->bdim.x;
+    t_idx.y = (i / r->bdim.x) % r->bdim.y;
+    t_idx.z = i / (r->bdim.x * r->bdim.y);
+}
+
+void yield_fiber() {
+    Runner* r = tl_runner;
+    int me = r->cur;
+    swapcontext(&r->fibers[me].ctx, &r->sched);
+}
+
+void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
+    r->ensure();
+    r->n = block.x * block.y * block.z;
+    if (r->n > kMaxThreads) { fprintf(stderr, "emu: block too large\n"); abort(); }
+    r->bdim = block;
+    r->body = &body;
+    r->block_arrived = 0;
+    for (int w = 0; w < kMaxThreads / 64; ++w) r->wave_arrived[w] = 0;
+    for (int i = 0; i < r->n; ++i) {
+        Fiber& f = r->fibers[i];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = r->stacks + (size_t)i * kStack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = &r->sched;
+        f.done = false;
+        makecontext(&f.ctx, trampoline, 0);
+    }
+    int live = r->n;
+    long spins = 0;
+    while (live > 0) {
+        for (int i = 0; i < r->n; ++i) {
+            if (r->fibers[i].done) continue;
+            r->cur = i;
+            set_tid(r, i);
+            swapcontext(&r->sched, &r->fibers[i].ctx);
+            if (r->fibers[i].done) --live;
+        }
+        if (++spins > 200000000L) { fprintf(stderr, "emu: deadlock (divergent barrier?)\n"); abort(); }
+    }
+}
+
+// ---- persistent worker pool ------------------------------------------------
+struct Pool {
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cv_done;
+    unsigned long job_id = 0;
+    dim3 grid, block;
+    const std::function<void()>* body = nullptr;
+    std::atomic<long> next{0};
+    long total = 0;
+    int active = 0;
+    bool stop = false;
+
+    Pool() {
+        int n = (int)std::thread::hardware_concurrency();
+        const char* e = getenv("LECO_EMU_THREADS");
+        if (e) n = atoi(e);
+        if (n < 1) n = 1;
+        for (int i = 0; i < n; ++i) th.emplace_back([this] { worker(); });
+    }
+    ~Pool() {
+        { std::lock_guard<std::mutex> l(mu); stop = true; }
+        cv.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void worker() {
+        Runner* r = new Runner();
+        tl_runner = r;
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> l(mu);
+                cv.wait(l, [&] { return stop || job_id != seen; });
+                if (stop) return;
+                seen = job_id;
+            }
+            for (;;) {
+                long b = next.fetch_add(1);
+                if (b >= total) break;
+                b_idx.x = b % grid.x;
+                b_idx.y = (b / grid.x) % grid.y;
+                b_idx.z = b / ((long)grid.x * grid.y);
+                b_dim = block;
+                g_dim = grid;
+                run_block(r, block, *body);
+            }
+            {
+                std::lock_guard<std::mutex> l(mu);
+                if (--active == 0) cv_done.notify_all();
+            }
+        }
+    }
+    void run(dim3 g, dim3 b, const std::function<void()>& fn) {
+        std::unique_lock<std::mutex> l(mu);
+        grid = g; block = b; body = &fn;
+        total = (long)g.x * g.y * g.z;
+        next = 0;
+        active = (int)th.size();
+        ++job_id;
+        cv.notify_all();
+        cv_done.wait(l, [&] { return active == 0; });
+    }
+};
+Pool& pool() { static Pool p; return p; }
+}  // namespace
+
+void sync_block() {
+    Runner* r = tl_runner;
+    unsigned g = r->block_gen;
+    if (++r->block_arrived == r->n) {
+        r->block_arrived = 0;
+        r->block_gen = g + 1;
+    } else {
+        while (r->block_gen == g) yield_fiber();
+    }
+}
+
+int lane() { return tl_runner->cur & 63; }
+
+const unsigned char* wave_gather(const void* in, int bytes) {
+    Runner* r = tl_runner;
+    int w = r->cur >> 6, ln = r->cur & 63;
+    int wave_n = r->n - w * 64 < 64 ? r->n - w * 64 : 64;
+    unsigned g = r->wave_gen[w];
+    unsigned char* buf = r->slots + ((size_t)(w * 2 + (g & 1)) * 64) * kSlot;
+    if (bytes > kSlot) { fprintf(stderr, "emu: slot overflow\n"); abort(); }
+    memcpy(buf + (size_t)ln * kSlot, in, bytes);
+    if (++r->wave_arrived[w] == wave_n) {
+        r->wave_arrived[w] = 0;
+        r->wave_gen[w] = g + 1;
+    } else {
+        while (r->wave_gen[w] == g) yield_fiber();
+    }
+    return buf;
+}
+
+void launch(dim3 grid, dim3 block, const std::function<void()>& body) { pool().run(grid, block, body); }
+}  // namespace emu

@@ -1,0 +1,68 @@
+// TEST INFRASTRUCTURE ONLY -- host-emulation twin of leco_amd/csrc/prims/leco_prims.h.
+// Same names and semantics; the wave64 collectives are implemented over emu::wave_gather.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace leco {
+typedef unsigned short bf16_t;
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+static inline float __uint_as_float_emu(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint_emu(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+#define __uint_as_float leco::__uint_as_float_emu
+#define __float_as_uint leco::__float_as_uint_emu
+
+static inline float bf2f(bf16_t h) { return __uint_as_float_emu(((unsigned)h) << 16); }
+static inline bf16_t f2bf(float f) {
+    unsigned u = __float_as_uint_emu(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+static inline unsigned pack_bf2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+// v_mfma_f32_16x16x32_bf16 lane maps (cdna_hip_programming.md section 3):
+// lane l supplies A[l&15][8*(l>>4)+t], B[8*(l>>4)+t][l&15]; holds D[4*(l>>4)+r][l&15].
+static inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    struct Dep { short a[8]; short b[8]; } d;
+    for (int t = 0; t < 8; ++t) { d.a[t] = a[t]; d.b[t] = b[t]; }
+    const unsigned char* all = emu::wave_gather(&d, sizeof(d));
+    int l = emu::lane();
+    int j = l & 15, g = l >> 4;
+    f32x4 out = c;
+    for (int r = 0; r < 4; ++r) {
+        int i = 4 * g + r;
+        float acc = 0.f;
+        for (int k = 0; k < 32; ++k) {
+            const Dep* la = reinterpret_cast<const Dep*>(all + (size_t)(i + 16 * (k >> 3)) * emu::kSlot);
+            const Dep* lb = reinterpret_cast<const Dep*>(all + (size_t)(j + 16 * (k >> 3)) * emu::kSlot);
+            acc += bf2f((bf16_t)la->a[k & 7]) * bf2f((bf16_t)lb->b[k & 7]);
+        }
+        out[r] = c[r] + acc;
+    }
+    return out;
+}
+
+static inline int lane_id() { return emu::lane(); }
+static inline float shfl_xor(float v, int mask) {
+    const unsigned char* all = emu::wave_gather(&v, 4);
+    float r;
+    memcpy(&r, all + (size_t)(emu::lane() ^ mask) * emu::kSlot, 4);
+    return r;
+}
+static inline float shfl(float v, int src) {
+    const unsigned char* all = emu::wave_gather(&v, 4);
+    float r;
+    memcpy(&r, all + (size_t)(src & 63) * emu::kSlot, 4);
+    return r;
+}
+static inline float fast_exp2(float x) { return exp2f(x); }
+static inline float fast_rcp(float x) { return 1.0f / x; }
+}  // namespace leco
