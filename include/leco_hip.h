@@ -105,6 +105,110 @@ int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, floa
                     int64_t g_sj, int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
                     leco_stream_t stream);
 
+/* same as leco_gemm with an explicit tile choice: 0 heuristic, 1 = 128x128, 2 = 128x160,
+ * 3 = 64x64 (tests / tuning). */
+int leco_gemm_tile(const leco_gemm_args* args, int tile, leco_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Normalisation (diffusers GroupNorm(32) in ResnetBlock2D / Transformer2DModel / conv_norm_out,
+ * LayerNorm in BasicTransformerBlock; call site train_util.py:156-160; dgrads train_lora.py:279).
+ * x may be the channel concat [x0 | x1] (x1 == NULL: single source).  stats / bstats are
+ * fp32 [batch][groups][2] scratch ({sum, sumsq} resp. {sum dxhat, sum dxhat*xhat}); the
+ * forward stats must be kept for the backward.  act: LECO_ACT_NONE / LECO_ACT_SILU.
+ * ---------------------------------------------------------------------- */
+int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
+                       const float* gamma, const float* beta, int32_t batch, int32_t hw, int32_t c,
+                       int32_t groups, float eps, int32_t act, float* stats, void* y, int64_t ldy,
+                       leco_stream_t stream);
+int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
+                       const void* dy, int64_t lddy, const float* gamma, const float* beta,
+                       const float* stats, int32_t batch, int32_t hw, int32_t c, int32_t groups,
+                       float eps, int32_t act, float* bstats, void* dx, int64_t lddx,
+                       leco_stream_t stream);
+int leco_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                       int32_t m, int32_t c, void* y, int64_t ldy, float* mean, float* rstd,
+                       leco_stream_t stream);
+/* dx = LayerNorm dgrad (+ dres if not NULL: the residual-branch gradient) */
+int leco_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* gamma,
+                       const float* mean, const float* rstd, const void* dres, int64_t ldres,
+                       int32_t m, int32_t c, void* dx, int64_t lddx, leco_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Attention core softmax(Q K^T * scale) V per (batch, head); replaces diffusers' Attention
+ * processor / xformers memory_efficient_attention (train_lora.py:68).  q/k/v/o are bf16 with
+ * token stride ld* and batch stride bs* (elements); head h occupies columns [h*d, (h+1)*d).
+ * lse: fp32 [batch][heads][sq] (log-sum-exp of the scaled scores), needed by the backward.
+ * head_dim in {32, 40, 64, 80, 160}.
+ * ---------------------------------------------------------------------- */
+int leco_attention_fwd(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk,
+                       int64_t bsk, const void* v, int64_t ldv, int64_t bsv, void* o, int64_t ldo,
+                       int64_t bso, float* lse, int32_t batch, int32_t heads, int32_t sq,
+                       int32_t skv, int32_t head_dim, float scale, leco_stream_t stream);
+/* dQ, dK, dV from dO (flash backward, recomputing P from lse).  delta: fp32 [batch][heads][sq]
+ * scratch.  No atomics: dQ and dK/dV are produced by two deterministic kernels. */
+int leco_attention_bwd(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk,
+                       int64_t bsk, const void* v, int64_t ldv, int64_t bsv, const void* o,
+                       int64_t ldo, int64_t bso, const void* d_o, int64_t lddo, int64_t bsdo,
+                       const float* lse, float* delta, void* dq, int64_t lddq,
+                       int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv,
+                       int64_t bsdv, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                       int32_t head_dim, float scale, leco_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Elementwise / small kernels.
+ * ---------------------------------------------------------------------- */
+/* GEGLU (diffusers FeedForward ff.net.0): y[m][f] = u[m][f] * gelu_erf(u[m][F+f]) */
+int leco_geglu_fwd(const void* u, int64_t ldu, void* y, int64_t ldy, int32_t m, int32_t f,
+                   leco_stream_t stream);
+int leco_geglu_bwd(const void* u, int64_t ldu, const void* dy, int64_t lddy, void* du, int64_t lddu,
+                   int32_t m, int32_t f, leco_stream_t stream);
+/* out = a + b (+ c) on row-strided bf16 matrices (gradient fan-in at residual/skip joins) */
+int leco_add(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc,
+             void* out, int64_t ldo, int32_t m, int32_t cols, leco_stream_t stream);
+/* dgrad of F.interpolate(scale=2, nearest) (Upsample2D): dx = 2x2 block sums of dy */
+int leco_upsample2x_bwd(const void* dy, void* dx, int32_t batch, int32_t h, int32_t w, int32_t c,
+                        leco_stream_t stream);
+/* UNet conv_in: NCHW bf16 (batch,cin,h,w) -> channels-last bf16; w fp32 [cout][cin][3][3] */
+int leco_conv_in(const void* x, const float* w, const float* bias, void* y, int32_t batch, int32_t h,
+                 int32_t wd, int32_t cin, int32_t cout, leco_stream_t stream);
+/* UNet conv_out: channels-last bf16 -> NCHW fp32 (batch,4,h,w); w bf16 [4][3][3][c]; and its dgrad */
+int leco_conv_out(const void* x, const void* w, const float* bias, float* y, int32_t batch, int32_t h,
+                  int32_t wd, int32_t c, int32_t cout, leco_stream_t stream);
+int leco_conv_out_bwd(const float* dy, const void* w, void* dx, int32_t batch, int32_t h, int32_t wd,
+                      int32_t c, int32_t cout, leco_stream_t stream);
+/* diffusers Timesteps(flip_sin_to_cos=True, freq_shift=0): out[i] = [cos | sin](t_i * f), bf16
+ * [n][dim]; t_i = t_table[*idx + i*t_stride] (idx may be NULL => 0): the timestep is read on
+ * the device so a captured graph can be replayed for every denoising step. */
+int leco_timestep_embedding(const float* t_table, const int32_t* idx, int32_t t_stride, int32_t n,
+                            int32_t dim, void* out, leco_stream_t stream);
+int leco_advance(int32_t* counter, leco_stream_t stream);
+/* predict_noise's guidance combine (train_util.py:163-166) fused with DDIMScheduler.step
+ * (train_util.py:190): eps = u + g (c - u); x <- coef[step][0] x + coef[step][1] eps; also writes
+ * the next UNet input cat([x]*2) as bf16 (train_util.py:151). */
+int leco_cfg_ddim_step(const float* pred, float* x, void* x2, const float* coef, const int32_t* step,
+                       float guidance, int64_t half_n, leco_stream_t stream);
+/* PromptEmbedsPair.loss (prompt_util.py:107-148) with MSELoss(mean) on device in fp32, plus
+ * d loss / d (raw target-pass UNet output) (train_lora.py:279 first autograd step). */
+int leco_esd_loss(const float* tgt, const float* pos, const float* neu, const float* unc, float g_pred,
+                  float g_loss, float sign, int64_t half_n, float* loss, float* dpred,
+                  leco_stream_t stream);
+/* torch.optim.AdamW step on the flat fp32 LoRA slab + refresh of its bf16 shadow
+ * (train_lora.py:280).  hyper (device): {lr, 1-beta1^t, 1-beta2^t, grad_scale}. */
+int leco_adamw(float* p, const float* g, float* m, float* v, void* shadow, const float* hyper,
+               float beta1, float beta2, float eps, float wd, int64_t n, leco_stream_t stream);
+int leco_cast_f32_bf16(const float* x, void* y, int64_t n, leco_stream_t stream);
+int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * hipGraph capture of a whole UNet pass (the reference issues ~10^4 eager kernel launches
+ * per pass from Python; here a pass is one graph launch).
+ * ---------------------------------------------------------------------- */
+typedef void* leco_graph_t;
+int leco_graph_begin_capture(leco_stream_t stream);
+int leco_graph_end_capture(leco_stream_t stream, leco_graph_t* out);
+int leco_graph_launch(leco_graph_t graph, leco_stream_t stream);
+int leco_graph_destroy(leco_graph_t graph);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,543 @@
+// Flash-style attention forward for the UNet's self- and cross-attention:
+//   O = softmax(Q K^T * scale) V  per (batch, head), never materialising the score matrix.
+// Head dims 32/40/64/80/160 (SD1.x: 40/80/160, SD2.x/SDXL: 64), key counts 77 .. 9216.
+//
+// gfx950 mapping (wave64, v_mfma_f32_16x16x32_bf16):
+//   * one workgroup = 4 waves = QF*64 query rows of one (b, head); K/V stream through LDS in
+//     64-key tiles shared by the 4 waves (K row-major with a 16-byte row pad => conflict-free
+//     ds_read_b128; V transposed on the way in so the PV operand is two ds_read_b64);
+//   * both products are issued "swapped" -- S^T = K Q^T and O^T = V^T P^T -- so that every
+//     lane owns ONE query row (col = lane & 15): the online-softmax state (running max, sum)
+//     is one scalar per lane, the row max needs only two xor-shuffles (lanes l, l^16, l^32,
+//     l^48 hold the same row), and P never leaves registers: with the key order of a tile
+//     permuted consistently on the V side, the S^T accumulator registers ARE the P^T operand;
+//   * exp2 with scale*log2(e) folded in; fp32 running statistics; bf16 P for the PV MFMA;
+//   * epilogue: lane holds 4 consecutive d of its row => 8-byte stores; LSE saved for backward.
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <leco_prims.h>
+#include <math.h>
+
+#include "common.h"
+
+namespace leco {
+namespace {
+
+struct AttnArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v;
+    int64_t ldq, ldk, ldv;     // token strides (elements)
+    int64_t bsq, bsk, bsv;     // batch strides (elements)
+    bf16_t* o; int64_t ldo, bso;
+    float* lse;                // [B][H][Sq] natural-log sum-exp of the scaled scores
+    int heads, sq, skv;
+    float scale_log2;          // scale * log2(e)
+};
+
+constexpr int KT = 64;  // keys per tile
+
+template <int D, int QF>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+    constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
+    constexpr int NKS = DK / 32, NFD = DV / 16, NDC = D / 8;
+    constexpr int KROW = DK + 8;   // padded K row (elements)
+    constexpr int VROW = KT + 8;   // padded V^T row (elements)
+    __shared__ __attribute__((aligned(16))) bf16_t smem[KT * KROW + DV * VROW];
+    bf16_t* sK = smem;
+    bf16_t* sV = smem + KT * KROW;
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int q0 = (int)blockIdx.x * (64 * QF) + wave * (16 * QF);
+
+    const bf16_t* qb = p.q + (int64_t)b * p.bsq + (int64_t)h * D;
+    const bf16_t* kb = p.k + (int64_t)b * p.bsk + (int64_t)h * D;
+    const bf16_t* vb = p.v + (int64_t)b * p.bsv + (int64_t)h * D;
+
+    // zero the V^T rows [D, DV) once (never written by the tile loads)
+    for (int e = tid; e < DV * VROW; e += 256) sV[e] = 0;
+
+    // Q fragments (MFMA B operand: col = query row, k = head-dim)
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    bf16x8 qf[QF][NKS];
+#pragma unroll
+    for (int u = 0; u < QF; ++u) {
+        const int qrow = q0 + u * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int ch = ks * 4 + fg;
+            u32x4 t = (qrow < p.sq && ch < NDC) ? *(const u32x4*)(qb + (int64_t)qrow * p.ldq + ch * 8) : zero4;
+            qf[u][ks] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
+
+    f32x4 acc_o[QF][NFD];
+    float m_run[QF], l_run[QF];
+#pragma unroll
+    for (int u = 0; u < QF; ++u) {
+        m_run[u] = -INFINITY;
+        l_run[u] = 0.f;
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd) acc_o[u][fd] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int kv0 = 0; kv0 < p.skv; kv0 += KT) {
+        __syncthreads();
+        // K tile: [key][DK] row-major (zero beyond D / beyond skv)
+        for (int e = tid; e < KT * (DK / 8); e += 256) {
+            const int key = e / (DK / 8), ch = e - key * (DK / 8);
+            u32x4 t = (kv0 + key < p.skv && ch < NDC)
+                          ? *(const u32x4*)(kb + (int64_t)(kv0 + key) * p.ldk + ch * 8) : zero4;
+            *(u32x4*)(sK + key * KROW + ch * 8) = t;
+        }
+        // V tile transposed: sV[d][key]
+        for (int e = tid; e < KT * NDC; e += 256) {
+            const int key = e / NDC, ch = e - key * NDC;
+            u32x4 t = (kv0 + key < p.skv) ? *(const u32x4*)(vb + (int64_t)(kv0 + key) * p.ldv + ch * 8) : zero4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sV[(ch * 8 + 2 * i) * VROW + key] = (bf16_t)(t[i] & 0xffffu);
+                sV[(ch * 8 + 2 * i + 1) * VROW + key] = (bf16_t)(t[i] >> 16);
+            }
+        }
+        __syncthreads();
+
+        // S^T = K Q^T : lane holds S[q = fr][key = kv0 + 16 f + 4 fg + r]
+        f32x4 acc_s[QF][4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            bf16x8 kf[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                kf[ks] = *(const bf16x8*)(sK + (16 * f + fr) * KROW + (ks * 4 + fg) * 8);
+#pragma unroll
+            for (int u = 0; u < QF; ++u) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) a = mfma16(kf[ks], qf[u][ks], a);
+                acc_s[u][f] = a;
+            }
+        }
+
+        // online softmax per owned query row; P^T operand built in registers
+        u32x4 pw[QF][2];
+        float alpha[QF];
+#pragma unroll
+        for (int u = 0; u < QF; ++u) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kv0 + 16 * f + 4 * fg + r;
+                    float sv = key < p.skv ? acc_s[u][f][r] * p.scale_log2 : -INFINITY;
+                    acc_s[u][f][r] = sv;
+                    mx = fmaxf(mx, sv);
+                }
+            mx = fmaxf(mx, shfl_xor(mx, 16));
+            mx = fmaxf(mx, shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[u], mx);
+            alpha[u] = fast_exp2(m_run[u] - m_new);
+            m_run[u] = m_new;
+            float rs = 0.f;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float e0 = fast_exp2(acc_s[u][f][0] - m_new), e1 = fast_exp2(acc_s[u][f][1] - m_new);
+                float e2 = fast_exp2(acc_s[u][f][2] - m_new), e3 = fast_exp2(acc_s[u][f][3] - m_new);
+                rs += (e0 + e1) + (e2 + e3);
+                pw[u][f >> 1][(f & 1) * 2] = pack_bf2(e0, e1);
+                pw[u][f >> 1][(f & 1) * 2 + 1] = pack_bf2(e2, e3);
+            }
+            l_run[u] = l_run[u] * alpha[u] + rs;
+        }
+
+        // O^T += V^T P^T.  V^T fragment (MFMA A operand: row = d, k = permuted key): MFMA k index
+        // 8*fg + t  <->  tile key 16*(2s + (t>>2)) + 4*fg + (t&3), matching the P^T registers.
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd) {
+#pragma unroll
+            for (int u = 0; u < QF; ++u) {
+                acc_o[u][fd][0] *= alpha[u]; acc_o[u][fd][1] *= alpha[u];
+                acc_o[u][fd][2] *= alpha[u]; acc_o[u][fd][3] *= alpha[u];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16_t* row = sV + (16 * fd + fr) * VROW + 4 * fg;
+                u32x2 lo = *(const u32x2*)(row + 16 * (2 * s));
+                u32x2 hi = *(const u32x2*)(row + 16 * (2 * s + 1));
+                u32x4 t = {lo[0], lo[1], hi[0], hi[1]};
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, t);
+#pragma unroll
+                for (int u = 0; u < QF; ++u)
+                    acc_o[u][fd] = mfma16(vf, __builtin_bit_cast(bf16x8, pw[u][s]), acc_o[u][fd]);
+            }
+        }
+    }
+
+    bf16_t* ob = p.o + (int64_t)b * p.bso + (int64_t)h * D;
+#pragma unroll
+    for (int u = 0; u < QF; ++u) {
+        float l = l_run[u];
+        l += shfl_xor(l, 16);
+        l += shfl_xor(l, 32);
+        const float inv = 1.f / l;
+        const int qrow = q0 + u * 16 + fr;
+        if (qrow < p.sq) {
+#pragma unroll
+            for (int fd = 0; fd < NFD; ++fd) {
+                const int d = 16 * fd + 4 * fg;
+                if (d < D) {
+                    f32x4 o = acc_o[u][fd];
+                    u32x2 w = {pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv)};
+                    *(u32x2*)(ob + (int64_t)qrow * p.ldo + d) = w;
+                }
+            }
+            if (fg == 0 && p.lse)
+                p.lse[((int64_t)b * p.heads + h) * p.sq + qrow] = (m_run[u] + log2f(l)) * 0.6931471805599453f;
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Backward (once per optimizer step, for the LoRA-on "target" pass only).  P is recomputed
+// from the saved LSE; no atomics, deterministic:
+//   attn_delta : delta[q] = sum_d dO[q][d] O[q][d]
+//   attn_bwd_dq : same shape as the forward (a wave owns 16 query rows, K/V stream through
+//                 LDS): S^T = K Q^T, dP^T = V dO^T, dS = P (dP - delta), dQ^T += K^T dS^T.
+//   attn_bwd_dkv: a wave owns 16 keys (K, V fragments live in registers), Q/dO stream through
+//                 LDS in 32-row tiles, both row-major (for S = Q K^T, dP = dO V^T) and
+//                 transposed (for dV^T += dO^T P, dK^T += Q^T dS).
+// The register-resident P / dS accumulators are re-used directly as the second MFMA operand
+// through the same key (resp. query) permutation trick as the forward.
+// ------------------------------------------------------------------------------------------
+struct AttnBwdArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v; const bf16_t* o; const bf16_t* d_o;
+    int64_t ldq, ldk, ldv, ldo, lddo;
+    int64_t bsq, bsk, bsv, bso, bsdo;
+    const float* lse; float* delta;
+    bf16_t* dq; bf16_t* dk; bf16_t* dv;
+    int64_t lddq, lddk, lddv, bsdq, bsdk, bsdv;
+    int heads, sq, skv;
+    float scale, scale_log2;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_delta_kernel(AttnBwdArgs p, int batch) {
+    const int64_t total = (int64_t)batch * p.heads * p.sq;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int qi = (int)(e % p.sq);
+        const int h = (int)((e / p.sq) % p.heads), b = (int)(e / ((int64_t)p.sq * p.heads));
+        const bf16_t* orow = p.o + (int64_t)b * p.bso + (int64_t)qi * p.ldo + h * D;
+        const bf16_t* drow = p.d_o + (int64_t)b * p.bsdo + (int64_t)qi * p.lddo + h * D;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) {
+            u32x4 a = *(const u32x4*)(orow + c * 8), d = *(const u32x4*)(drow + c * 8);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc += bf2f((bf16_t)(a[i] & 0xffffu)) * bf2f((bf16_t)(d[i] & 0xffffu));
+                acc += bf2f((bf16_t)(a[i] >> 16)) * bf2f((bf16_t)(d[i] >> 16));
+            }
+        }
+        p.delta[e] = acc;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+    constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
+    constexpr int NKS = DK / 32, NFD = DV / 16, NDC = D / 8;
+    constexpr int KROW = DK + 8, VROW = KT + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * KT * KROW + DV * VROW];
+    bf16_t* sK = smem;
+    bf16_t* sV = smem + KT * KROW;
+    bf16_t* sKt = smem + 2 * KT * KROW;
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int q0 = (int)blockIdx.x * 64 + wave * 16;
+    const int qrow = q0 + fr;
+    const bool qok = qrow < p.sq;
+
+    const bf16_t* kb = p.k + (int64_t)b * p.bsk + (int64_t)h * D;
+    const bf16_t* vb = p.v + (int64_t)b * p.bsv + (int64_t)h * D;
+    for (int e = tid; e < DV * VROW; e += 256) sKt[e] = 0;
+
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    bf16x8 qf[NKS], dof[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int ch = ks * 4 + fg;
+        const bool ok = qok && ch < NDC;
+        u32x4 t = ok ? *(const u32x4*)(p.q + (int64_t)b * p.bsq + (int64_t)qrow * p.ldq + h * D + ch * 8) : zero4;
+        u32x4 u = ok ? *(const u32x4*)(p.d_o + (int64_t)b * p.bsdo + (int64_t)qrow * p.lddo + h * D + ch * 8) : zero4;
+        qf[ks] = __builtin_bit_cast(bf16x8, t);
+        dof[ks] = __builtin_bit_cast(bf16x8, u);
+    }
+    const int64_t stat = ((int64_t)b * p.heads + h) * p.sq + (qok ? qrow : 0);
+    const float lse2 = p.lse[stat] * 1.4426950408889634f;
+    const float dlt = p.delta[stat];
+
+    f32x4 acc[NFD];
+#pragma unroll
+    for (int fd = 0; fd < NFD; ++fd) acc[fd] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int kv0 = 0; kv0 < p.skv; kv0 += KT) {
+        __syncthreads();
+        for (int e = tid; e < KT * (DK / 8); e += 256) {
+            const int key = e / (DK / 8), ch = e - key * (DK / 8);
+            const bool ok = kv0 + key < p.skv && ch < NDC;
+            u32x4 tk = ok ? *(const u32x4*)(kb + (int64_t)(kv0 + key) * p.ldk + ch * 8) : zero4;
+            u32x4 tv = ok ? *(const u32x4*)(vb + (int64_t)(kv0 + key) * p.ldv + ch * 8) : zero4;
+            *(u32x4*)(sK + key * KROW + ch * 8) = tk;
+            *(u32x4*)(sV + key * KROW + ch * 8) = tv;
+            if (ch < NDC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sKt[(ch * 8 + 2 * i) * VROW + key] = (bf16_t)(tk[i] & 0xffffu);
+                    sKt[(ch * 8 + 2 * i + 1) * VROW + key] = (bf16_t)(tk[i] >> 16);
+                }
+            }
+        }
+        __syncthreads();
+
+        u32x4 pw[2];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(sK + (16 * f + fr) * KROW + (ks * 4 + fg) * 8);
+                const bf16x8 vf = *(const bf16x8*)(sV + (16 * f + fr) * KROW + (ks * 4 + fg) * 8);
+                s = mfma16(kf, qf[ks], s);
+                dp = mfma16(vf, dof[ks], dp);
+            }
+            float ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kv0 + 16 * f + 4 * fg + r;
+                const float pr = key < p.skv ? fast_exp2(s[r] * p.scale_log2 - lse2) : 0.f;
+                ds[r] = pr * (dp[r] - dlt);
+            }
+            pw[f >> 1][(f & 1) * 2] = pack_bf2(ds[0], ds[1]);
+            pw[f >> 1][(f & 1) * 2 + 1] = pack_bf2(ds[2], ds[3]);
+        }
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const bf16_t* row = sKt + (16 * fd + fr) * VROW + 4 * fg;
+                u32x2 lo = *(const u32x2*)(row + 16 * (2 * s2));
+                u32x2 hi = *(const u32x2*)(row + 16 * (2 * s2 + 1));
+                u32x4 t = {lo[0], lo[1], hi[0], hi[1]};
+                acc[fd] = mfma16(__builtin_bit_cast(bf16x8, t), __builtin_bit_cast(bf16x8, pw[s2]), acc[fd]);
+            }
+    }
+    if (qok) {
+        bf16_t* dst = p.dq + (int64_t)b * p.bsdq + (int64_t)qrow * p.lddq + h * D;
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd) {
+            const int d = 16 * fd + 4 * fg;
+            if (d < D) {
+                u32x2 w = {pack_bf2(acc[fd][0] * p.scale, acc[fd][1] * p.scale),
+                           pack_bf2(acc[fd][2] * p.scale, acc[fd][3] * p.scale)};
+                *(u32x2*)(dst + d) = w;
+            }
+        }
+    }
+}
+
+constexpr int QT = 32;  // query rows per tile in the dK/dV kernel
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
+    constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
+    constexpr int NKS = DK / 32, NFD = DV / 16, NDC = D / 8;
+    constexpr int KROW = DK + 8, TROW = QT + 8;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * QT * KROW + 2 * DV * TROW];
+    __shared__ __attribute__((aligned(16))) float sstat[2 * QT];
+    bf16_t* sQ = smem;
+    bf16_t* sDO = smem + QT * KROW;
+    bf16_t* sQt = smem + 2 * QT * KROW;
+    bf16_t* sDOt = sQt + DV * TROW;
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int key = (int)blockIdx.x * 64 + wave * 16 + fr;
+    const bool kok = key < p.skv;
+
+    for (int e = tid; e < 2 * DV * TROW; e += 256) sQt[e] = 0;
+
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    bf16x8 kf[NKS], vf[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+        const int ch = ks * 4 + fg;
+        const bool ok = kok && ch < NDC;
+        u32x4 t = ok ? *(const u32x4*)(p.k + (int64_t)b * p.bsk + (int64_t)key * p.ldk + h * D + ch * 8) : zero4;
+        u32x4 u = ok ? *(const u32x4*)(p.v + (int64_t)b * p.bsv + (int64_t)key * p.ldv + h * D + ch * 8) : zero4;
+        kf[ks] = __builtin_bit_cast(bf16x8, t);
+        vf[ks] = __builtin_bit_cast(bf16x8, u);
+    }
+    f32x4 acc_dk[NFD], acc_dv[NFD];
+#pragma unroll
+    for (int fd = 0; fd < NFD; ++fd) {
+        acc_dk[fd] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc_dv[fd] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const bf16_t* qb = p.q + (int64_t)b * p.bsq + (int64_t)h * D;
+    const bf16_t* dob = p.d_o + (int64_t)b * p.bsdo + (int64_t)h * D;
+    const int64_t stat0 = ((int64_t)b * p.heads + h) * p.sq;
+
+    for (int q0 = 0; q0 < p.sq; q0 += QT) {
+        __syncthreads();
+        for (int e = tid; e < QT * (DK / 8); e += 256) {
+            const int qi = e / (DK / 8), ch = e - qi * (DK / 8);
+            const bool ok = q0 + qi < p.sq && ch < NDC;
+            u32x4 tq = ok ? *(const u32x4*)(qb + (int64_t)(q0 + qi) * p.ldq + ch * 8) : zero4;
+            u32x4 td = ok ? *(const u32x4*)(dob + (int64_t)(q0 + qi) * p.lddo + ch * 8) : zero4;
+            *(u32x4*)(sQ + qi * KROW + ch * 8) = tq;
+            *(u32x4*)(sDO + qi * KROW + ch * 8) = td;
+            if (ch < NDC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    sQt[(ch * 8 + 2 * i) * TROW + qi] = (bf16_t)(tq[i] & 0xffffu);
+                    sQt[(ch * 8 + 2 * i + 1) * TROW + qi] = (bf16_t)(tq[i] >> 16);
+                    sDOt[(ch * 8 + 2 * i) * TROW + qi] = (bf16_t)(td[i] & 0xffffu);
+                    sDOt[(ch * 8 + 2 * i + 1) * TROW + qi] = (bf16_t)(td[i] >> 16);
+                }
+            }
+        }
+        if (tid < QT) {
+            const bool ok = q0 + tid < p.sq;
+            sstat[tid] = ok ? p.lse[stat0 + q0 + tid] * 1.4426950408889634f : 0.f;
+            sstat[QT + tid] = ok ? p.delta[stat0 + q0 + tid] : 0.f;
+        }
+        __syncthreads();
+
+        // S[q][key], dP[q][key]: lane holds q = q0 + 16 f + 4 fg + r for its key (= fr)
+        u32x4 pp, pds;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const bf16x8 aq = *(const bf16x8*)(sQ + (16 * f + fr) * KROW + (ks * 4 + fg) * 8);
+                const bf16x8 ad = *(const bf16x8*)(sDO + (16 * f + fr) * KROW + (ks * 4 + fg) * 8);
+                s = mfma16(aq, kf[ks], s);
+                dp = mfma16(ad, vf[ks], dp);
+            }
+            const f32x4 l4 = *(const f32x4*)(sstat + 16 * f + 4 * fg);
+            const f32x4 d4 = *(const f32x4*)(sstat + QT + 16 * f + 4 * fg);
+            float pr[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = q0 + 16 * f + 4 * fg + r < p.sq;
+                pr[r] = ok ? fast_exp2(s[r] * p.scale_log2 - l4[r]) : 0.f;
+                ds[r] = pr[r] * (dp[r] - d4[r]);
+            }
+            pp[2 * f] = pack_bf2(pr[0], pr[1]);
+            pp[2 * f + 1] = pack_bf2(pr[2], pr[3]);
+            pds[2 * f] = pack_bf2(ds[0], ds[1]);
+            pds[2 * f + 1] = pack_bf2(ds[2], ds[3]);
+        }
+        // dV^T += dO^T P ; dK^T += Q^T dS   (MFMA k index 8 fg + t <-> tile row 16 (t>>2) + 4 fg + (t&3))
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd) {
+            const bf16_t* rq = sQt + (16 * fd + fr) * TROW + 4 * fg;
+            const bf16_t* rd = sDOt + (16 * fd + fr) * TROW + 4 * fg;
+            u32x2 qlo = *(const u32x2*)(rq), qhi = *(const u32x2*)(rq + 16);
+            u32x2 dlo = *(const u32x2*)(rd), dhi = *(const u32x2*)(rd + 16);
+            u32x4 tq = {qlo[0], qlo[1], qhi[0], qhi[1]};
+            u32x4 td = {dlo[0], dlo[1], dhi[0], dhi[1]};
+            acc_dv[fd] = mfma16(__builtin_bit_cast(bf16x8, td), __builtin_bit_cast(bf16x8, pp), acc_dv[fd]);
+            acc_dk[fd] = mfma16(__builtin_bit_cast(bf16x8, tq), __builtin_bit_cast(bf16x8, pds), acc_dk[fd]);
+        }
+    }
+    if (kok) {
+        bf16_t* dkd = p.dk + (int64_t)b * p.bsdk + (int64_t)key * p.lddk + h * D;
+        bf16_t* dvd = p.dv + (int64_t)b * p.bsdv + (int64_t)key * p.lddv + h * D;
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd) {
+            const int d = 16 * fd + 4 * fg;
+            if (d < D) {
+                u32x2 wk = {pack_bf2(acc_dk[fd][0] * p.scale, acc_dk[fd][1] * p.scale),
+                            pack_bf2(acc_dk[fd][2] * p.scale, acc_dk[fd][3] * p.scale)};
+                u32x2 wv = {pack_bf2(acc_dv[fd][0], acc_dv[fd][1]), pack_bf2(acc_dv[fd][2], acc_dv[fd][3])};
+                *(u32x2*)(dkd + d) = wk;
+                *(u32x2*)(dvd + d) = wv;
+            }
+        }
+    }
+}
+
+template <int D>
+int launch_bwd(const AttnBwdArgs& a, int batch, hipStream_t s) {
+    const int64_t rows = (int64_t)batch * a.heads * a.sq;
+    hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, a, batch);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<D>), dim3(cdiv(a.sq, 64), a.heads, batch), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<D>), dim3(cdiv(a.skv, 64), a.heads, batch), dim3(256), 0, s, a);
+    return check_launch("leco_attention_bwd");
+}
+
+template <int D>
+int launch_fwd(const AttnArgs& a, int batch, hipStream_t s) {
+    if (a.sq >= 1024) {
+        hipLaunchKernelGGL((attn_fwd_kernel<D, 2>), dim3(cdiv(a.sq, 128), a.heads, batch), dim3(256), 0, s, a);
+    } else {
+        hipLaunchKernelGGL((attn_fwd_kernel<D, 1>), dim3(cdiv(a.sq, 64), a.heads, batch), dim3(256), 0, s, a);
+    }
+    return check_launch("leco_attention_fwd");
+}
+}  // namespace
+}  // namespace leco
+
+using namespace leco;
+
+extern "C" int leco_attention_fwd(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk,
+                                  int64_t bsk, const void* v, int64_t ldv, int64_t bsv, void* o,
+                                  int64_t ldo, int64_t bso, float* lse, int32_t batch, int32_t heads,
+                                  int32_t sq, int32_t skv, int32_t head_dim, float scale,
+                                  leco_stream_t stream) {
+    if (batch <= 0 || heads <= 0 || sq <= 0 || skv <= 0) return fail(-EINVAL, "attention: empty problem");
+    if ((ldq | ldk | ldv | ldo | bsq | bsk | bsv | bso) % 8) return fail(-EINVAL, "attention: strides must be multiples of 8 elements");
+    AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, bsq, bsk, bsv,
+               (bf16_t*)o, ldo, bso, lse, heads, sq, skv, scale * 1.4426950408889634f};
+    hipStream_t s = (hipStream_t)stream;
+    switch (head_dim) {
+        case 32: return launch_fwd<32>(a, batch, s);
+        case 40: return launch_fwd<40>(a, batch, s);
+        case 64: return launch_fwd<64>(a, batch, s);
+        case 80: return launch_fwd<80>(a, batch, s);
+        case 160: return launch_fwd<160>(a, batch, s);
+        default: return fail(-EINVAL, "attention: unsupported head_dim %d (32/40/64/80/160)", head_dim);
+    }
+}
+
+extern "C" int leco_attention_bwd(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk,
+                                  int64_t bsk, const void* v, int64_t ldv, int64_t bsv, const void* o,
+                                  int64_t ldo, int64_t bso, const void* d_o, int64_t lddo, int64_t bsdo,
+                                  const float* lse, float* delta, void* dq, int64_t lddq, int64_t bsdq,
+                                  void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv,
+                                  int64_t bsdv, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                                  int32_t head_dim, float scale, leco_stream_t stream) {
+    if (batch <= 0 || heads <= 0 || sq <= 0 || skv <= 0) return fail(-EINVAL, "attention_bwd: empty problem");
+    if ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv | bsq | bsk | bsv | bso | bsdo | bsdq | bsdk | bsdv) % 4)
+        return fail(-EINVAL, "attention_bwd: strides must be multiples of 4 elements");
+    AttnBwdArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
+                  ldq, ldk, ldv, ldo, lddo, bsq, bsk, bsv, bso, bsdo, lse, delta,
+                  (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, bsdq, bsdk, bsdv,
+                  heads, sq, skv, scale, scale * 1.4426950408889634f};
+    hipStream_t s = (hipStream_t)stream;
+    switch (head_dim) {
+        case 32: return launch_bwd<32>(a, batch, s);
+        case 40: return launch_bwd<40>(a, batch, s);
+        case 64: return launch_bwd<64>(a, batch, s);
+        case 80: return launch_bwd<80>(a, batch, s);
+        case 160: return launch_bwd<160>(a, batch, s);
+        default: return fail(-EINVAL, "attention_bwd: unsupported head_dim %d", head_dim);
+    }
+}

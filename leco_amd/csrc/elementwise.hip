@@ -1,0 +1,491 @@
+// HBM-bound elementwise / small kernels of the LECO step: GEGLU, conv_in / conv_out (the two
+// convolutions that are not GEMM-shaped: Cin = 4 and Cout = 4), timestep sinusoid, gradient adds,
+// 2x2 upsample dgrad, CFG-combine + DDIM update, ESD loss + its gradient, fused AdamW.
+// All bf16 traffic is moved as 16-byte vectors (8 x bf16 per lane); latent-sized tensors
+// ((bs,4,h,w), a few hundred KB) stay fp32.
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <leco_prims.h>
+#include <math.h>
+
+#include "common.h"
+
+namespace leco {
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = bf2f((bf16_t)(v[i] & 0xffffu));
+        f[2 * i + 1] = bf2f((bf16_t)(v[i] >> 16));
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.7071067811865476f)); }
+__device__ __forceinline__ float dgelu_erf(float x) {
+    return 0.5f * (1.f + erff(x * 0.7071067811865476f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+inline int grid_for(int64_t n_items) {
+    int64_t g = (n_items + 255) / 256;
+    return (int)(g < 1 ? 1 : (g > 8192 ? 8192 : g));
+}
+
+// ---- GEGLU: y = a * gelu(g), u = [a | g] -----------------------------------------------------
+__global__ __launch_bounds__(256) void geglu_fwd_kernel(const bf16_t* u, int64_t ldu, bf16_t* y, int64_t ldy,
+                                                         int M, int F) {
+    const int nv = F / 8;
+    const int64_t total = (int64_t)M * nv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / nv;
+        const int c = (int)(e - r * nv) * 8;
+        float a[8], g[8], o[8];
+        unpack8(*(const u32x4*)(u + r * ldu + c), a);
+        unpack8(*(const u32x4*)(u + r * ldu + F + c), g);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = a[i] * gelu_erf(g[i]);
+        *(u32x4*)(y + r * ldy + c) = pack8(o);
+    }
+}
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* u, int64_t ldu, const bf16_t* dy,
+                                                         int64_t lddy, bf16_t* du, int64_t lddu, int M, int F) {
+    const int nv = F / 8;
+    const int64_t total = (int64_t)M * nv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / nv;
+        const int c = (int)(e - r * nv) * 8;
+        float a[8], g[8], d[8], da[8], dg[8];
+        unpack8(*(const u32x4*)(u + r * ldu + c), a);
+        unpack8(*(const u32x4*)(u + r * ldu + F + c), g);
+        unpack8(*(const u32x4*)(dy + r * lddy + c), d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            da[i] = d[i] * gelu_erf(g[i]);
+            dg[i] = d[i] * a[i] * dgelu_erf(g[i]);
+        }
+        *(u32x4*)(du + r * lddu + c) = pack8(da);
+        *(u32x4*)(du + r * lddu + F + c) = pack8(dg);
+    }
+}
+
+// ---- out = a + b (+ c), row-strided bf16 -------------------------------------------------------
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* a, int64_t lda, const bf16_t* b, int64_t ldb,
+                                                   const bf16_t* c, int64_t ldc, bf16_t* o, int64_t ldo, int M,
+                                                   int C) {
+    const int nv = C / 8;
+    const int64_t total = (int64_t)M * nv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / nv;
+        const int col = (int)(e - r * nv) * 8;
+        float x[8], y[8];
+        unpack8(*(const u32x4*)(a + r * lda + col), x);
+        unpack8(*(const u32x4*)(b + r * ldb + col), y);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] += y[i];
+        if (c) {
+            unpack8(*(const u32x4*)(c + r * ldc + col), y);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] += y[i];
+        }
+        *(u32x4*)(o + r * ldo + col) = pack8(x);
+    }
+}
+
+// ---- dgrad of nearest-2x upsample: dx[b][y][x][c] = sum of the 2x2 block of dy --------------------
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* dy, bf16_t* dx, int B, int H, int W,
+                                                            int C) {
+    const int nv = C / 8;
+    const int64_t total = (int64_t)B * H * W * nv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t pix = e / nv;
+        const int col = (int)(e - pix * nv) * 8;
+        const int x = (int)(pix % W), y = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t[8];
+#pragma unroll
+        for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+            for (int dx_ = 0; dx_ < 2; ++dx_) {
+                const int64_t src = ((int64_t)(b * 2 * H + 2 * y + dy_) * (2 * W) + 2 * x + dx_) * C + col;
+                unpack8(*(const u32x4*)(dy + src), t);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += t[i];
+            }
+        *(u32x4*)(dx + pix * C + col) = pack8(acc);
+    }
+}
+
+// ---- conv_in: 3x3 pad 1, Cin (<=8) -> Cout, NCHW bf16 in, channels-last bf16 out -------------------
+// weights fp32 [Cout][Cin][3][3] (PyTorch layout), bias fp32.
+__global__ __launch_bounds__(256) void conv_in_kernel(const bf16_t* x, const float* w, const float* bias,
+                                                       bf16_t* y, int B, int H, int W, int Cin, int Cout) {
+    const int nv = Cout / 8;
+    const int64_t total = (int64_t)B * H * W * nv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t pix = e / nv;
+        const int co = (int)(e - pix * nv) * 8;
+        const int px = (int)(pix % W), py = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = bias[co + i];
+        for (int c = 0; c < Cin; ++c)
+            for (int kh = 0; kh < 3; ++kh) {
+                const int iy = py + kh - 1;
+                if (iy < 0 || iy >= H) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ix = px + kw - 1;
+                    if (ix < 0 || ix >= W) continue;
+                    const float xv = bf2f(x[((int64_t)(b * Cin + c) * H + iy) * W + ix]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i] += xv * w[((co + i) * Cin + c) * 9 + kh * 3 + kw];
+                }
+            }
+        *(u32x4*)(y + pix * Cout + co) = pack8(acc);
+    }
+}
+
+// ---- conv_out: 3x3 pad 1, C -> Cout (4), channels-last bf16 in, NCHW fp32 out ------------------------
+// one wave per output pixel; weights bf16 [Cout][3][3][C]; lanes split C in vectors of 8.
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const bf16_t* w, const float* bias,
+                                                        float* y, int B, int H, int W, int C) {
+    const int lane = lane_id();
+    const int64_t pix = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t npix = (int64_t)B * H * W;
+    const bool live = pix < npix;
+    const int64_t pp = live ? pix : 0;
+    const int px = (int)(pp % W), py = (int)((pp / W) % H), b = (int)(pp / ((int64_t)W * H));
+    const int nv = C / 8;
+    float acc[COUT];
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;  // wave-uniform
+        const bf16_t* xr = x + ((int64_t)(b * H + iy) * W + ix) * C;
+        for (int v = lane; v < nv; v += 64) {
+            float xv[8], wv[8];
+            unpack8(*(const u32x4*)(xr + v * 8), xv);
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                unpack8(*(const u32x4*)(w + ((int64_t)(o * 9 + tap)) * C + v * 8), wv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[o] += xv[i] * wv[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[o] += shfl_xor(acc[o], m);
+    }
+    if (live && lane == 0) {
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) y[((int64_t)(b * COUT + o) * H + py) * W + px] = acc[o] + bias[o];
+    }
+}
+
+// dgrad of conv_out: dx[pix][c] = sum_{tap,o} dy[b][o][pix - off(tap)] * w[o][tap][c]
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_out_bwd_kernel(const float* dy, const bf16_t* w, bf16_t* dx, int B,
+                                                            int H, int W, int C) {
+    const int nv = C / 8;
+    const int64_t total = (int64_t)B * H * W * nv;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t pix = e / nv;
+        const int c = (int)(e - pix * nv) * 8;
+        const int px = (int)(pix % W), py = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int tap = 0; tap < 9; ++tap) {
+            // output pixel (oy, ox) used input (py, px) through tap iff oy + kh - 1 = py
+            const int oy = py - (tap / 3 - 1), ox = px - (tap % 3 - 1);
+            if (oy < 0 || oy >= H || ox < 0 || ox >= W) continue;
+#pragma unroll
+            for (int o = 0; o < COUT; ++o) {
+                const float d = dy[((int64_t)(b * COUT + o) * H + oy) * W + ox];
+                float wv[8];
+                unpack8(*(const u32x4*)(w + ((int64_t)(o * 9 + tap)) * C + c), wv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] += d * wv[i];
+            }
+        }
+        *(u32x4*)(dx + pix * C + c) = pack8(acc);
+    }
+}
+
+// ---- timestep sinusoid: out[i] = [cos(t_i f) | sin(t_i f)], f_j = exp(-ln(1e4) j / half) -------------
+__global__ void timestep_embedding_kernel(const float* t_table, const int* idx, int t_stride, int n, int dim,
+                                          bf16_t* out) {
+    const int half = dim / 2;
+    const int base = idx ? *idx : 0;
+    for (int e = (int)(blockIdx.x * blockDim.x + threadIdx.x); e < n * half; e += (int)(gridDim.x * blockDim.x)) {
+        const int i = e / half, j = e - i * half;
+        const float t = t_table[base + i * t_stride];
+        const float f = expf(-9.210340371976184f * (float)j / (float)half);
+        const float a = t * f;
+        out[i * dim + j] = f2bf(cosf(a));
+        out[i * dim + half + j] = f2bf(sinf(a));
+    }
+}
+
+__global__ void advance_kernel(int* counter) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *counter += 1;
+}
+
+// ---- CFG combine + DDIM update (train_util.py:163-166,190; DDIM eta = 0 is linear in (x, model_out)) ----
+// pred: fp32 [2*bs][n] raw UNet output (uncond half first); x: fp32 [bs][n] latents, updated in place;
+// x2: bf16 [2*bs][n] next UNet input = cat([x]*2).  coef[step] = {c_x, c_e}.
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* pred, float* x, bf16_t* x2, const float* coef,
+                                                        const int* step, float guidance, int64_t half_n) {
+    const int st = step ? *step : 0;
+    const float cx = coef[2 * st], ce = coef[2 * st + 1];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < half_n; e += (int64_t)gridDim.x * 256) {
+        const float u = pred[e], c = pred[half_n + e];
+        const float eps = u + guidance * (c - u);
+        const float xn = cx * x[e] + ce * eps;
+        x[e] = xn;
+        const bf16_t hb = f2bf(xn);
+        x2[e] = hb;
+        x2[half_n + e] = hb;
+    }
+}
+
+// ---- ESD loss (prompt_util.py:107-135 with MSELoss, train_lora.py:96,265-270) and d loss / d target-pass output --
+// each *_pred is the raw fp32 [2*bs][n] UNet output; guided = u + g_pred*(c - u) (train_util.py:163-166).
+// target_goal = neutral + sign * g_loss * (positive - unconditional); loss = mean((target - goal)^2).
+// dpred[2*bs][n]: d loss / d raw target output = {(1-g_pred) * d, g_pred * d}, d = 2 (target-goal)/N.
+__global__ __launch_bounds__(256) void esd_loss_kernel(const float* tgt, const float* pos, const float* neu,
+                                                        const float* unc, float g_pred, float g_loss, float sign,
+                                                        int64_t half_n, float* loss, float* dpred) {
+    __shared__ float red[4];
+    float part = 0.f;
+    const float inv_n = 1.f / (float)half_n;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < half_n; e += (int64_t)gridDim.x * 256) {
+        const float t = tgt[e] + g_pred * (tgt[half_n + e] - tgt[e]);
+        const float p = pos[e] + g_pred * (pos[half_n + e] - pos[e]);
+        const float n = neu[e] + g_pred * (neu[half_n + e] - neu[e]);
+        const float u = unc[e] + g_pred * (unc[half_n + e] - unc[e]);
+        const float goal = n + sign * g_loss * (p - u);
+        const float diff = t - goal;
+        part += diff * diff;
+        if (dpred) {
+            const float d = 2.f * diff * inv_n;
+            dpred[e] = (1.f - g_pred) * d;
+            dpred[half_n + e] = g_pred * d;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) part += shfl_xor(part, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+}
+
+// ---- fused AdamW over the flat LoRA slab (torch.optim.AdamW semantics, train_lora.py:280) ----------------
+// hyper (device fp32): {lr, bias_correction1, bias_correction2, grad_scale}
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, bf16_t* shadow,
+                                                     const float* hyper, float beta1, float beta2, float eps,
+                                                     float wd, int64_t n) {
+    const float lr = hyper[0], bc1 = hyper[1], bc2 = hyper[2], gs = hyper[3];
+    const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float gr = g[e] * gs;
+        float pv = p[e] * (1.f - lr * wd);
+        const float mm = beta1 * m[e] + (1.f - beta1) * gr;
+        const float vv = beta2 * v[e] + (1.f - beta2) * gr * gr;
+        const float denom = sqrtf(vv) * inv_sqrt_bc2 + eps;
+        pv -= step_size * mm / denom;
+        p[e] = pv;
+        m[e] = mm;
+        v[e] = vv;
+        shadow[e] = f2bf(pv);
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* x, bf16_t* y, int64_t n) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) y[e] = f2bf(x[e]);
+}
+
+// ---- LoRA operand packing (see leco_hip.h) -------------------------------------------------------------
+__global__ __launch_bounds__(256) void lora_pack_kernel(const leco_lora_site* sites) {
+    const leco_lora_site s = sites[blockIdx.y];
+    const int R = s.groups * s.r, R16 = (R + 15) / 16 * 16, Rp = (R + 31) / 32 * 32;
+    const int gn = s.n / s.groups;
+    const int64_t n0 = (int64_t)R16 * s.k, n1 = (int64_t)s.n * Rp, n2 = (int64_t)R16 * s.n, n3 = (int64_t)s.k * Rp;
+    bf16_t* dn_s = (bf16_t*)s.dn_s;
+    bf16_t* up_p = (bf16_t*)s.up_p;
+    bf16_t* up_t = (bf16_t*)s.up_t;
+    bf16_t* dn_p = (bf16_t*)s.dn_p;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n0 + n1 + n2 + n3; e += (int64_t)gridDim.x * 256) {
+        if (e < n0) {  // dn_s[j][k] = down[g][jj][k]
+            const int j = (int)(e / s.k), k = (int)(e - (int64_t)j * s.k);
+            bf16_t val = 0;
+            if (j < R) val = ((const bf16_t*)s.down[j / s.r])[(int64_t)(j % s.r) * s.k + k];
+            dn_s[e] = val;
+        } else if (e < n0 + n1) {  // up_p[n][j] = scale * up[g][n - g*gn][jj] if j in group(n)
+            const int64_t t = e - n0;
+            const int n = (int)(t / Rp), j = (int)(t - (int64_t)n * Rp), g = n / gn;
+            float val = 0.f;
+            if (j >= g * s.r && j < (g + 1) * s.r)
+                val = s.scale * bf2f(((const bf16_t*)s.up[g])[(int64_t)(n - g * gn) * s.r + (j - g * s.r)]);
+            up_p[t] = f2bf(val);
+        } else if (e < n0 + n1 + n2) {  // up_t[j][n] = up[g][n - g*gn][jj] if group(n) == j / r
+            const int64_t t = e - n0 - n1;
+            const int j = (int)(t / s.n), n = (int)(t - (int64_t)j * s.n), g = n / gn;
+            bf16_t val = 0;
+            if (j < R && j / s.r == g) val = ((const bf16_t*)s.up[g])[(int64_t)(n - g * gn) * s.r + (j % s.r)];
+            up_t[t] = val;
+        } else {  // dn_p[k][j] = scale * down[g][jj][k]
+            const int64_t t = e - n0 - n1 - n2;
+            const int k = (int)(t / Rp), j = (int)(t - (int64_t)k * Rp);
+            float val = 0.f;
+            if (j < R) val = s.scale * bf2f(((const bf16_t*)s.down[j / s.r])[(int64_t)(j % s.r) * s.k + k]);
+            dn_p[t] = f2bf(val);
+        }
+    }
+}
+
+// ---- LoRA weight gradients: G[j][c] += scale * sum_m P[m][j] Q[m][c] -----------------------------------
+// block = 256 threads: thread owns column c of a 256-wide column tile; blockIdx.y walks 256-row slabs of M;
+// P slab staged in LDS (fp32).  r <= 16.
+constexpr int WG_ROWS = 256;
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_t ldp, const bf16_t* Q, int64_t ldq,
+                                                          float* G, int64_t g_sj, int64_t g_sc, int M, int r,
+                                                          int cols, float scale) {
+    __shared__ float sp[WG_ROWS * 16];
+    const int tid = (int)threadIdx.x;
+    const int c = (int)blockIdx.x * 256 + tid;
+    const int m0 = (int)blockIdx.y * WG_ROWS;
+    const int rows = min(WG_ROWS, M - m0);
+    for (int e = tid; e < rows * r; e += 256) {
+        const int mm = e / r, j = e - mm * r;
+        sp[mm * 16 + j] = bf2f(P[(int64_t)(m0 + mm) * ldp + j]);
+    }
+    __syncthreads();
+    if (c >= cols) return;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int mm = 0; mm < rows; ++mm) {
+        const float q = bf2f(Q[(int64_t)(m0 + mm) * ldq + c]);
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (j < r) acc[j] += sp[mm * 16 + j] * q;
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        if (j < r) atomicAdd(&G[j * g_sj + c * g_sc], acc[j] * scale);
+}
+}  // namespace
+}  // namespace leco
+
+using namespace leco;
+#define LECO_STREAM ((hipStream_t)stream)
+
+extern "C" int leco_geglu_fwd(const void* u, int64_t ldu, void* y, int64_t ldy, int32_t m, int32_t f,
+                              leco_stream_t stream) {
+    if (f % 8) return fail(-EINVAL, "geglu: F=%d %% 8 != 0", f);
+    hipLaunchKernelGGL(geglu_fwd_kernel, dim3(grid_for((int64_t)m * f / 8)), dim3(256), 0, LECO_STREAM,
+                       (const bf16_t*)u, ldu, (bf16_t*)y, ldy, m, f);
+    return check_launch("leco_geglu_fwd");
+}
+extern "C" int leco_geglu_bwd(const void* u, int64_t ldu, const void* dy, int64_t lddy, void* du, int64_t lddu,
+                              int32_t m, int32_t f, leco_stream_t stream) {
+    if (f % 8) return fail(-EINVAL, "geglu: F=%d %% 8 != 0", f);
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid_for((int64_t)m * f / 8)), dim3(256), 0, LECO_STREAM,
+                       (const bf16_t*)u, ldu, (const bf16_t*)dy, lddy, (bf16_t*)du, lddu, m, f);
+    return check_launch("leco_geglu_bwd");
+}
+extern "C" int leco_add(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc,
+                        void* out, int64_t ldo, int32_t m, int32_t cols, leco_stream_t stream) {
+    if (cols % 8) return fail(-EINVAL, "add: cols=%d %% 8 != 0", cols);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for((int64_t)m * cols / 8)), dim3(256), 0, LECO_STREAM,
+                       (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (const bf16_t*)c, ldc, (bf16_t*)out, ldo, m, cols);
+    return check_launch("leco_add");
+}
+extern "C" int leco_upsample2x_bwd(const void* dy, void* dx, int32_t batch, int32_t h, int32_t w, int32_t c,
+                                   leco_stream_t stream) {
+    if (c % 8) return fail(-EINVAL, "upsample_bwd: C=%d %% 8 != 0", c);
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for((int64_t)batch * h * w * c / 8)), dim3(256), 0, LECO_STREAM,
+                       (const bf16_t*)dy, (bf16_t*)dx, batch, h, w, c);
+    return check_launch("leco_upsample2x_bwd");
+}
+extern "C" int leco_conv_in(const void* x, const float* w, const float* bias, void* y, int32_t batch, int32_t h,
+                            int32_t wd, int32_t cin, int32_t cout, leco_stream_t stream) {
+    if (cout % 8) return fail(-EINVAL, "conv_in: Cout=%d %% 8 != 0", cout);
+    hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for((int64_t)batch * h * wd * cout / 8)), dim3(256), 0, LECO_STREAM,
+                       (const bf16_t*)x, w, bias, (bf16_t*)y, batch, h, wd, cin, cout);
+    return check_launch("leco_conv_in");
+}
+extern "C" int leco_conv_out(const void* x, const void* w, const float* bias, float* y, int32_t batch, int32_t h,
+                             int32_t wd, int32_t c, int32_t cout, leco_stream_t stream) {
+    if (cout != 4 || c % 8) return fail(-EINVAL, "conv_out: needs Cout=4 (got %d), C %% 8 == 0", cout);
+    const int64_t npix = (int64_t)batch * h * wd;
+    hipLaunchKernelGGL((conv_out_kernel<4>), dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, LECO_STREAM,
+                       (const bf16_t*)x, (const bf16_t*)w, bias, y, batch, h, wd, c);
+    return check_launch("leco_conv_out");
+}
+extern "C" int leco_conv_out_bwd(const float* dy, const void* w, void* dx, int32_t batch, int32_t h, int32_t wd,
+                                 int32_t c, int32_t cout, leco_stream_t stream) {
+    if (cout != 4 || c % 8) return fail(-EINVAL, "conv_out_bwd: needs Cout=4, C %% 8 == 0");
+    hipLaunchKernelGGL((conv_out_bwd_kernel<4>), dim3(grid_for((int64_t)batch * h * wd * c / 8)), dim3(256), 0,
+                       LECO_STREAM, dy, (const bf16_t*)w, (bf16_t*)dx, batch, h, wd, c);
+    return check_launch("leco_conv_out_bwd");
+}
+extern "C" int leco_timestep_embedding(const float* t_table, const int32_t* idx, int32_t t_stride, int32_t n,
+                                       int32_t dim, void* out, leco_stream_t stream) {
+    if (dim % 2) return fail(-EINVAL, "timestep_embedding: odd dim");
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv((long)n * dim / 2, 256)), dim3(256), 0, LECO_STREAM,
+                       t_table, (const int*)idx, t_stride, n, dim, (bf16_t*)out);
+    return check_launch("leco_timestep_embedding");
+}
+extern "C" int leco_advance(int32_t* counter, leco_stream_t stream) {
+    hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, LECO_STREAM, (int*)counter);
+    return check_launch("leco_advance");
+}
+extern "C" int leco_cfg_ddim_step(const float* pred, float* x, void* x2, const float* coef, const int32_t* step,
+                                  float guidance, int64_t half_n, leco_stream_t stream) {
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for(half_n)), dim3(256), 0, LECO_STREAM, pred, x, (bf16_t*)x2,
+                       coef, (const int*)step, guidance, half_n);
+    return check_launch("leco_cfg_ddim_step");
+}
+extern "C" int leco_esd_loss(const float* tgt, const float* pos, const float* neu, const float* unc, float g_pred,
+                             float g_loss, float sign, int64_t half_n, float* loss, float* dpred,
+                             leco_stream_t stream) {
+    (void)hipMemsetAsync(loss, 0, sizeof(float), LECO_STREAM);
+    hipLaunchKernelGGL(esd_loss_kernel, dim3(grid_for(half_n) > 256 ? 256 : grid_for(half_n)), dim3(256), 0,
+                       LECO_STREAM, tgt, pos, neu, unc, g_pred, g_loss, sign, half_n, loss, dpred);
+    return check_launch("leco_esd_loss");
+}
+extern "C" int leco_adamw(float* p, const float* g, float* m, float* v, void* shadow, const float* hyper,
+                          float beta1, float beta2, float eps, float wd, int64_t n, leco_stream_t stream) {
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, LECO_STREAM, p, g, m, v, (bf16_t*)shadow,
+                       hyper, beta1, beta2, eps, wd, n);
+    return check_launch("leco_adamw");
+}
+extern "C" int leco_cast_f32_bf16(const float* x, void* y, int64_t n, leco_stream_t stream) {
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, LECO_STREAM, x, (bf16_t*)y, n);
+    return check_launch("leco_cast_f32_bf16");
+}
+extern "C" int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream) {
+    hipError_t e = hipMemsetAsync(p, value, (size_t)bytes, LECO_STREAM);
+    if (e != hipSuccess) return fail(-EIO, "leco_memset: %s", hipGetErrorString(e));
+    return 0;
+}
+extern "C" int leco_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_stream_t stream) {
+    if (nsites <= 0) return 0;
+    hipLaunchKernelGGL(lora_pack_kernel, dim3(64, (unsigned)nsites), dim3(256), 0, LECO_STREAM, sites);
+    return check_launch("leco_lora_pack");
+}
+extern "C" int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj,
+                               int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
+                               leco_stream_t stream) {
+    if (r <= 0 || r > 16) return fail(-EINVAL, "lora_wgrad: rank %d unsupported (1..16)", r);
+    hipLaunchKernelGGL(lora_wgrad_kernel, dim3(cdiv(cols, 256), cdiv(m, WG_ROWS)), dim3(256), 0, LECO_STREAM,
+                       (const bf16_t*)p, ldp, (const bf16_t*)q, ldq, g, g_sj, g_sc, m, r, cols, scale);
+    return check_launch("leco_lora_wgrad");
+}

@@ -1,0 +1,338 @@
+// GroupNorm(32)(+SiLU) and LayerNorm, forward and dgrad, channels-last bf16.
+// HBM-bound: every kernel moves 16-byte (8 x bf16) vectors per lane; statistics are fp32.
+//
+// GroupNorm on [B][HW][C] with G groups of cg = C/G adjacent channels:
+//   gn_stats : per (sample, pixel-range) block; each thread owns 8 adjacent channels, sums
+//              x and x^2 over its pixels, folds them into per-group LDS bins, then one fp32
+//              atomicAdd pair per (block, group) into stats[b][g] = {sum, sumsq}.
+//   gn_apply : y = act((x - mean) * rstd * gamma + beta), act = SiLU or identity.
+// The input may be the channel-concat of two tensors (UNet skip connections): channels
+// [0,c0) come from x0, [c0,C) from x1 -- the concat is never materialised.
+// Backward (frozen gamma/beta => dgrad only): gn_bwd_stats accumulates {sum dxhat, sum dxhat*xhat}
+// per (b,g), gn_bwd_apply forms dx = rstd*(dxhat - s1/n - xhat*s2/n).
+//
+// LayerNorm over the last dim (C <= 2048): one wave64 per row, two-pass statistics held in
+// registers, wave-shuffle reductions.
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <leco_prims.h>
+
+#include "common.h"
+
+namespace leco {
+namespace {
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = bf2f((bf16_t)(v[i] & 0xffffu));
+        f[2 * i + 1] = bf2f((bf16_t)(v[i] >> 16));
+    }
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+__device__ __forceinline__ float silu(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float dsilu(float z) {
+    float s = 1.f / (1.f + __expf(-z));
+    return s * (1.f + z * (1.f - s));
+}
+
+struct GnSrc {
+    const bf16_t* x0;
+    const bf16_t* x1;
+    int64_t ld0, ld1;
+    int c0;  // channels served by x0
+};
+__device__ __forceinline__ u32x4 gn_load(const GnSrc& s, int64_t row, int c) {
+    return c < s.c0 ? *(const u32x4*)(s.x0 + row * s.ld0 + c) : *(const u32x4*)(s.x1 + row * s.ld1 + (c - s.c0));
+}
+
+constexpr int GN_MAX_GROUPS = 32;
+
+// MODE 0: forward stats of x.  MODE 1: backward stats (needs dy, fwd stats, gamma, beta).
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc src, const bf16_t* dy, int64_t lddy,
+                                                        const float* fstats, const float* gamma,
+                                                        const float* beta, int act, float eps, int hw,
+                                                        int C, int G, int pix_per_block, float* stats) {
+    __shared__ float bins[GN_MAX_GROUPS * 2];
+    const int tid = (int)threadIdx.x;
+    const int b = (int)blockIdx.y;
+    const int p0 = (int)blockIdx.x * pix_per_block;
+    const int p1 = min(p0 + pix_per_block, hw);
+    const int nvec = C / 8, cg = C / G;
+    const int cols = nvec < 256 ? nvec : 256, rows_par = 256 / cols;
+    if (tid < 2 * GN_MAX_GROUPS) bins[tid] = 0.f;
+    __syncthreads();
+    const float inv_n = 1.f / ((float)hw * (float)cg);
+    if (tid < rows_par * cols) {
+        const int r = tid / cols;
+        for (int v = tid - r * cols; v < nvec; v += cols) {
+            const int c = v * 8;
+            float s1[8], s2[8], ga[8], be[8], mu[8], rs[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+            if (MODE == 1) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    int g = (c + i) / cg;
+                    float m = fstats[(b * G + g) * 2] * inv_n;
+                    float var = fstats[(b * G + g) * 2 + 1] * inv_n - m * m;
+                    mu[i] = m;
+                    rs[i] = rsqrtf(fmaxf(var, 0.f) + eps);
+                    ga[i] = gamma[c + i];
+                    be[i] = beta[c + i];
+                }
+            }
+            for (int p = p0 + r; p < p1; p += rows_par) {
+                const int64_t row = (int64_t)b * hw + p;
+                float x[8];
+                unpack8(gn_load(src, row, c), x);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { s1[i] += x[i]; s2[i] += x[i] * x[i]; }
+                } else {
+                    float d[8];
+                    unpack8(*(const u32x4*)(dy + row * lddy + c), d);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        float xh = (x[i] - mu[i]) * rs[i];
+                        float dz = d[i];
+                        if (act) dz *= dsilu(xh * ga[i] + be[i]);
+                        float dxh = dz * ga[i];
+                        s1[i] += dxh;
+                        s2[i] += dxh * xh;
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int g = (c + i) / cg;
+                atomicAdd(&bins[2 * g], s1[i]);
+                atomicAdd(&bins[2 * g + 1], s2[i]);
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * G) atomicAdd(&stats[(int64_t)b * G * 2 + tid], bins[tid]);
+}
+
+// MODE 0: forward apply.  MODE 1: backward apply (dx).
+template <int MODE>
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc src, const bf16_t* dy, int64_t lddy,
+                                                        const float* fstats, const float* bstats,
+                                                        const float* gamma, const float* beta, int act,
+                                                        float eps, int hw, int C, int G, int64_t total_vec,
+                                                        bf16_t* out, int64_t ldo) {
+    const int nvec = C / 8, cg = C / G;
+    const float inv_n = 1.f / ((float)hw * (float)cg);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total_vec; e += (int64_t)gridDim.x * 256) {
+        const int64_t row = e / nvec;
+        const int c = (int)(e - row * nvec) * 8;
+        const int b = (int)(row / hw);
+        float x[8], o[8], d[8];
+        unpack8(gn_load(src, row, c), x);
+        if (MODE == 1) unpack8(*(const u32x4*)(dy + row * lddy + c), d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = (c + i) / cg;
+            const float m = fstats[(b * G + g) * 2] * inv_n;
+            const float var = fstats[(b * G + g) * 2 + 1] * inv_n - m * m;
+            const float rs = rsqrtf(fmaxf(var, 0.f) + eps);
+            const float xh = (x[i] - m) * rs;
+            const float ga = gamma[c + i], be = beta[c + i];
+            if (MODE == 0) {
+                float z = xh * ga + be;
+                o[i] = act ? silu(z) : z;
+            } else {
+                float dz = d[i];
+                if (act) dz *= dsilu(xh * ga + be);
+                const float dxh = dz * ga;
+                const float s1 = bstats[(b * G + g) * 2] * inv_n, s2 = bstats[(b * G + g) * 2 + 1] * inv_n;
+                o[i] = rs * (dxh - s1 - xh * s2);
+            }
+        }
+        *(u32x4*)(out + row * ldo + c) = pack8(o);
+    }
+}
+
+constexpr int LN_MAXV = 4;  // vectors of 8 per lane => C <= 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, int64_t ldx, const float* gamma,
+                                                      const float* beta, float eps, int M, int C,
+                                                      bf16_t* y, int64_t ldy, float* mean, float* rstd) {
+    const int lane = lane_id();
+    const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int nvec = C / 8;
+    const bool live = row < M;
+    const int64_t r = live ? row : 0;
+    float v[LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int vv = lane + 64 * j;
+        if (vv < nvec) {
+            unpack8(*(const u32x4*)(x + r * ldx + vv * 8), v[j]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[j][i];
+        }
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        if (lane + 64 * j < nvec) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { float d = v[j][i] - mu; ss += d * d; }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(ss) / (float)C + eps);
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int vv = lane + 64 * j;
+        if (vv < nvec) {
+            float o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (v[j][i] - mu) * rs * gamma[vv * 8 + i] + beta[vv * 8 + i];
+            *(u32x4*)(y + r * ldy + vv * 8) = pack8(o);
+        }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)) (+ dres), dxhat = dy * gamma
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, int64_t ldx, const bf16_t* dy,
+                                                      int64_t lddy, const float* gamma, const float* mean,
+                                                      const float* rstd, const bf16_t* dres, int64_t ldres,
+                                                      int M, int C, bf16_t* dx, int64_t lddx) {
+    const int lane = lane_id();
+    const int row = (int)blockIdx.x * 4 + ((int)threadIdx.x >> 6);
+    const int nvec = C / 8;
+    const bool live = row < M;
+    const int64_t r = live ? row : 0;
+    const float mu = mean[r], rs = rstd[r];
+    float xh[LN_MAXV][8], dh[LN_MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int vv = lane + 64 * j;
+        if (vv < nvec) {
+            float xv[8], dv[8];
+            unpack8(*(const u32x4*)(x + r * ldx + vv * 8), xv);
+            unpack8(*(const u32x4*)(dy + r * lddy + vv * 8), dv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                xh[j][i] = (xv[i] - mu) * rs;
+                dh[j][i] = dv[i] * gamma[vv * 8 + i];
+                s1 += dh[j][i];
+                s2 += dh[j][i] * xh[j][i];
+            }
+        }
+    }
+    s1 = wave_sum(s1) / (float)C;
+    s2 = wave_sum(s2) / (float)C;
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int vv = lane + 64 * j;
+        if (vv < nvec) {
+            float o[8], rr[8];
+            if (dres) unpack8(*(const u32x4*)(dres + r * ldres + vv * 8), rr);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                o[i] = rs * (dh[j][i] - s1 - xh[j][i] * s2);
+                if (dres) o[i] += rr[i];
+            }
+            *(u32x4*)(dx + r * lddx + vv * 8) = pack8(o);
+        }
+    }
+}
+
+int gn_check(int C, int G, int c0, const void* x1) {
+    if (G <= 0 || G > GN_MAX_GROUPS || C % G || C % 8) return fail(-EINVAL, "groupnorm: bad C=%d G=%d", C, G);
+    if (x1 && (c0 % 8 || c0 <= 0 || c0 >= C)) return fail(-EINVAL, "groupnorm: bad concat split %d of %d", c0, C);
+    return 0;
+}
+int pix_per_block(int batch, int hw) {
+    int nblk = 1024 / (batch > 0 ? batch : 1);
+    if (nblk < 1) nblk = 1;
+    int ppb = cdiv(hw, nblk);
+    return ppb < 8 ? 8 : ppb;
+}
+}  // namespace
+}  // namespace leco
+
+using namespace leco;
+
+extern "C" int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
+                                  const float* gamma, const float* beta, int32_t batch, int32_t hw,
+                                  int32_t c, int32_t groups, float eps, int32_t act, float* stats,
+                                  void* y, int64_t ldy, leco_stream_t stream) {
+    int rc = gn_check(c, groups, c0, x1);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
+    (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * batch * groups, s);
+    const int ppb = pix_per_block(batch, hw);
+    hipLaunchKernelGGL((gn_stats_kernel<0>), dim3(cdiv(hw, ppb), batch), dim3(256), 0, s, src,
+                       (const bf16_t*)nullptr, (int64_t)0, (const float*)nullptr, gamma, beta, act, eps, hw, c,
+                       groups, ppb, stats);
+    const int64_t total = (int64_t)batch * hw * (c / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(grid), dim3(256), 0, s, src, (const bf16_t*)nullptr,
+                       (int64_t)0, (const float*)stats, (const float*)nullptr, gamma, beta, act, eps, hw, c,
+                       groups, total, (bf16_t*)y, ldy);
+    return check_launch("leco_groupnorm_fwd");
+}
+
+extern "C" int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
+                                  const void* dy, int64_t lddy, const float* gamma, const float* beta,
+                                  const float* stats, int32_t batch, int32_t hw, int32_t c, int32_t groups,
+                                  float eps, int32_t act, float* bstats, void* dx, int64_t lddx,
+                                  leco_stream_t stream) {
+    int rc = gn_check(c, groups, c0, x1);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
+    (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * batch * groups, s);
+    const int ppb = pix_per_block(batch, hw);
+    hipLaunchKernelGGL((gn_stats_kernel<1>), dim3(cdiv(hw, ppb), batch), dim3(256), 0, s, src,
+                       (const bf16_t*)dy, lddy, stats, gamma, beta, act, eps, hw, c, groups, ppb, bstats);
+    const int64_t total = (int64_t)batch * hw * (c / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(grid), dim3(256), 0, s, src, (const bf16_t*)dy, lddy,
+                       stats, (const float*)bstats, gamma, beta, act, eps, hw, c, groups, total, (bf16_t*)dx,
+                       lddx);
+    return check_launch("leco_groupnorm_bwd");
+}
+
+extern "C" int leco_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta,
+                                  float eps, int32_t m, int32_t c, void* y, int64_t ldy, float* mean,
+                                  float* rstd, leco_stream_t stream) {
+    if (c % 8 || c > 64 * 8 * LN_MAXV) return fail(-EINVAL, "layernorm: unsupported C=%d", c);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(m, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       ldx, gamma, beta, eps, m, c, (bf16_t*)y, ldy, mean, rstd);
+    return check_launch("leco_layernorm_fwd");
+}
+
+extern "C" int leco_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy,
+                                  const float* gamma, const float* mean, const float* rstd,
+                                  const void* dres, int64_t ldres, int32_t m, int32_t c, void* dx,
+                                  int64_t lddx, leco_stream_t stream) {
+    if (c % 8 || c > 64 * 8 * LN_MAXV) return fail(-EINVAL, "layernorm: unsupported C=%d", c);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(cdiv(m, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       ldx, (const bf16_t*)dy, lddy, gamma, mean, rstd, (const bf16_t*)dres, ldres, m, c,
+                       (bf16_t*)dx, lddx);
+    return check_launch("leco_layernorm_bwd");
+}

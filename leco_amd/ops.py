@@ -1,0 +1,191 @@
+"""Typed Python front for every entry point of ``libleco_hip.so``.
+
+Each function returns an :class:`Op` -- the C function plus its marshalled argument tuple --
+so that callers can either run it immediately (``op.run()``) or append it to a static launch
+plan that is later replayed eagerly or captured into a hipGraph (``leco_amd.unet``).  Tensors
+are only used for their device pointers; nothing here computes in PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import hip
+from .hip import ACT_NONE, ACT_SILU, A_PLAIN, GemmArgs, LoraSite, ptr  # noqa: F401
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+_SIGS = {
+    "leco_groupnorm_fwd": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
+    "leco_groupnorm_bwd": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
+    "leco_layernorm_fwd": [_vp, _i64, _vp, _vp, _f32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
+    "leco_layernorm_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp],
+    "leco_attention_fwd": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "leco_attention_bwd": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
+                           _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
+                           _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "leco_geglu_fwd": [_vp, _i64, _vp, _i64, _i32, _i32, _vp],
+    "leco_geglu_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
+    "leco_add": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
+    "leco_upsample2x_bwd": [_vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "leco_conv_in": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "leco_conv_out": [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "leco_conv_out_bwd": [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp],
+    "leco_timestep_embedding": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
+    "leco_advance": [_vp, _vp],
+    "leco_cfg_ddim_step": [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp],
+    "leco_esd_loss": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp, _vp, _vp],
+    "leco_adamw": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _vp],
+    "leco_cast_f32_bf16": [_vp, _vp, _i64, _vp],
+    "leco_memset": [_vp, _i32, _i64, _vp],
+    "leco_lora_pack": [_vp, _i32, _vp],
+    "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
+}
+_fn_cache = {}
+_fn_lib = None
+
+
+def _fn(name: str):
+    global _fn_lib
+    lib = hip.lib()
+    if _fn_lib is not lib:
+        _fn_cache.clear()
+        _fn_lib = lib
+    f = _fn_cache.get(name)
+    if f is None:
+        f = getattr(lib, name)
+        if name in _SIGS:
+            f.argtypes = _SIGS[name]
+        f.restype = C.c_int
+        _fn_cache[name] = f
+    return f
+
+
+class Op:
+    """One enqueue-only C-ABI call: ``fn(*args, stream)``."""
+    __slots__ = ("name", "fn", "args", "keep")
+
+    def __init__(self, name: str, args: tuple, keep=None):
+        self.name = name
+        self.fn = _fn(name)
+        self.args = args
+        self.keep = keep  # python objects whose memory the args point to
+
+    def run(self, stream=None) -> None:
+        rc = self.fn(*self.args, stream)
+        if rc != 0:
+            hip.check(rc, self.name)
+
+
+def run_plan(plan: Sequence[Op], stream=None) -> None:
+    for op in plan:
+        rc = op.fn(*op.args, stream)
+        if rc != 0:
+            hip.check(rc, op.name)
+
+
+# ---------------------------------------------------------------------------------------------
+def gemm(args: GemmArgs, keep=None) -> Op:
+    return Op("leco_gemm", (C.byref(args),), keep=(args, keep))
+
+
+def groupnorm_fwd(x0, ld0, x1, ld1, c0, gamma, beta, batch, hw, c, groups, eps, act, stats, y, ldy) -> Op:
+    return Op("leco_groupnorm_fwd", (ptr(x0), ld0, ptr(x1), ld1, c0, ptr(gamma), ptr(beta), batch, hw, c,
+                                     groups, eps, act, ptr(stats), ptr(y), ldy))
+
+
+def groupnorm_bwd(x0, ld0, x1, ld1, c0, dy, lddy, gamma, beta, stats, batch, hw, c, groups, eps, act,
+                  bstats, dx, lddx) -> Op:
+    return Op("leco_groupnorm_bwd", (ptr(x0), ld0, ptr(x1), ld1, c0, ptr(dy), lddy, ptr(gamma), ptr(beta),
+                                     ptr(stats), batch, hw, c, groups, eps, act, ptr(bstats), ptr(dx), lddx))
+
+
+def layernorm_fwd(x, ldx, gamma, beta, eps, m, c, y, ldy, mean, rstd) -> Op:
+    return Op("leco_layernorm_fwd", (ptr(x), ldx, ptr(gamma), ptr(beta), eps, m, c, ptr(y), ldy, ptr(mean),
+                                     ptr(rstd)))
+
+
+def layernorm_bwd(x, ldx, dy, lddy, gamma, mean, rstd, dres, ldres, m, c, dx, lddx) -> Op:
+    return Op("leco_layernorm_bwd", (ptr(x), ldx, ptr(dy), lddy, ptr(gamma), ptr(mean), ptr(rstd), ptr(dres),
+                                     ldres, m, c, ptr(dx), lddx))
+
+
+def attention_fwd(q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, o, ldo, bso, lse, batch, heads, sq, skv, d, scale) -> Op:
+    return Op("leco_attention_fwd", (q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, o, ldo, bso, ptr(lse), batch, heads,
+                                     sq, skv, d, scale))
+
+
+def attention_bwd(q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, o, ldo, bso, do, lddo, bsdo, lse, delta,
+                  dq, lddq, bsdq, dk, lddk, bsdk, dv, lddv, bsdv, batch, heads, sq, skv, d, scale) -> Op:
+    return Op("leco_attention_bwd", (q, ldq, bsq, k, ldk, bsk, v, ldv, bsv, o, ldo, bso, do, lddo, bsdo,
+                                     ptr(lse), ptr(delta), dq, lddq, bsdq, dk, lddk, bsdk, dv, lddv,
+                                     bsdv, batch, heads, sq, skv, d, scale))
+
+
+def geglu_fwd(u, ldu, y, ldy, m, f) -> Op:
+    return Op("leco_geglu_fwd", (ptr(u), ldu, ptr(y), ldy, m, f))
+
+
+def geglu_bwd(u, ldu, dy, lddy, du, lddu, m, f) -> Op:
+    return Op("leco_geglu_bwd", (ptr(u), ldu, ptr(dy), lddy, ptr(du), lddu, m, f))
+
+
+def add(a, lda, b, ldb, c, ldc, out, ldo, m, cols) -> Op:
+    """a, b, c, out are raw device addresses (ints) so that column-offset views can be passed."""
+    return Op("leco_add", (a, lda, b, ldb, c, ldc, out, ldo, m, cols))
+
+
+def upsample2x_bwd(dy, dx, batch, h, w, c) -> Op:
+    return Op("leco_upsample2x_bwd", (ptr(dy), ptr(dx), batch, h, w, c))
+
+
+def conv_in(x, w, bias, y, batch, h, wd, cin, cout) -> Op:
+    return Op("leco_conv_in", (ptr(x), ptr(w), ptr(bias), ptr(y), batch, h, wd, cin, cout))
+
+
+def conv_out(x, w, bias, y, batch, h, wd, c, cout) -> Op:
+    return Op("leco_conv_out", (ptr(x), ptr(w), ptr(bias), ptr(y), batch, h, wd, c, cout))
+
+
+def conv_out_bwd(dy, w, dx, batch, h, wd, c, cout) -> Op:
+    return Op("leco_conv_out_bwd", (ptr(dy), ptr(w), ptr(dx), batch, h, wd, c, cout))
+
+
+def timestep_embedding(t_table, idx, t_stride, n, dim, out) -> Op:
+    return Op("leco_timestep_embedding", (ptr(t_table), ptr(idx), t_stride, n, dim, ptr(out)))
+
+
+def advance(counter) -> Op:
+    return Op("leco_advance", (ptr(counter),))
+
+
+def cfg_ddim_step(pred, x, x2, coef, step, guidance, half_n) -> Op:
+    return Op("leco_cfg_ddim_step", (ptr(pred), ptr(x), ptr(x2), ptr(coef), ptr(step), guidance, half_n))
+
+
+def esd_loss(tgt, pos, neu, unc, g_pred, g_loss, sign, half_n, loss, dpred) -> Op:
+    return Op("leco_esd_loss", (ptr(tgt), ptr(pos), ptr(neu), ptr(unc), g_pred, g_loss, sign, half_n, ptr(loss),
+                                ptr(dpred)))
+
+
+def adamw(p, g, m, v, shadow, hyper, beta1, beta2, eps, wd, n) -> Op:
+    return Op("leco_adamw", (ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), ptr(hyper), beta1, beta2, eps, wd, n))
+
+
+def cast_f32_bf16(x, y, n) -> Op:
+    return Op("leco_cast_f32_bf16", (ptr(x), ptr(y), n))
+
+
+def memset(t: torch.Tensor, value: int = 0) -> Op:
+    return Op("leco_memset", (ptr(t), value, t.numel() * t.element_size()))
+
+
+def lora_pack(sites_dev: torch.Tensor, nsites: int) -> Op:
+    return Op("leco_lora_pack", (ptr(sites_dev), nsites))
+
+
+def lora_wgrad(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale) -> Op:
+    """p, q, g are raw device addresses (ints)."""
+    return Op("leco_lora_wgrad", (p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale))

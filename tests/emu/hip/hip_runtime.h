@@ -18,6 +18,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <algorithm>
+using std::min;
+using std::max;
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 
 struct dim3 {
     unsigned x, y, z;
