@@ -74,12 +74,23 @@ class Op:
         self.keep = keep  # python objects whose memory the args point to
 
     def run(self, stream=None) -> None:
+        if stream is None:
+            stream = default_stream()
         rc = self.fn(*self.args, stream)
         if rc != 0:
             hip.check(rc, self.name)
 
 
+def default_stream():
+    """torch's current HIP stream handle (None when bound to the host emulator)."""
+    if hip.is_emulated() or not torch.cuda.is_available():
+        return None
+    return torch.cuda.current_stream().cuda_stream
+
+
 def run_plan(plan: Sequence[Op], stream=None) -> None:
+    if stream is None:
+        stream = default_stream()
     for op in plan:
         rc = op.fn(*op.args, stream)
         if rc != 0:

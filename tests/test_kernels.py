@@ -1,0 +1,333 @@
+"""Per-kernel parity: every C-ABI kernel vs a plain fp32 PyTorch statement of the same op on
+the same bf16-rounded inputs.  Runs twice: on the host emulator of the kernel sources (CPU
+tier) and on the gfx950 build (`-m gpu`).  Tolerances (relative L2):
+  1e-5  where the result is compared in fp32 (MFMA fp32 accumulate vs torch fp32),
+  2e-3  where the kernel rounds its result (or P / dS inside attention) to bf16 -- one bf16
+        rounding is 2^-9 ~ 2e-3 worst case, ~1.1e-3 RMS -- compared against the un-rounded fp32."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from leco_amd import hip, ops
+
+bf = torch.bfloat16
+TOL32, TOLBF = 1e-5, 3e-3
+
+
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("tile,M,N,K", [(3, 100, 72, 128), (1, 300, 136, 192), (2, 200, 320, 64), (0, 70, 64, 64),
+                                        (1, 128, 128, 64), (2, 256, 160, 128)])
+def test_gemm_plain_full_epilogue(dev, tile, M, N, K):
+    torch.manual_seed(0)
+    a = torch.randn(M, K).to(bf).to(dev); w = (torch.randn(N, K) / K ** 0.5).to(bf).to(dev)
+    ae = torch.randn(M, 32).to(bf).to(dev); we = (torch.randn(N, 32) * 0.1).to(bf).to(dev)
+    bias = torch.randn(N).to(dev); rb = torch.randn((M + 49) // 50, N).to(dev); res = torch.randn(M, N).to(bf).to(dev)
+    out = torch.zeros(M, N, dtype=bf, device=dev); o32 = torch.zeros(M, N, device=dev)
+    g = hip.gemm_args(a, w, out, m=M, n=N, k=K, a_ext=ae, w_ext=we, ext_k=32, bias=bias, rowbias=rb,
+                      rows_per_group=50, residual=res, act=hip.ACT_SILU, out_f32=o32)
+    hip.gemm(g, ops.default_stream(), tile)
+    _sync(dev)
+    ref = a.float() @ w.float().T + ae.float() @ we.float().T + bias + rb.repeat_interleave(50, 0)[:M] + res.float()
+    ref = F.silu(ref)
+    assert rel_err(o32, ref) < TOL32
+    assert rel_err(out, ref) < TOLBF
+
+
+def test_gemm_mfma_layout_asymmetric(dev):
+    """A = I-like / asymmetric-B check (cdna_hip_programming.md: transposes must be caught)."""
+    M = N = K = 64
+    a = torch.eye(M).to(bf).to(dev)
+    w = (torch.arange(N)[:, None] * 0.5 - torch.arange(K)[None, :] * 0.25).to(bf).to(dev)  # w[n][k]
+    o32 = torch.zeros(M, N, device=dev)
+    hip.gemm(hip.gemm_args(a, w, None, m=M, n=N, k=K, out_f32=o32), ops.default_stream())
+    _sync(dev)
+    assert torch.equal(o32, w.float().T)
+
+
+def test_gemm_two_source(dev):
+    torch.manual_seed(1)
+    M, N, K = 130, 64, 192
+    a0 = torch.randn(M, 64).to(bf).to(dev); a1 = torch.randn(M, 128).to(bf).to(dev)
+    w = (torch.randn(N, K) / K ** 0.5).to(bf).to(dev); o32 = torch.zeros(M, N, device=dev)
+    hip.gemm(hip.gemm_args(a0, w, None, m=M, n=N, k=K, lda=64, a1=a1, lda1=128, k_split=64, out_f32=o32),
+             ops.default_stream())
+    _sync(dev)
+    assert rel_err(o32, torch.cat([a0, a1], 1).float() @ w.float().T) < TOL32
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    a = torch.zeros(8, 40, dtype=bf, device=dev)
+    with pytest.raises(hip.LecoError):
+        hip.gemm(hip.gemm_args(a, a, a, m=8, n=8, k=40), ops.default_stream())
+
+
+@pytest.mark.parametrize("mode", ["s1", "s2", "up2", "tr2", "s1_dgrad", "concat"])
+def test_conv3x3_modes(dev, mode):
+    torch.manual_seed(2)
+    B, H, W_, Ci, Co = 2, 6, 10, 64, 64
+    x = torch.randn(B, Ci, H, W_).to(bf); wt = (torch.randn(Co, Ci, 3, 3) / (9 * Ci) ** 0.5).to(bf)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wh = wt.permute(0, 2, 3, 1).contiguous().reshape(Co, 9 * Ci).to(dev)
+    wtr = wt.flip(2, 3).permute(1, 2, 3, 0).contiguous().reshape(Ci, 9 * Co).to(dev)
+
+    def run(amode, src, w, cin, cout, ho, wo, hin, win, **kw):
+        o32 = torch.zeros(B * ho * wo, cout, device=dev)
+        g = hip.gemm_args(src, w, None, m=B * ho * wo, n=cout, k=9 * cin, lda=kw.pop("lda", cin), a_mode=amode,
+                          conv=(B, ho, wo, hin, win), out_f32=o32, **kw)
+        hip.gemm(g, ops.default_stream())
+        _sync(dev)
+        return o32.reshape(B, ho, wo, cout).permute(0, 3, 1, 2).cpu()
+
+    xf, wf = x.float(), wt.float()
+    if mode == "s1":
+        got, ref = run(hip.A_CONV3_S1, xh, wh, Ci, Co, H, W_, H, W_), F.conv2d(xf, wf, padding=1)
+    elif mode == "s2":
+        got, ref = run(hip.A_CONV3_S2, xh, wh, Ci, Co, H // 2, W_ // 2, H, W_), F.conv2d(xf, wf, padding=1, stride=2)
+    elif mode == "up2":
+        got = run(hip.A_CONV3_UP2, xh, wh, Ci, Co, 2 * H, 2 * W_, H, W_)
+        ref = F.conv2d(F.interpolate(xf, scale_factor=2.0, mode="nearest"), wf, padding=1)
+    elif mode in ("tr2", "s1_dgrad"):
+        stride = 2 if mode == "tr2" else 1
+        dy = torch.randn(B, Co, H // stride, W_ // stride).to(bf)
+        xx = xf.clone().requires_grad_(True)
+        F.conv2d(xx, wf, padding=1, stride=stride).backward(dy.float())
+        dyh = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+        amode = hip.A_CONV3_TR2 if mode == "tr2" else hip.A_CONV3_S1
+        got, ref = run(amode, dyh, wtr, Co, Ci, H, W_, H // stride, W_ // stride), xx.grad
+    else:
+        x2 = torch.randn(B, 128, H, W_).to(bf); wt2 = (torch.randn(Co, 192, 3, 3) / (9 * 192) ** 0.5).to(bf)
+        x2h = x2.permute(0, 2, 3, 1).contiguous().to(dev)
+        wh2 = wt2.permute(0, 2, 3, 1).contiguous().reshape(Co, 9 * 192).to(dev)
+        got = run(hip.A_CONV3_S1, xh, wh2, 192, Co, H, W_, H, W_, lda=64, a1=x2h, lda1=128, k_split=64)
+        ref = F.conv2d(torch.cat([x, x2], 1).float(), wt2.float(), padding=1)
+    assert rel_err(got, ref) < TOL32
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_groupnorm_fwd_bwd(dev, act):
+    torch.manual_seed(3)
+    B, HW, C0, C1, G = 2, 37, 64, 128, 32
+    C = C0 + C1
+    x0 = torch.randn(B * HW, C0).to(bf).to(dev); x1 = (torch.randn(B * HW, C1) * 2 + 0.5).to(bf).to(dev)
+    gamma = torch.randn(C).to(dev); beta = torch.randn(C).to(dev)
+    stats = torch.zeros(B, G, 2, device=dev); y = torch.zeros(B * HW, C, dtype=bf, device=dev)
+    ops.groupnorm_fwd(x0, C0, x1, C1, C0, gamma, beta, B, HW, C, G, 1e-5, act, stats, y, C).run()
+    xc = torch.cat([x0, x1], 1).float().cpu().reshape(B, HW, C).permute(0, 2, 1).requires_grad_(True)
+    ref = F.group_norm(xc, G, gamma.cpu(), beta.cpu(), 1e-5)
+    ref = F.silu(ref) if act else ref
+    dy = torch.randn(B * HW, C).to(bf).to(dev); bstats = torch.zeros(B, G, 2, device=dev)
+    dx = torch.zeros(B * HW, C, dtype=bf, device=dev)
+    ops.groupnorm_bwd(x0, C0, x1, C1, C0, dy, C, gamma, beta, stats, B, HW, C, G, 1e-5, act, bstats, dx, C).run()
+    _sync(dev)
+    ref.backward(dy.float().cpu().reshape(B, HW, C).permute(0, 2, 1))
+    assert rel_err(y.cpu().reshape(B, HW, C).permute(0, 2, 1), ref) < TOLBF
+    assert rel_err(dx.cpu().reshape(B, HW, C).permute(0, 2, 1), xc.grad) < TOLBF
+
+
+@pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64)])
+def test_layernorm_fwd_bwd(dev, M, C):
+    torch.manual_seed(4)
+    x = (torch.randn(M, C) * 1.5 + 0.3).to(bf).to(dev); gamma = torch.randn(C).to(dev); beta = torch.randn(C).to(dev)
+    y = torch.zeros(M, C, dtype=bf, device=dev); mean = torch.zeros(M, device=dev); rstd = torch.zeros(M, device=dev)
+    ops.layernorm_fwd(x, C, gamma, beta, 1e-5, M, C, y, C, mean, rstd).run()
+    xx = x.float().cpu().requires_grad_(True)
+    ref = F.layer_norm(xx, (C,), gamma.cpu(), beta.cpu(), 1e-5)
+    dy = torch.randn(M, C).to(bf).to(dev); dres = torch.randn(M, C).to(bf).to(dev)
+    dx = torch.zeros(M, C, dtype=bf, device=dev)
+    ops.layernorm_bwd(x, C, dy, C, gamma, mean, rstd, dres, C, M, C, dx, C).run()
+    _sync(dev)
+    ref.backward(dy.float().cpu())
+    assert rel_err(y.cpu(), ref) < TOLBF
+    assert rel_err(dx.cpu(), xx.grad + dres.float().cpu()) < TOLBF
+
+
+ATTN_CASES = [(2, 2, 70, 77, 40), (1, 3, 130, 130, 80), (1, 2, 64, 200, 160), (2, 2, 50, 64, 64), (1, 2, 96, 96, 32),
+              (1, 1, 1100, 1100, 40)]
+
+
+@pytest.mark.parametrize("B,H,Sq,Skv,D", ATTN_CASES)
+def test_attention_fwd_bwd(dev, B, H, Sq, Skv, D):
+    torch.manual_seed(5)
+    C = H * D
+    q = torch.randn(B, Sq, C).to(bf).to(dev); k = torch.randn(B, Skv, C).to(bf).to(dev)
+    v = torch.randn(B, Skv, C).to(bf).to(dev)
+    o = torch.zeros(B, Sq, C, dtype=bf, device=dev); lse = torch.zeros(B, H, Sq, device=dev)
+    sc = D ** -0.5
+    ops.attention_fwd(q.data_ptr(), C, Sq * C, k.data_ptr(), C, Skv * C, v.data_ptr(), C, Skv * C, o.data_ptr(), C,
+                      Sq * C, lse, B, H, Sq, Skv, D, sc).run()
+    do = torch.randn(B, Sq, C).to(bf).to(dev)
+    dq = torch.zeros_like(q); dk = torch.zeros_like(k); dv = torch.zeros_like(v)
+    delta = torch.zeros(B, H, Sq, device=dev)
+    ops.attention_bwd(q.data_ptr(), C, Sq * C, k.data_ptr(), C, Skv * C, v.data_ptr(), C, Skv * C, o.data_ptr(), C,
+                      Sq * C, do.data_ptr(), C, Sq * C, lse, delta, dq.data_ptr(), C, Sq * C, dk.data_ptr(), C,
+                      Skv * C, dv.data_ptr(), C, Skv * C, B, H, Sq, Skv, D, sc).run()
+    _sync(dev)
+    qq, kk, vv = [t.float().cpu().requires_grad_(True) for t in (q, k, v)]
+    qh = qq.reshape(B, Sq, H, D).transpose(1, 2); kh = kk.reshape(B, Skv, H, D).transpose(1, 2)
+    vh = vv.reshape(B, Skv, H, D).transpose(1, 2)
+    s = (qh @ kh.transpose(-1, -2)) * sc
+    ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Sq, C)
+    ref.backward(do.float().cpu())
+    assert rel_err(o.cpu(), ref) < TOLBF
+    assert rel_err(lse.cpu(), torch.logsumexp(s, -1)) < 1e-5
+    assert rel_err(dq.cpu(), qq.grad) < 4e-3
+    assert rel_err(dk.cpu(), kk.grad) < 4e-3
+    assert rel_err(dv.cpu(), vv.grad) < 4e-3
+
+
+def test_attention_strided_fused_qkv(dev):
+    """q|k|v packed in one [B][S][3C] buffer (how the UNet engine lays them out)."""
+    torch.manual_seed(6)
+    B, H, S, D = 2, 2, 48, 40
+    C = H * D
+    qkv = torch.randn(B, S, 3 * C).to(bf).to(dev)
+    o = torch.zeros(B, S, C, dtype=bf, device=dev); lse = torch.zeros(B, H, S, device=dev)
+    p0 = qkv.data_ptr()
+    ops.attention_fwd(p0, 3 * C, S * 3 * C, p0 + 2 * C, 3 * C, S * 3 * C, p0 + 4 * C, 3 * C, S * 3 * C, o.data_ptr(), C,
+                      S * C, lse, B, H, S, S, D, D ** -0.5).run()
+    _sync(dev)
+    q, k, v = [t.float().cpu().reshape(B, S, H, D).transpose(1, 2) for t in qkv.chunk(3, -1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * D ** -0.5, -1) @ v).transpose(1, 2).reshape(B, S, C)
+    assert rel_err(o.cpu(), ref) < TOLBF
+
+
+def test_elementwise_family(dev):
+    torch.manual_seed(7)
+    M, Fd = 33, 128
+    u = torch.randn(M, 2 * Fd).to(bf).to(dev); y = torch.zeros(M, Fd, dtype=bf, device=dev)
+    ops.geglu_fwd(u, 2 * Fd, y, Fd, M, Fd).run()
+    uu = u.float().cpu().requires_grad_(True)
+    a, g = uu.chunk(2, -1)
+    ref = a * F.gelu(g)
+    dy = torch.randn(M, Fd).to(bf).to(dev); du = torch.zeros(M, 2 * Fd, dtype=bf, device=dev)
+    ops.geglu_bwd(u, 2 * Fd, dy, Fd, du, 2 * Fd, M, Fd).run()
+    ref.backward(dy.float().cpu())
+    _sync(dev)
+    assert rel_err(y.cpu(), ref) < TOLBF and rel_err(du.cpu(), uu.grad) < TOLBF
+    # strided add
+    a = torch.randn(10, 64).to(bf).to(dev); b = torch.randn(10, 128).to(bf).to(dev); c = torch.randn(10, 64).to(bf).to(dev)
+    o = torch.zeros(10, 64, dtype=bf, device=dev)
+    ops.add(a.data_ptr(), 64, b.data_ptr() + 64 * 2, 128, c.data_ptr(), 64, o.data_ptr(), 64, 10, 64).run()
+    _sync(dev)
+    assert rel_err(o, a.float() + b[:, 64:].float() + c.float()) < TOLBF
+    # upsample dgrad
+    B, H, W, C = 2, 3, 5, 64
+    dyh = torch.randn(B, 2 * H, 2 * W, C).to(bf).to(dev); dx = torch.zeros(B, H, W, C, dtype=bf, device=dev)
+    ops.upsample2x_bwd(dyh, dx, B, H, W, C).run()
+    xx = torch.zeros(B, C, H, W, requires_grad=True)
+    F.interpolate(xx, scale_factor=2.0, mode="nearest").backward(dyh.float().cpu().permute(0, 3, 1, 2))
+    _sync(dev)
+    assert rel_err(dx.cpu().permute(0, 3, 1, 2), xx.grad) < TOLBF
+
+
+def test_conv_in_out(dev):
+    torch.manual_seed(8)
+    B, H, W, Ci, Co = 2, 6, 7, 4, 64
+    x = torch.randn(B, Ci, H, W).to(bf).to(dev); w = (torch.randn(Co, Ci, 3, 3) * 0.2).to(dev); bias = torch.randn(Co).to(dev)
+    y = torch.zeros(B, H, W, Co, dtype=bf, device=dev)
+    ops.conv_in(x, w, bias, y, B, H, W, Ci, Co).run()
+    _sync(dev)
+    assert rel_err(y.cpu().permute(0, 3, 1, 2), F.conv2d(x.float().cpu(), w.cpu(), bias.cpu(), padding=1)) < TOLBF
+    C = 128
+    xh = torch.randn(B, H, W, C).to(bf).to(dev); w4 = (torch.randn(4, C, 3, 3) * 0.05).to(bf); b4 = torch.randn(4).to(dev)
+    wl = w4.permute(0, 2, 3, 1).contiguous().to(dev); yo = torch.zeros(B, 4, H, W, device=dev)
+    ops.conv_out(xh, wl, b4, yo, B, H, W, C, 4).run()
+    xx = xh.float().cpu().permute(0, 3, 1, 2).requires_grad_(True)
+    ref = F.conv2d(xx, w4.float(), b4.cpu(), padding=1)
+    dyo = torch.randn(B, 4, H, W).to(dev); dxh = torch.zeros(B, H, W, C, dtype=bf, device=dev)
+    ops.conv_out_bwd(dyo, wl, dxh, B, H, W, C, 4).run()
+    ref.backward(dyo.cpu())
+    _sync(dev)
+    assert rel_err(yo.cpu(), ref) < TOL32
+    assert rel_err(dxh.cpu().permute(0, 3, 1, 2), xx.grad) < TOLBF
+
+
+def test_timestep_ddim_loss_adamw(dev):
+    from oracle.unet_ref import timestep_sinusoid
+    torch.manual_seed(9)
+    tt = torch.tensor([999., 980., 0., 1., 500.], device=dev); idx = torch.tensor([1], dtype=torch.int32, device=dev)
+    out = torch.zeros(2, 320, dtype=bf, device=dev)
+    ops.timestep_embedding(tt, idx, 0, 2, 320, out).run()
+    ops.advance(idx).run()
+    _sync(dev)
+    assert rel_err(out.cpu(), timestep_sinusoid(torch.tensor([980., 980.]), 320)) < TOLBF
+    assert idx.item() == 2
+    bs, n = 2, 4 * 8 * 8
+    pred = torch.randn(2 * bs * n, device=dev); x = torch.randn(bs * n, device=dev)
+    x2 = torch.zeros(2 * bs * n, dtype=bf, device=dev)
+    coef = torch.tensor([0., 0., 1.01, -0.03, 5, 5], device=dev); st = torch.tensor([1], dtype=torch.int32, device=dev)
+    x_ref = 1.01 * x - 0.03 * (pred[:bs * n] + 3 * (pred[bs * n:] - pred[:bs * n]))
+    ops.cfg_ddim_step(pred, x, x2, coef, st, 3.0, bs * n).run()
+    _sync(dev)
+    assert rel_err(x, x_ref) < 1e-6 and rel_err(x2, torch.cat([x_ref, x_ref])) < TOLBF
+    t, p, nn_, u = [torch.randn(2 * bs * n, device=dev) for _ in range(4)]
+    loss = torch.zeros(1, device=dev); dp = torch.zeros(2 * bs * n, device=dev)
+    ops.esd_loss(t, p, nn_, u, 1.0, 1.5, -1.0, bs * n, loss, dp).run()
+    _sync(dev)
+    tt_ = t.cpu().clone().requires_grad_(True)
+
+    def gd(z):
+        return z[:bs * n] + 1.0 * (z[bs * n:] - z[:bs * n])
+    ref = F.mse_loss(gd(tt_), gd(nn_.cpu()) - 1.5 * (gd(p.cpu()) - gd(u.cpu())))
+    ref.backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    assert rel_err(dp.cpu(), tt_.grad) < 1e-5
+    N = 1000
+    p0 = torch.randn(N); g0 = torch.randn(N)
+    pp = p0.clone().to(dev); m0 = torch.zeros(N, device=dev); v0 = torch.zeros(N, device=dev)
+    sh = torch.zeros(N, dtype=bf, device=dev)
+    pt = torch.nn.Parameter(p0.clone()); opt = torch.optim.AdamW([pt], lr=1e-2)
+    for step in range(1, 4):
+        pt.grad = g0 * step
+        opt.step()
+        hyper = torch.tensor([1e-2, 1 - 0.9 ** step, 1 - 0.999 ** step, 1.0], device=dev)
+        gg = (g0 * step).to(dev)
+        ops.adamw(pp, gg, m0, v0, sh, hyper, 0.9, 0.999, 1e-8, 0.01, N).run()
+        _sync(dev)
+    assert rel_err(pp.cpu(), pt.data) < 1e-5 and rel_err(sh.cpu(), pt.data) < TOLBF
+
+
+def test_lora_pack_forward_wgrad(dev):
+    torch.manual_seed(10)
+    r, K, N_, groups, M = 4, 64, 192, 3, 70
+    downs = [torch.randn(r, K).to(bf).to(dev) for _ in range(groups)]
+    ups = [torch.randn(N_ // groups, r).to(bf).to(dev) for _ in range(groups)]
+    R, R16, Rp = groups * r, 16, 32
+    dn_s = torch.zeros(Rp, K, dtype=bf, device=dev); up_p = torch.zeros(N_, Rp, dtype=bf, device=dev)
+    up_t = torch.zeros(R16, N_, dtype=bf, device=dev); dn_p = torch.zeros(K, Rp, dtype=bf, device=dev)
+    site = hip.LoraSite()
+    for g in range(groups):
+        site.down[g] = downs[g].data_ptr(); site.up[g] = ups[g].data_ptr()
+    site.groups, site.r, site.k, site.n, site.scale = groups, r, K, N_, 0.25
+    site.dn_s, site.up_p, site.up_t, site.dn_p = dn_s.data_ptr(), up_p.data_ptr(), up_t.data_ptr(), dn_p.data_ptr()
+    buf = torch.frombuffer(bytearray(bytes(site)), dtype=torch.uint8).clone().to(dev)
+    ops.lora_pack(buf, 1).run()
+    _sync(dev)
+    dn_ref = torch.cat(downs, 0).cpu()
+    upbd = torch.block_diag(*[u_.float().cpu() for u_ in ups])
+    assert torch.equal(dn_s[:R].cpu(), dn_ref) and dn_s[R:].abs().max().item() == 0
+    assert rel_err(up_p[:, :R].cpu(), 0.25 * upbd) < TOLBF and up_p[:, R:].abs().max().item() == 0
+    assert torch.equal(up_t[:R].cpu().float(), upbd.T)
+    assert rel_err(dn_p[:, :R].cpu(), 0.25 * dn_ref.float().T) < TOLBF
+    # y = x W^T + s (x A^T) B^T via T = x dn_s^T then the K-extension tile
+    x = torch.randn(M, K).to(bf).to(dev); Wm = (torch.randn(N_, K) / 8).to(bf).to(dev)
+    T = torch.zeros(M, Rp, dtype=bf, device=dev)
+    ops.gemm(hip.gemm_args(x, dn_s, T, m=M, n=Rp, k=K)).run()
+    o32 = torch.zeros(M, N_, device=dev)
+    ops.gemm(hip.gemm_args(x, Wm, None, m=M, n=N_, k=K, a_ext=T, w_ext=up_p, ext_k=Rp, out_f32=o32)).run()
+    _sync(dev)
+    ref = x.float().cpu() @ Wm.float().cpu().T + T.float().cpu()[:, :R] @ (0.25 * upbd).to(bf).float().T
+    assert rel_err(o32.cpu(), ref) < TOL32
+    ref_T = x.float().cpu() @ dn_ref.float().T
+    assert rel_err(T[:, :R].cpu(), ref_T) < TOLBF
+    dy = torch.randn(M, N_).to(bf).to(dev); G = torch.zeros(N_ // groups, r, device=dev)
+    ops.lora_wgrad(T.data_ptr() + 2 * r, Rp, dy.data_ptr() + 2 * 64, N_, G.data_ptr(), 1, r, M, r, 64, 0.25).run()
+    _sync(dev)
+    assert rel_err(G.cpu(), 0.25 * dy[:, 64:128].float().cpu().T @ T[:, r:2 * r].float().cpu()) < 1e-5
