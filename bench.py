@@ -1,0 +1,168 @@
+#!/usr/bin/env python
+"""bench.py -- LECO training steps/sec on MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[1] -- SDv1.5 UNet (random-init weights of the
+exact architecture, synthetic prompt embeddings), LoRA rank 4 / alpha 1 "lierla" (192 modules),
+512x512 (latent 64x64), prompt batch_size 2 (UNet batch 4 with the classifier-free-guidance
+duplication), bf16 MFMA / fp32 accumulate, DDIM, max_denoising_steps 50.  One "step" is one full
+reference-faithful optimizer step (train_lora.py:141-290): k guided denoising passes with LoRA on,
+three LoRA-off passes, one LoRA-on pass, ESD loss, backward, (all-reduce,) AdamW.  k follows the
+seeded sequence `torch.Generator().manual_seed(0); randint(1, 50)` (mean 25), the same on all ranks.
+
+N > 1: one process per GPU (torchrun env), weak scaling -- every rank runs its own step on its own
+noise; the only collective is the all-reduce of the flat LoRA gradient slab.  `value` is the
+whole-job rate: world_size * K / max-over-ranks wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+F_FWD_SD15_512 = 0.8033e12   # FLOPs of one sample-pass
+ATTN_SHARE = 0.157
+PEAK_BF16 = 2.5e15           # dense bf16 MFMA, MI355X_MICROARCH.md
+
+
+def step_flops(bs: int, k: int) -> float:
+    """Reference-faithful algorithmic work of one step: W_ref(k) = 2 bs F_fwd (k + 4 + 1 + a)."""
+    return 2 * bs * F_FWD_SD15_512 * (k + 5 + ATTN_SHARE)
+
+
+def cpu_baseline(seconds_budget: float = 30.0):
+    """The oracle (CPU restatement of the reference's diffusers UNet) timed on the host cores:
+    whole fp32 B=2 SD1.5 forward passes at 512^2 (config 0: bs=1), extrapolated to a k=25 step with
+    W_ref(k): t_step = (k + 4) t_fwd + (1 + 1 + a) t_fwd."""
+    from oracle import unet_ref as R
+    torch.manual_seed(0)
+    with torch.device("cpu"):
+        m = R.UNet2DConditionModel(R.sd15_config())
+    m.requires_grad_(False)
+    x = torch.randn(2, 4, 64, 64)
+    ctx = torch.randn(2, 77, 768)
+    times = []
+    t_start = time.perf_counter()
+    with torch.no_grad():
+        while len(times) < 3 and (time.perf_counter() - t_start) < seconds_budget:
+            t0 = time.perf_counter()
+            m(x, torch.tensor(500), encoder_hidden_states=ctx)
+            times.append(time.perf_counter() - t0)
+    t_fwd = min(times)
+    k = 25
+    t_step = (k + 4) * t_fwd + (2 + ATTN_SHARE) * t_fwd
+    return {"value": 1.0 / t_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} fp32 forward passes of the oracle SD1.5 UNet (B=2, 512^2, bs=1) = {t_fwd:.2f} s "
+                      f"each, extrapolated to one k=25 step with W_ref(k) (fwd-equivalents: k+4 fwd, 1 fwd + bwd)",
+            "host_cpus": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--arch", default="sd15")
+    ap.add_argument("--bs", type=int, default=2)
+    ap.add_argument("--res", type=int, default=512)
+    ap.add_argument("--rank", type=int, default=4)
+    args = ap.parse_args()
+
+    from leco_amd import model_util, prompt_util, train_util
+    from leco_amd.lora import LoRANetwork
+    from leco_amd.train import FusedStep, init_distributed
+
+    rank, world, local = init_distributed()
+    assert world == args.gpus or world == 1 and args.gpus == 1, f"launch with torchrun --nproc-per-node {args.gpus}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    import io
+    import contextlib
+    tokenizer, text_encoder, unet, sched = model_util.load_models(f"synthetic:{args.arch}", "ddim")
+    unet.to(dev, dtype=torch.bfloat16)
+    unet.requires_grad_(False)
+    unet.eval()
+    unet.use_graphs = not args.no_graphs
+    torch.manual_seed(1234)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(unet, rank=args.rank, multiplier=1.0, alpha=1.0).to(dev)
+    # lora_up starts at zero in the reference; give it a small value so the LoRA path does real work
+    g = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        for l in net.unet_loras:
+            l.lora_up.weight.copy_((torch.randn(l.lora_up.weight.shape, generator=g) * 0.02).to(dev))
+    net.mark_updated()
+    settings = prompt_util.PromptSettings(target="van gogh", positive="van gogh", unconditional="", neutral="",
+                                          action="erase", guidance_scale=1.0, resolution=args.res, batch_size=args.bs)
+    emb = {p: text_encoder([p])[0] for p in ("van gogh", "")}
+    pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["van gogh"], emb["van gogh"], emb[""], emb[""], settings)
+    fused = FusedStep(unet, net, sched, 50, lr=1e-4, world_size=world)
+
+    kgen = torch.Generator().manual_seed(0)
+    ks = [torch.randint(1, 50, (1,), generator=kgen).item() for _ in range(args.warmup + args.steps)]
+    noise_gen = torch.Generator().manual_seed(1000 + rank)
+
+    def one(i):
+        lat = train_util.get_initial_latents(sched, args.bs, args.res, args.res, 1, generator=noise_gen)
+        return fused.step(pair, ks[i], lat)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        one(i)
+    barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for i in range(args.warmup, args.warmup + args.steps):
+        loss = one(i)
+    e1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    dt_ev = e0.elapsed_time(e1) * 1e-3
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank != 0:
+        return
+    timed_ks = ks[args.warmup:]
+    flops = sum(step_flops(args.bs, k) for k in timed_ks)
+    achieved = flops / dt_ev / 1e12
+    out = {
+        "metric": "LECO train-steps/sec, SDv1.5 rank-4 512px bs=2", "value": world * args.steps / dt, "unit": "steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"SDv1.5 UNet (random init) LECO erase step, LoRA rank {args.rank} lierla, "
+                               f"{args.res}x{args.res}, prompt batch {args.bs} (UNet batch {2 * args.bs}), DDIM 50, "
+                               f"reference-faithful pass structure (k+3+1 fwd, 1 bwd)",
+                   "global_batch": args.bs * world, "k_sequence_seed": 0, "k_mean": sum(timed_ks) / len(timed_ks),
+                   "hip_graphs": bool(unet.use_graphs), "parallelism": f"dp{world}", "loss": float(loss.item())},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                     "frac": achieved / (PEAK_BF16 / 1e12), "traffic": None,
+                     "note": "algorithmic FLOPs W_ref(k)=2*bs*F_fwd*(k+5+a) summed over the timed steps / HIP-event "
+                             "time on the compute stream (rank 0); per-kernel breakdown in profiles/"},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline()
+        except Exception as e:  # the baseline leg must never hide the GPU number
+            out["cpu_baseline"] = {"value": None, "error": repr(e)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

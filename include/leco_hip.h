@@ -64,6 +64,7 @@ typedef struct leco_gemm_args {
     const float* bias;        /* fp32 [N] or NULL */
     const float* rowbias;     /* fp32 [M/rows_per_group][N] or NULL (time-embedding add) */
     int32_t rows_per_group;
+    int64_t ld_rowbias;       /* row stride of rowbias (elements) */
     const void* residual;     /* bf16 [M][N] (row stride ldr) or NULL */
     int64_t ldr;
     int32_t act;

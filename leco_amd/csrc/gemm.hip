@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, int t
     for (int i = 0; i < FM; ++i) {
         const int m = m0 + wave_m * WM + i * 16 + fr;
         if (m >= M) continue;
-        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * N : nullptr;
+        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias : nullptr;
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
             const int n = n0 + wave_n * WN + j * 16 + 4 * fg;

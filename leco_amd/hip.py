@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
         ("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32),
         ("a_ext", C.c_void_p), ("ld_aext", C.c_int64), ("w_ext", C.c_void_p), ("ld_wext", C.c_int64),
         ("ext_k", C.c_int32),
-        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("rows_per_group", C.c_int32),
+        ("bias", C.c_void_p), ("rowbias", C.c_void_p), ("rows_per_group", C.c_int32), ("ld_rowbias", C.c_int64),
         ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("act", C.c_int32),
         ("c", C.c_void_p), ("ldc", C.c_int64), ("c_f32", C.c_void_p), ("ldc32", C.c_int64),
@@ -118,8 +118,11 @@ def stream_ptr(t: Optional[torch.Tensor] = None) -> Optional[int]:
     return torch.cuda.current_stream().cuda_stream
 
 
-def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
+def ptr(t) -> Optional[int]:
+    """Device address of a tensor (ints / None pass through, so views can be given as raw addresses)."""
+    if t is None or isinstance(t, int):
+        return t
+    return t.data_ptr()
 
 
 def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, m: int, n: int, k: int,
@@ -128,7 +131,7 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, 
               a_ext: Optional[torch.Tensor] = None, w_ext: Optional[torch.Tensor] = None, ext_k: int = 0,
               ld_aext: int = 0, ld_wext: int = 0,
               bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
-              rows_per_group: int = 0, residual: Optional[torch.Tensor] = None, ldr: int = 0,
+              rows_per_group: int = 0, ld_rowbias: int = 0, residual: Optional[torch.Tensor] = None, ldr: int = 0,
               act: int = ACT_NONE, ldc: Optional[int] = None, out_f32: Optional[torch.Tensor] = None,
               ldc32: int = 0) -> GemmArgs:
     """Build the argument block for leco_gemm.  ``conv`` = (batch, h_out, w_out, h_in, w_in)."""
@@ -147,6 +150,7 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, 
     g.a_ext, g.w_ext, g.ext_k = ptr(a_ext), ptr(w_ext), ext_k
     g.ld_aext, g.ld_wext = ld_aext or ext_k, ld_wext or ext_k
     g.bias, g.rowbias, g.rows_per_group = ptr(bias), ptr(rowbias), rows_per_group
+    g.ld_rowbias = ld_rowbias or n
     g.residual, g.ldr = ptr(residual), ldr or n
     g.act = act
     g.c, g.ldc = ptr(out), (n if ldc is None else ldc)

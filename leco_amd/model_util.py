@@ -1,0 +1,137 @@
+"""Model loading -- interface of the reference's ``model_util.py`` (``load_models`` :104-129,
+``load_models_xl`` :205-227, ``create_noise_scheduler`` :230-278) without diffusers:
+
+* a diffusers-format folder (``unet/config.json`` + ``unet/diffusion_pytorch_model.safetensors``,
+  ``tokenizer/``, ``text_encoder/``) is read directly: the UNet module tree here uses the diffusers
+  state-dict key names, so ``load_state_dict`` applies as is; CLIP comes from ``transformers``;
+* ``synthetic:<sd15|sd21|sdxl|tiny>`` builds a seeded random-init UNet of that architecture and a
+  deterministic stand-in text encoder (there are no checkpoints and no network on the build /
+  benchmark boxes);
+* single-file ``.ckpt`` / ``.safetensors`` checkpoints (LDM key layout) are a "next" row
+   and raise for now.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import math
+import os
+from typing import Optional
+
+import torch
+
+from .scheduler import create_noise_scheduler  # noqa: F401  (re-exported, model_util.py:230)
+from .unet import UNet2DConditionModel, UNetConfig, sd15_config, sd21_config, sdxl_config
+
+TOKENIZER_V1_MODEL_NAME = "CompVis/stable-diffusion-v1-4"
+TOKENIZER_V2_MODEL_NAME = "stabilityai/stable-diffusion-2-1"
+
+
+def tiny_config(linear_proj: bool = False) -> UNetConfig:
+    return UNetConfig(block_out_channels=(64, 128, 128, 128), layers_per_block=1, attention_head_dim=2,
+                      cross_attention_dim=64, use_linear_projection=linear_proj, sample_size=16)
+
+
+SYNTHETIC = {"sd15": sd15_config, "sd21": sd21_config, "sdxl": sdxl_config, "tiny": tiny_config}
+
+
+def init_synthetic_(unet: torch.nn.Module, seed: int = 1234) -> torch.nn.Module:
+    """Seeded PyTorch-default-style init (U(+-1/sqrt(fan_in)) for conv/linear weights, norm
+    gamma=1 / beta=0); keeps activations O(1) through every block."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in unet.named_parameters():
+            if p.ndim >= 2:
+                bound = 1.0 / math.sqrt(p[0].numel())
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+            elif "norm" in name:
+                p.fill_(1.0 if name.endswith("weight") else 0.0)
+            else:
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * 0.02)
+    return unet
+
+
+class SyntheticTokenizer:
+    model_max_length = 77
+
+    def __call__(self, prompts, **kw):
+        class _Out:
+            pass
+        o = _Out()
+        o.input_ids = list(prompts)
+        return o
+
+
+class SyntheticTextEncoder(torch.nn.Module):
+    """Deterministic stand-in for CLIP: embeds a prompt string as N(0,1) noise seeded by its hash
+    (``randn(1,77,C)``).  ``[0]`` of the output is the (1,77,C) embedding."""
+
+    def __init__(self, dim: int, pooled_dim: Optional[int] = None):
+        super().__init__()
+        self.dim, self.pooled_dim = dim, pooled_dim
+        self._p = torch.nn.Parameter(torch.zeros(1))
+
+    @property
+    def device(self):
+        return self._p.device
+
+    def embed(self, prompt: str) -> torch.Tensor:
+        seed = int.from_bytes(hashlib.sha256(prompt.encode()).digest()[:4], "little")
+        g = torch.Generator().manual_seed(4321 + seed)
+        return torch.randn(1, 77, self.dim, generator=g)
+
+    def forward(self, tokens, **kw):
+        emb = torch.cat([self.embed(p) for p in tokens]).to(self._p.device, self._p.dtype)
+        return (emb,)
+
+
+def _load_unet_folder(path: str) -> UNet2DConditionModel:
+    with open(os.path.join(path, "config.json")) as f:
+        cfg = UNetConfig.from_dict(json.load(f))
+    unet = UNet2DConditionModel(cfg)
+    st = os.path.join(path, "diffusion_pytorch_model.safetensors")
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        sd = load_file(st)
+    else:
+        sd = torch.load(os.path.join(path, "diffusion_pytorch_model.bin"), map_location="cpu")
+    missing, unexpected = unet.load_state_dict(sd, strict=False)
+    if missing:
+        raise KeyError(f"UNet checkpoint {path} lacks keys, e.g. {missing[:5]}")
+    return unet
+
+
+def load_diffusers_model(path: str, v2: bool = False, clip_skip: Optional[int] = None,
+                         weight_dtype: torch.dtype = torch.float32):
+    from transformers import CLIPTextModel, CLIPTokenizer
+    tokenizer = CLIPTokenizer.from_pretrained(path, subfolder="tokenizer")
+    full = 24 if v2 else 12
+    default_layers = 23 if v2 else 12  # v2: penultimate layer (model_util.py:43-49)
+    nl = full - (clip_skip - 1) if clip_skip is not None else default_layers
+    text_encoder = CLIPTextModel.from_pretrained(path, subfolder="text_encoder", num_hidden_layers=nl,
+                                                 torch_dtype=weight_dtype)
+    unet = _load_unet_folder(os.path.join(path, "unet")).to(weight_dtype)
+    return tokenizer, text_encoder, unet
+
+
+def load_synthetic_model(kind: str, seed: int = 1234):
+    cfg = SYNTHETIC[kind]()
+    unet = init_synthetic_(UNet2DConditionModel(cfg), seed)
+    return SyntheticTokenizer(), SyntheticTextEncoder(cfg.cross_attention_dim), unet
+
+
+def load_models(pretrained_model_name_or_path: str, scheduler_name: str, v2: bool = False, v_pred: bool = False,
+                weight_dtype: torch.dtype = torch.float32):
+    p = pretrained_model_name_or_path
+    if p.startswith("synthetic:"):
+        tokenizer, text_encoder, unet = load_synthetic_model(p.split(":", 1)[1])
+    elif p.endswith(".ckpt") or p.endswith(".safetensors"):
+        raise NotImplementedError("single-file LDM checkpoints are not converted yet; pass a diffusers-format "
+                                  "folder (unet/, tokenizer/, text_encoder/) or synthetic:<arch>")
+    elif os.path.isdir(p):
+        tokenizer, text_encoder, unet = load_diffusers_model(p, v2=v2, weight_dtype=weight_dtype)
+    else:
+        raise FileNotFoundError(f"{p}: not a local diffusers folder (no network access on this system); "
+                                f"use a local path or synthetic:<sd15|sd21|sdxl|tiny>")
+    scheduler = create_noise_scheduler(scheduler_name, prediction_type="v_prediction" if v_pred else "epsilon")
+    return tokenizer, text_encoder, unet, scheduler

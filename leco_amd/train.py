@@ -1,0 +1,300 @@
+"""LECO training loop on the MI355X hot path.
+
+``train(config, prompts)`` has the reference's signature and observable behaviour
+(train_lora.py:34-321): same config / prompt objects, same per-iteration sampling (prompt pair,
+``timesteps_to`` in [1, max_denoising_steps), resolution bucket, CPU Gaussian latents), same
+save cadence and file names.  The per-step arithmetic (train_lora.py:141-290) is executed by
+:class:`FusedStep`:
+
+  1. k LoRA-ON classifier-free-guided UNet passes + DDIM updates (train_util.py:172-193);
+     each pass is ONE hipGraph launch (UNet forward + guidance combine + DDIM update + timestep
+     advance, all reading their scalars from device memory);
+  2. three LoRA-OFF passes (positive / neutral / unconditional) at t = timesteps1000[k*1000/n]
+     (train_lora.py:195-237) -- the predictions stay on the device (the reference copies each
+     to the host);
+  3. one LoRA-ON pass for the target prompt whose activations are kept;
+  4. ESD objective + its gradient in one kernel (prompt_util.py:107-135, fp32, on device);
+  5. backward plan (dgrad through the UNet, wgrad of LoRA down/up only) into the flat fp32
+     gradient slab;
+  6. data parallel: ONE all-reduce (RCCL over xGMI) of that slab -- no other collective;
+  7. fused AdamW on the flat fp32 master slab, refreshing the bf16 shadow the kernels read.
+
+Nothing in a step synchronises with the host; ``loss`` is a device scalar.
+"""
+from __future__ import annotations
+
+import ast
+import math
+import os
+from pathlib import Path
+from typing import List, Optional
+
+import torch
+
+from . import config_util, model_util, ops, prompt_util, train_util
+from .config_util import RootConfig
+from .lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV, LoRANetwork
+from .prompt_util import PromptEmbedsCache, PromptEmbedsPair, PromptSettings
+
+DENOISE_GUIDANCE = 3.0  # hard-coded in the reference loop (train_lora.py:192)
+
+
+def dist_info():
+    """(rank, world, local_rank) from the torchrun environment; (0, 1, 0) when single-process."""
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+
+
+def init_distributed(backend: Optional[str] = None):
+    import torch.distributed as dist
+    rank, world, local = dist_info()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class FusedStep:
+    """One optimizer step of LECO training as launch plans on the UNet engine."""
+
+    def __init__(self, unet, network: LoRANetwork, scheduler, max_denoising_steps: int = 50, lr: float = 1e-4,
+                 betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, world_size: int = 1,
+                 process_group=None):
+        self.unet, self.net, self.sched = unet, network, scheduler
+        self.n_steps = max_denoising_steps
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.world, self.pg = world_size, process_group
+        self.opt_step = 0
+        dev = unet.device
+        self.dev = dev
+        # device-side schedule tables
+        scheduler.set_timesteps(max_denoising_steps)
+        self.ts_f = scheduler.timesteps.to(torch.float32).to(dev)          # [n] 980, 960, ...
+        self.coef = scheduler.coef_table().to(dev).contiguous()            # [n][2]
+        self.all_t = torch.arange(0, scheduler.num_train_timesteps, dtype=torch.float32, device=dev)
+        self.single_slot = 512
+        self.slot_idx = torch.tensor([self.single_slot], dtype=torch.int32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ctx_cache = {}
+        self._state = {}
+
+    # ---- per (batch, h, w) state: latents + per-pass prediction copies + the denoise plan -----------
+    def _bucket(self, bs: int, h: int, w: int):
+        key = (bs, h, w)
+        st = self._state.get(key)
+        if st is None:
+            plan = self.unet.prepare((2 * bs, 4, h, w), lora_on=True)
+            st = dict(plan=plan,
+                      x=torch.zeros(bs, 4, h, w, dtype=torch.float32, device=self.dev),
+                      preds={n: torch.zeros_like(plan.pred) for n in ("positive", "neutral", "unconditional")},
+                      half_n=bs * 4 * h * w)
+            tail = [ops.cfg_ddim_step(plan.pred, st["x"], plan.x_in, self.coef, plan.t_idx, DENOISE_GUIDANCE,
+                                      st["half_n"]),
+                    ops.advance(plan.t_idx)]
+            plan.lists["denoise"] = plan.lists["fwd_on"] + tail
+            self._state[key] = st
+        return st
+
+    def _ctx(self, pair: PromptEmbedsPair, which: str, bs: int) -> torch.Tensor:
+        key = (id(pair), which, bs)
+        c = self._ctx_cache.get(key)
+        if c is None:
+            c = train_util.concat_embeddings(pair.unconditional, getattr(pair, which), bs)
+            c = c.to(self.dev, torch.bfloat16).contiguous()
+            self._ctx_cache[key] = c
+        return c
+
+    def _run(self, plan, which: str):
+        self.unet._run(plan, which)
+
+    @torch.no_grad()
+    def step(self, pair: PromptEmbedsPair, timesteps_to: int, latents: torch.Tensor, lr: Optional[float] = None):
+        """``latents``: (bs,4,h,w) initial noise (any device / dtype), as returned by
+        ``train_util.get_initial_latents``.  Returns the loss as a 1-element device tensor."""
+        net, unet = self.net, self.unet
+        bs, _, h, w = latents.shape
+        st = self._bucket(bs, h, w)
+        plan = st["plan"]
+        k = int(timesteps_to)
+        n = self.n_steps
+        # 1. partial denoising with LoRA on (train_lora.py:179-193)
+        net.multiplier = 1.0
+        unet.prepare((2 * bs, 4, h, w), lora_on=True)   # re-packs LoRA operands if the slab changed
+        x = st["x"]
+        x.copy_(latents.to(self.dev, torch.float32))
+        plan.x_in.copy_(torch.cat([x, x]).to(torch.bfloat16))
+        plan.ctx.copy_(self._ctx(pair, "target", bs))
+        plan.t_table[:n].copy_(self.ts_f)
+        plan.t_idx.zero_()
+        for _ in range(k):
+            self._run(plan, "denoise")
+        # 2. frozen predictions at the "current" timestep (train_lora.py:195-237)
+        t_cur = int(self.sched.num_train_timesteps - 1 - int(k * self.sched.num_train_timesteps / n))
+        plan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])
+        plan.t_idx.copy_(self.slot_idx)
+        net.multiplier = 0
+        for which in ("positive", "neutral", "unconditional"):
+            plan.ctx.copy_(self._ctx(pair, which, bs))
+            self._run(plan, "fwd_off")
+            st["preds"][which].copy_(plan.pred)
+        # 3. target prediction with LoRA on; activations stay resident for the backward
+        net.multiplier = 1.0
+        plan.ctx.copy_(self._ctx(pair, "target", bs))
+        self._run(plan, "fwd_on")
+        # 4. ESD objective + gradient w.r.t. the raw target prediction
+        ops.esd_loss(plan.pred, st["preds"]["positive"], st["preds"]["neutral"], st["preds"]["unconditional"], 1.0,
+                     float(pair.guidance_scale), pair.sign, st["half_n"], self.loss, plan.dpred).run()
+        # 5. backward into the flat gradient slab
+        net.grad.zero_()
+        self._run(plan, "bwd")
+        net.multiplier = 0  # the reference leaves the `with network:` block here
+        # 6. data parallel: one all-reduce of the LoRA gradient slab
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(net.grad, group=self.pg)
+        # 7. fused AdamW on the fp32 master slab (+ bf16 shadow)
+        self.opt_step += 1
+        b1, b2 = self.betas
+        lr = self.lr if lr is None else lr
+        net.hyper.copy_(torch.tensor([lr, 1 - b1 ** self.opt_step, 1 - b2 ** self.opt_step, 1.0 / self.world]),
+                        non_blocking=True)
+        ops.adamw(net.slab.detach(), net.grad, net.exp_avg, net.exp_avg_sq, net.shadow, net.hyper, b1, b2, self.eps,
+                  self.wd, net.slab.numel()).run()
+        net.mark_updated()
+        return self.loss
+
+
+def flush():
+    import gc
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    gc.collect()
+
+
+def _parse_optimizer_args(s: str) -> dict:
+    kwargs = {}
+    if s is not None and len(s) > 0:
+        for arg in s.split(" "):
+            key, value = arg.split("=")
+            kwargs[key] = ast.literal_eval(value)
+    return kwargs
+
+
+def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[torch.device] = None,
+          use_graphs: bool = True, progress: bool = True):
+    """Reference entry point ``train(config, prompts)`` (train_lora.py:34).  Extra keyword
+    arguments only select the device and execution mode."""
+    rank, world, local = init_distributed()
+    if device is None:
+        device = torch.device(f"cuda:{local}" if torch.cuda.is_available() else "cpu")
+    if device.type == "cuda":
+        torch.cuda.set_device(device)
+    metadata = {"prompts": ",".join([p.model_dump_json() for p in prompts]), "config": config.model_dump_json()}
+    save_path = Path(config.save.path)
+    modules = list(DEFAULT_TARGET_REPLACE)
+    if config.network.type == "c3lier":
+        modules += UNET_TARGET_REPLACE_MODULE_CONV
+    if config.logging.verbose:
+        print(metadata)
+    wandb = None
+    if config.logging.use_wandb and rank == 0:
+        import wandb  # optional dependency, only when requested
+        wandb.init(project=f"LECO_{config.save.name}", config=metadata)
+    weight_dtype = config_util.parse_precision(config.train.precision)
+    save_weight_dtype = config_util.parse_precision(config.train.precision)  # sic, train_lora.py:55
+    if weight_dtype != torch.bfloat16:
+        print(f"note: the MI355X path computes in bf16 MFMA with fp32 accumulation; train.precision="
+              f"{config.train.precision} only selects the dtype of the saved LoRA.")
+
+    tokenizer, text_encoder, unet, noise_scheduler = model_util.load_models(
+        config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler,
+        v2=config.pretrained_model.v2, v_pred=config.pretrained_model.v_pred)
+    text_encoder.to(device, dtype=torch.bfloat16)
+    text_encoder.eval()
+    unet.to(device, dtype=torch.bfloat16)
+    unet.enable_xformers_memory_efficient_attention()
+    unet.requires_grad_(False)
+    unet.eval()
+    unet.use_graphs = use_graphs and device.type == "cuda"
+
+    if world > 1:   # identical LoRA init on every rank
+        torch.manual_seed(1234)
+    network = LoRANetwork(unet, rank=config.network.rank, multiplier=1.0, alpha=config.network.alpha,
+                          train_method=config.network.training_method, target_replace_modules=modules
+                          ).to(device, dtype=weight_dtype)
+
+    opt_name = config.train.optimizer.lower()
+    optimizer_kwargs = _parse_optimizer_args(config.train.optimizer_args)
+    if opt_name not in ("adam", "adamw"):
+        raise NotImplementedError(f"optimizer '{config.train.optimizer}': only adam / adamw run fused on the MI355X "
+                                  f"path (the other names need packages that are not installed here)")
+    wd_default = 1e-2 if opt_name == "adamw" else 0.0
+    fused = FusedStep(unet, network, noise_scheduler, config.train.max_denoising_steps, lr=config.train.lr,
+                      betas=tuple(optimizer_kwargs.get("betas", (0.9, 0.999))), eps=optimizer_kwargs.get("eps", 1e-8),
+                      weight_decay=optimizer_kwargs.get("weight_decay", wd_default), world_size=world)
+    # LR schedule: drive torch's own scheduler objects on a dummy parameter so the values are exact
+    _dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=config.train.lr)
+    lr_scheduler = train_util.get_lr_scheduler(config.train.lr_scheduler, _dummy, max_iterations=config.train.iterations,
+                                               lr_min=config.train.lr / 100)
+    criteria = torch.nn.MSELoss()
+
+    print("Prompts")
+    cache = PromptEmbedsCache()
+    prompt_pairs: List[PromptEmbedsPair] = []
+    with torch.no_grad():
+        for settings in prompts:
+            print(settings)
+            for prompt in [settings.target, settings.positive, settings.neutral, settings.unconditional]:
+                if cache[prompt] is None:
+                    cache[prompt] = train_util.encode_prompts(tokenizer, text_encoder, [prompt])
+            prompt_pairs.append(PromptEmbedsPair(criteria, cache[settings.target], cache[settings.positive],
+                                                 cache[settings.unconditional], cache[settings.neutral], settings))
+    del tokenizer
+    del text_encoder
+    flush()
+
+    it = range(config.train.iterations)
+    pbar = None
+    if progress and rank == 0:
+        from tqdm import tqdm
+        pbar = it = tqdm(it)
+    # DP: every rank draws its own prompt pair / noise, but the SAME k (shared-seed generator) so that
+    # all ranks run the same number of denoising passes.
+    k_gen = torch.Generator().manual_seed(20230701) if world > 1 else None
+    loss = None
+    for i in it:
+        pair = prompt_pairs[torch.randint(0, len(prompt_pairs), (1,)).item()]
+        timesteps_to = torch.randint(1, config.train.max_denoising_steps, (1,), generator=k_gen).item()
+        height, width = pair.resolution, pair.resolution
+        if pair.dynamic_resolution:
+            height, width = train_util.get_random_resolution_in_bucket(pair.resolution)
+        if config.logging.verbose:
+            print("gudance_scale:", pair.guidance_scale, "resolution:", pair.resolution, "dynamic_resolution:",
+                  pair.dynamic_resolution, (height, width), "batch_size:", pair.batch_size)
+        latents = train_util.get_initial_latents(noise_scheduler, pair.batch_size, height, width, 1)
+        loss = fused.step(pair, timesteps_to, latents, lr=lr_scheduler.get_last_lr()[0])
+        if pbar is not None and (i % 10 == 0 or config.logging.verbose):
+            pbar.set_description(f"Loss*1k: {loss.item() * 1000:.4f}")
+        if wandb is not None:
+            wandb.log({"loss": loss.item(), "iteration": i, "lr": lr_scheduler.get_last_lr()[0]})
+        _dummy.step()
+        lr_scheduler.step()
+        if i % config.save.per_steps == 0 and i != 0 and i != config.train.iterations - 1 and rank == 0:
+            print("Saving...")
+            save_path.mkdir(parents=True, exist_ok=True)
+            network.save_weights(save_path / f"{config.save.name}_{i}steps.safetensors", dtype=save_weight_dtype)
+    if rank == 0:
+        print("Saving...")
+        save_path.mkdir(parents=True, exist_ok=True)
+        network.save_weights(save_path / f"{config.save.name}_last.safetensors", dtype=save_weight_dtype)
+    flush()
+    print("Done.")
+    return network, (loss.item() if loss is not None else None)
+
+
+def main(args):
+    config = config_util.load_config_from_yaml(args.config_file)
+    prompts = prompt_util.load_prompts_from_yaml(config.prompts_file)
+    train(config, prompts)

@@ -1,0 +1,1013 @@
+"""UNet2DConditionModel on the MI355X hot path.
+
+This module replaces ``diffusers.UNet2DConditionModel.forward`` and its autograd backward --
+the reference's call sites are ``train_util.py:156-160`` / ``:239-244`` (forward) and
+``train_lora.py:279`` (``loss.backward()``) -- with a *static launch plan* of the hand-written
+HIP kernels in ``libleco_hip.so``:
+
+* The module tree keeps the diffusers class / attribute names (``Transformer2DModel``,
+  ``ResnetBlock2D``, ``Downsample2D``, ``Upsample2D``; leaves are plain ``torch.nn.Linear`` /
+  ``torch.nn.Conv2d``) because the reference discovers LoRA targets and derives the saved key
+  names from them (``lora.py:169-199``), and so that diffusers-format state dicts load as is.
+  The leaves only *hold* weights; nothing here calls ``leaf.forward``.
+* For a given (batch, h, w) the engine builds ONE plan: every activation gets its own
+  pre-allocated channels-last bf16 buffer (288 GB of HBM: nothing is recomputed or re-used, so
+  the forward of the LoRA-on "target" pass doubles as the saved-activation set of the backward),
+  and every layer appends its kernel launches (``ops.Op``) to a forward list and pushes a
+  closure on a tape; unrolling the tape in reverse emits the backward list (dgrad everywhere
+  downstream of the first LoRA site, wgrad only for LoRA down/up).  A plan is replayed eagerly
+  or as one hipGraph launch.
+* Weight operands are re-laid once for the MFMA kernels: ``W[N][K]`` (conv: ``[N][kh][kw][Cin]``),
+  q|k|v fused to one ``[3C][C]`` GEMM, k|v of cross-attention fused, all 22 ``time_emb_proj``
+  fused into one GEMM; a transposed / flipped copy serves the dgrad GEMMs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import hip, ops
+from .hip import (ACT_NONE, ACT_SILU, A_CONV3_S1, A_CONV3_S2, A_CONV3_TR2, A_CONV3_UP2, A_PLAIN, gemm_args)
+
+bf16 = torch.bfloat16
+
+
+# =============================================================================================
+# configuration (public unet/config.json values of the three model families)
+# =============================================================================================
+@dataclass
+class UNetConfig:
+    in_channels: int = 4
+    out_channels: int = 4
+    block_out_channels: Tuple[int, ...] = (320, 640, 1280, 1280)
+    down_block_types: Tuple[str, ...] = ("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",)
+    up_block_types: Tuple[str, ...] = ("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3
+    layers_per_block: int = 2
+    transformer_layers_per_block: Union[int, Tuple[int, ...]] = 1
+    attention_head_dim: Union[int, Tuple[int, ...]] = 8  # diffusers' name; it is the head COUNT
+    cross_attention_dim: int = 768
+    use_linear_projection: bool = False
+    norm_num_groups: int = 32
+    norm_eps: float = 1e-5
+    sample_size: int = 64
+    addition_embed_type: Optional[str] = None
+    addition_time_embed_dim: int = 256
+    projection_class_embeddings_input_dim: int = 2816
+
+    def heads(self, level: int) -> int:
+        a = self.attention_head_dim
+        return a if isinstance(a, int) else a[level]
+
+    def depth(self, level: int) -> int:
+        a = self.transformer_layers_per_block
+        return a if isinstance(a, int) else a[level]
+
+    @classmethod
+    def from_dict(cls, d: dict) -> "UNetConfig":
+        keys = {f for f in cls.__dataclass_fields__}
+        kw = {k: (tuple(v) if isinstance(v, list) else v) for k, v in d.items() if k in keys}
+        return cls(**kw)
+
+
+def sd15_config() -> UNetConfig:
+    return UNetConfig()
+
+
+def sd21_config() -> UNetConfig:
+    return UNetConfig(attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024, use_linear_projection=True,
+                      sample_size=96)
+
+
+def sdxl_config() -> UNetConfig:
+    return UNetConfig(block_out_channels=(320, 640, 1280),
+                      down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                      up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"),
+                      transformer_layers_per_block=(1, 2, 10), attention_head_dim=(5, 10, 20),
+                      cross_attention_dim=2048, use_linear_projection=True, sample_size=128,
+                      addition_embed_type="text_time")
+
+
+# =============================================================================================
+# weight-holding module tree (names == diffusers state-dict keys)
+# =============================================================================================
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_dim, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb, groups, eps):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.norm1 = nn.GroupNorm(groups, cin, eps=eps)
+        self.conv1 = nn.Conv2d(cin, cout, 3, 1, 1)
+        self.time_emb_proj = nn.Linear(temb, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=eps)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1, 1, 0) if cin != cout else None
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, 2, 1)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, 1, 1)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, ctx_dim, heads):
+        super().__init__()
+        self.heads = heads
+        ctx_dim = dim if ctx_dim is None else ctx_dim
+        self.to_q = nn.Linear(dim, dim, bias=False)
+        self.to_k = nn.Linear(ctx_dim, dim, bias=False)
+        self.to_v = nn.Linear(ctx_dim, dim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Dropout(0.0)])
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, ctx_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, None, heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, ctx_dim, heads)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, dim, heads, ctx_dim, depth, groups, linear_proj):
+        super().__init__()
+        self.use_linear_projection = linear_proj
+        self.norm = nn.GroupNorm(groups, dim, eps=1e-6)
+        self.proj_in = nn.Linear(dim, dim) if linear_proj else nn.Conv2d(dim, dim, 1, 1, 0)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(dim, heads, ctx_dim) for _ in range(depth)])
+        self.proj_out = nn.Linear(dim, dim) if linear_proj else nn.Conv2d(dim, dim, 1, 1, 0)
+
+
+class _DownBlock(nn.Module):
+    def __init__(self, cfg, level, cin, cout, temb, attn, last):
+        super().__init__()
+        self.has_attn = attn
+        if attn:
+            self.attentions = nn.ModuleList([
+                Transformer2DModel(cout, cfg.heads(level), cfg.cross_attention_dim, cfg.depth(level),
+                                   cfg.norm_num_groups, cfg.use_linear_projection)
+                for _ in range(cfg.layers_per_block)])
+        self.resnets = nn.ModuleList([
+            ResnetBlock2D(cin if j == 0 else cout, cout, temb, cfg.norm_num_groups, cfg.norm_eps)
+            for j in range(cfg.layers_per_block)])
+        self.downsamplers = None if last else nn.ModuleList([Downsample2D(cout)])
+
+
+class CrossAttnDownBlock2D(_DownBlock):
+    pass
+
+
+class DownBlock2D(_DownBlock):
+    pass
+
+
+class UNetMidBlock2DCrossAttn(nn.Module):
+    def __init__(self, cfg, c, temb):
+        super().__init__()
+        lvl = len(cfg.block_out_channels) - 1
+        self.attentions = nn.ModuleList([
+            Transformer2DModel(c, cfg.heads(lvl), cfg.cross_attention_dim, cfg.depth(lvl), cfg.norm_num_groups,
+                               cfg.use_linear_projection)])
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, cfg.norm_num_groups, cfg.norm_eps) for _ in range(2)])
+
+
+class _UpBlock(nn.Module):
+    def __init__(self, cfg, level, prev, cout, skip_last, temb, attn, last):
+        super().__init__()
+        self.has_attn = attn
+        n = cfg.layers_per_block + 1
+        if attn:
+            self.attentions = nn.ModuleList([
+                Transformer2DModel(cout, cfg.heads(level), cfg.cross_attention_dim, cfg.depth(level),
+                                   cfg.norm_num_groups, cfg.use_linear_projection) for _ in range(n)])
+        res = []
+        for j in range(n):
+            skip = skip_last if j == n - 1 else cout
+            rin = prev if j == 0 else cout
+            res.append(ResnetBlock2D(rin + skip, cout, temb, cfg.norm_num_groups, cfg.norm_eps))
+        self.resnets = nn.ModuleList(res)
+        self.upsamplers = None if last else nn.ModuleList([Upsample2D(cout)])
+
+
+class CrossAttnUpBlock2D(_UpBlock):
+    pass
+
+
+class UpBlock2D(_UpBlock):
+    pass
+
+
+class UNetOutput:
+    def __init__(self, sample):
+        self.sample = sample
+
+
+# =============================================================================================
+# plan-time tensors and the build-time autograd tape
+# =============================================================================================
+class TRef:
+    """A row-major [rows][cols] bf16 activation view (row stride ``ld``) inside a device buffer."""
+    __slots__ = ("t", "ptr", "ld", "rows", "cols", "rg", "gparts", "name")
+
+    def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None, offset: int = 0,
+                 rg: bool = False, name: str = ""):
+        self.t = t
+        self.ptr = t.data_ptr() + offset * t.element_size()
+        self.ld = cols if ld is None else ld
+        self.rows, self.cols = rows, cols
+        self.rg = rg            # requires grad (some LoRA site is upstream)
+        self.gparts: List["TRef"] = []
+        self.name = name
+
+    def cols_view(self, c0: int, c1: int) -> "TRef":
+        v = TRef(self.t, self.rows, c1 - c0, self.ld, 0, self.rg, self.name)
+        v.ptr = self.ptr + c0 * 2
+        return v
+
+
+class LoraSiteState:
+    """Packed MFMA operands of one GEMM site that has LoRA modules attached."""
+
+    def __init__(self, site: "GemmSite", mods: list, r: int, dev):
+        self.mods = mods  # per group: LoRAModule or None
+        self.r = r
+        g = len(mods)
+        self.R = g * r
+        self.R16 = (self.R + 15) // 16 * 16
+        self.Rp = (self.R + 31) // 32 * 32
+        if self.Rp > 64:
+            raise ValueError(f"LoRA rank {r} x {g} fused groups exceeds the 64-wide K-extension tile")
+        K, N = site.lora_k, site.n
+        # dn_s / up_t get Rp rows (rows beyond R16 stay zero) so they can be GEMM weight operands
+        self.dn_s = torch.zeros(self.Rp, K, dtype=bf16, device=dev)
+        self.up_p = torch.zeros(N, self.Rp, dtype=bf16, device=dev)
+        self.up_t = torch.zeros(self.Rp, N, dtype=bf16, device=dev)
+        self.dn_p = torch.zeros(K, self.Rp, dtype=bf16, device=dev)
+
+
+class GemmSite:
+    """One contraction of the UNet (possibly several fused leaves) with its packed operands."""
+
+    def __init__(self, eng: "Engine", name: str, leaves: Sequence[Tuple[str, nn.Module]], conv3: bool = False,
+                 stride2: bool = False, up2: bool = False, extra_bias: Optional[torch.Tensor] = None):
+        self.eng, self.name = eng, name
+        self.leaf_names = [n for n, _ in leaves]
+        self.conv3, self.stride2, self.up2 = conv3, stride2, up2
+        dev = eng.device
+        ws, bs = [], []
+        for _, m in leaves:
+            w = m.weight.detach()
+            if w.ndim == 4 and w.shape[2] == 3:
+                w = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)  # [N][kh][kw][Cin]
+            elif w.ndim == 4:
+                w = w.reshape(w.shape[0], -1)
+            ws.append(w)
+            bs.append(None if m.bias is None else m.bias.detach().float())
+        self.group_n = ws[0].shape[0]
+        self.w = torch.cat(ws, 0).to(device=dev, dtype=bf16).contiguous()
+        self.n, self.k = self.w.shape
+        self.cin = self.k // 9 if conv3 else self.k
+        self.lora_k = self.k
+        if any(b is not None for b in bs):
+            self.bias = torch.cat([b if b is not None else torch.zeros(w.shape[0]) for b, w in zip(bs, ws)]).to(dev)
+        else:
+            self.bias = None
+        self._wt = None
+        self.lora: Optional[LoraSiteState] = None
+
+    @property
+    def wt(self) -> torch.Tensor:
+        """dgrad operand: W^T [K][N] (conv: spatially flipped, in/out swapped, [Cin][kh][kw][Cout])."""
+        if self._wt is None:
+            if self.conv3:
+                w4 = self.w.reshape(self.n, 3, 3, self.cin)
+                self._wt = w4.flip(1, 2).permute(3, 1, 2, 0).reshape(self.cin, 9 * self.n).contiguous()
+            else:
+                self._wt = self.w.t().contiguous()
+        return self._wt
+
+
+# =============================================================================================
+# the engine
+# =============================================================================================
+class Plan:
+    def __init__(self):
+        # named launch lists; callers may add their own (e.g. the fused denoising pass)
+        self.lists: Dict[str, List[ops.Op]] = {"fwd_on": [], "fwd_off": [], "bwd": []}
+        self.fwd: Dict[bool, List[ops.Op]] = {True: self.lists["fwd_on"], False: self.lists["fwd_off"]}
+        self.bwd: List[ops.Op] = self.lists["bwd"]
+        self.bufs: Dict[str, torch.Tensor] = {}
+        self.graphs: Dict[str, C.c_void_p] = {}
+
+
+class Engine:
+    def __init__(self, unet: "UNet2DConditionModel", device: torch.device):
+        self.unet, self.cfg, self.device = unet, unet.cfg, device
+        self.sites: Dict[str, GemmSite] = {}      # by site name
+        self.leaf_site: Dict[str, Tuple[GemmSite, int]] = {}  # leaf qualified name -> (site, group)
+        self.plans: Dict[Tuple[int, int, int], Plan] = {}
+        self.network = None  # LoRANetwork (set by attach_lora)
+        self.use_graphs = False
+        self._pack()
+
+    # ---- weight packing ------------------------------------------------------------------------
+    def _site(self, name, leaves, **kw) -> GemmSite:
+        s = GemmSite(self, name, leaves, **kw)
+        self.sites[name] = s
+        for g, (ln, _) in enumerate(leaves):
+            self.leaf_site[ln] = (s, g)
+        return s
+
+    def _f32(self, t) -> torch.Tensor:
+        return t.detach().float().to(self.device).contiguous()
+
+    def _pack(self):
+        u = self.unet
+        named = dict(u.named_modules())
+        self.named = named
+        # fused time-embedding projection of every ResnetBlock2D (+ conv1 bias folded in)
+        self.resnets = [(n, m) for n, m in named.items() if isinstance(m, ResnetBlock2D)]
+        self.temb_off: Dict[str, int] = {}
+        off = 0
+        for n, m in self.resnets:
+            self.temb_off[n] = off
+            off += m.out_channels
+        self.temb_total = off
+        s = self._site("time_emb_proj_all", [(n + ".time_emb_proj", m.time_emb_proj) for n, m in self.resnets])
+        s.bias = torch.cat([(m.time_emb_proj.bias.detach().float() + m.conv1.bias.detach().float())
+                            for _, m in self.resnets]).to(self.device)
+        self._site("time_embedding.linear_1", [("time_embedding.linear_1", u.time_embedding.linear_1)])
+        self._site("time_embedding.linear_2", [("time_embedding.linear_2", u.time_embedding.linear_2)])
+        if self.cfg.addition_embed_type == "text_time":
+            self._site("add_embedding.linear_1", [("add_embedding.linear_1", u.add_embedding.linear_1)])
+            self._site("add_embedding.linear_2", [("add_embedding.linear_2", u.add_embedding.linear_2)])
+        self.conv_in_w = self._f32(u.conv_in.weight)
+        self.conv_in_b = self._f32(u.conv_in.bias)
+        self.conv_out_w = u.conv_out.weight.detach().permute(0, 2, 3, 1).contiguous().to(self.device, bf16)
+        self.conv_out_b = self._f32(u.conv_out.bias)
+        self.norm_p: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        for n, m in named.items():
+            if isinstance(m, (nn.GroupNorm, nn.LayerNorm)):
+                self.norm_p[n] = (self._f32(m.weight), self._f32(m.bias))
+            if isinstance(m, ResnetBlock2D):
+                c1 = self._site(n + ".conv1", [(n + ".conv1", m.conv1)], conv3=True)
+                c1.bias = None  # folded into the fused time-embedding bias
+                self._site(n + ".conv2", [(n + ".conv2", m.conv2)], conv3=True)
+                if m.conv_shortcut is not None:
+                    self._site(n + ".conv_shortcut", [(n + ".conv_shortcut", m.conv_shortcut)])
+            elif isinstance(m, Downsample2D):
+                self._site(n + ".conv", [(n + ".conv", m.conv)], conv3=True, stride2=True)
+            elif isinstance(m, Upsample2D):
+                self._site(n + ".conv", [(n + ".conv", m.conv)], conv3=True, up2=True)
+            elif isinstance(m, Transformer2DModel):
+                self._site(n + ".proj_in", [(n + ".proj_in", m.proj_in)])
+                self._site(n + ".proj_out", [(n + ".proj_out", m.proj_out)])
+            elif isinstance(m, BasicTransformerBlock):
+                a1, a2 = m.attn1, m.attn2
+                self._site(n + ".attn1.qkv", [(n + ".attn1.to_q", a1.to_q), (n + ".attn1.to_k", a1.to_k),
+                                              (n + ".attn1.to_v", a1.to_v)])
+                self._site(n + ".attn1.to_out.0", [(n + ".attn1.to_out.0", a1.to_out[0])])
+                self._site(n + ".attn2.to_q", [(n + ".attn2.to_q", a2.to_q)])
+                self._site(n + ".attn2.kv", [(n + ".attn2.to_k", a2.to_k), (n + ".attn2.to_v", a2.to_v)])
+                self._site(n + ".attn2.to_out.0", [(n + ".attn2.to_out.0", a2.to_out[0])])
+                self._site(n + ".ff.net.0.proj", [(n + ".ff.net.0.proj", m.ff.net[0].proj)])
+                self._site(n + ".ff.net.2", [(n + ".ff.net.2", m.ff.net[2])])
+
+    # ---- LoRA ------------------------------------------------------------------------------------
+    def attach_lora(self, network) -> None:
+        """Bind a LoRANetwork: every LoRA module is matched to (site, group) by its leaf name."""
+        self.network = network
+        per_site: Dict[str, list] = {}
+        for lora in network.unet_loras:
+            if lora.leaf_name not in self.leaf_site:
+                raise KeyError(f"LoRA target {lora.leaf_name} has no GEMM site")
+            site, g = self.leaf_site[lora.leaf_name]
+            if site.conv3 or site.name == "time_emb_proj_all":
+                raise NotImplementedError(
+                    f"LoRA on {lora.leaf_name}: conv3x3 / time_emb_proj LoRA (c3lier) is not wired yet")
+            per_site.setdefault(site.name, [None] * len(site.leaf_names))[g] = lora
+        self.lora_sites: List[GemmSite] = []
+        for name, mods in per_site.items():
+            site = self.sites[name]
+            r = next(m for m in mods if m is not None).lora_dim
+            site.lora = LoraSiteState(site, mods, r, self.device)
+            self.lora_sites.append(site)
+        self.plans.clear()
+        self._build_pack_table()
+
+    def _build_pack_table(self):
+        net = self.network
+        sites = (hip.LoraSite * len(self.lora_sites))()
+        self._zero_dummy = {}
+        for i, site in enumerate(self.lora_sites):
+            st, d = site.lora, sites[i]
+            for g, mod in enumerate(st.mods):
+                if mod is None:  # group without a LoRA module: zero operands
+                    key = (st.r, site.k, site.group_n)
+                    if key not in self._zero_dummy:
+                        self._zero_dummy[key] = (torch.zeros(st.r, site.k, dtype=bf16, device=self.device),
+                                                 torch.zeros(site.group_n, st.r, dtype=bf16, device=self.device))
+                    dn, up = self._zero_dummy[key]
+                    d.down[g], d.up[g] = dn.data_ptr(), up.data_ptr()
+                else:
+                    d.down[g] = net.shadow.data_ptr() + mod.down_off * 2
+                    d.up[g] = net.shadow.data_ptr() + mod.up_off * 2
+            d.groups, d.r, d.k, d.n = len(st.mods), st.r, site.k, site.n
+            d.scale = 0.0  # filled by refresh_lora
+            d.dn_s, d.up_p, d.up_t, d.dn_p = st.dn_s.data_ptr(), st.up_p.data_ptr(), st.up_t.data_ptr(), st.dn_p.data_ptr()
+        self._pack_host = sites
+        self._pack_dev = torch.zeros(C.sizeof(sites), dtype=torch.uint8, device=self.device)
+        self._pack_scale = None
+
+    def refresh_lora(self, multiplier: float) -> None:
+        """Re-pack all LoRA operand images from the bf16 shadow (after an optimizer step)."""
+        net = self.network
+        if self._pack_scale != multiplier:
+            for i, site in enumerate(self.lora_sites):
+                mod = next(m for m in site.lora.mods if m is not None)
+                self._pack_host[i].scale = float(multiplier * mod.scale)
+            raw = torch.frombuffer(bytearray(bytes(self._pack_host)), dtype=torch.uint8)
+            self._pack_dev.copy_(raw)
+            self._pack_scale = multiplier
+        ops.lora_pack(self._pack_dev, len(self.lora_sites)).run()
+        net._packed_version = net.version
+
+    # ---- plan construction ---------------------------------------------------------------------
+    def plan(self, B: int, h: int, w: int) -> Plan:
+        key = (B, h, w)
+        if key not in self.plans:
+            self.plans[key] = PlanBuilder(self, B, h, w).build()
+        return self.plans[key]
+
+
+class PlanBuilder:
+    def __init__(self, eng: Engine, B: int, h: int, w: int):
+        self.eng, self.cfg, self.dev = eng, eng.cfg, eng.device
+        self.B, self.h, self.w = B, h, w
+        self.plan = Plan()
+        self.f_on: List[ops.Op] = self.plan.fwd[True]
+        self.f_off: List[ops.Op] = self.plan.fwd[False]
+        self.tape: List = []
+        self.nbuf = 0
+
+    # ---- helpers -----------------------------------------------------------------------------
+    def buf(self, name, shape, dtype=bf16, zero=False) -> torch.Tensor:
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+        key = name
+        while key in self.plan.bufs:
+            self.nbuf += 1
+            key = f"{name}#{self.nbuf}"
+        self.plan.bufs[key] = t
+        return t
+
+    def act(self, name, rows, cols, rg=False) -> TRef:
+        return TRef(self.buf(name, (rows, cols)), rows, cols, rg=rg, name=name)
+
+    def both(self, op: ops.Op):
+        self.f_on.append(op)
+        self.f_off.append(op)
+
+    def total_grad(self, t: TRef, out: List[ops.Op]) -> Optional[TRef]:
+        """Sum of the gradient contributions recorded for ``t`` (None if there are none)."""
+        parts = t.gparts
+        if not parts:
+            return None
+        if len(parts) == 1:
+            return parts[0]
+        acc = parts[0]
+        i = 1
+        while i < len(parts):
+            b = parts[i]
+            c = parts[i + 1] if i + 1 < len(parts) else None
+            dst = self.act("g_sum." + t.name, t.rows, t.cols)
+            out.append(ops.add(acc.ptr, acc.ld, b.ptr, b.ld, c.ptr if c else None, c.ld if c else 0, dst.ptr, dst.ld,
+                               t.rows, t.cols))
+            acc = dst
+            i += 2
+        return acc
+
+    # ---- GEMM site forward / backward -----------------------------------------------------------
+    def gemm_fwd(self, site: GemmSite, x: Union[TRef, Tuple[TRef, TRef]], name: str, *, conv=None, amode=A_PLAIN,
+                 rows: int, residual: Optional[TRef] = None, rowbias=None, rows_per_group=0, ld_rowbias=0,
+                 act=ACT_NONE, out: Optional[TRef] = None, out_f32: Optional[torch.Tensor] = None,
+                 bias="site") -> TRef:
+        xs = x if isinstance(x, tuple) else (x,)
+        rg_in = any(t.rg for t in xs) or (residual is not None and residual.rg)
+        lora = site.lora
+        y = out if out is not None else (self.act(name, rows, site.n) if out_f32 is None else None)
+        bias_t = site.bias if bias == "site" else bias
+        common = dict(m=rows, n=site.n, k=site.k, a_mode=amode, conv=conv, bias=bias_t, rowbias=rowbias,
+                      rows_per_group=rows_per_group, ld_rowbias=ld_rowbias,
+                      residual=residual.ptr if residual is not None else None,
+                      ldr=residual.ld if residual is not None else 0, act=act, out_f32=out_f32,
+                      ldc32=(out_f32.shape[-1] if out_f32 is not None else 0))
+        if len(xs) == 2:
+            common.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
+        a0, lda0 = xs[0].ptr, xs[0].ld
+        yptr = y.ptr if y is not None else None
+        ldc = y.ld if y is not None else site.n
+        g_off = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, **common)
+        self.f_off.append(ops.gemm(g_off, keep=(site, xs, residual, y)))
+        T = None
+        if lora is not None:
+            T = self.act(name + ".loraT", rows, lora.Rp)
+            kw = dict(m=rows, n=lora.Rp, k=site.k, a_mode=amode, conv=conv)
+            if len(xs) == 2:
+                kw.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
+            g_t = gemm_args(a0, lora.dn_s, T.ptr, lda=lda0, ldc=T.ld, **kw)
+            self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T)))
+            g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, a_ext=T.ptr, w_ext=lora.up_p, ext_k=lora.Rp,
+                             ld_aext=T.ld, ld_wext=lora.Rp, **common)
+            self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y)))
+        else:
+            self.f_on.append(ops.gemm(g_off))
+        if y is not None:
+            y.rg = rg_in or lora is not None
+            if y.rg:
+                self.tape.append(lambda: self.gemm_bwd(site, xs, y, T, conv, amode, rows, residual))
+        return y
+
+    def gemm_bwd(self, site: GemmSite, xs, y: TRef, T: Optional[TRef], conv, amode, rows, residual):
+        out = self.plan.bwd
+        dy = self.total_grad(y, out)
+        if dy is None:
+            return
+        if residual is not None and residual.rg:
+            residual.gparts.append(dy)
+        lora = site.lora
+        U = None
+        if lora is not None:
+            net = self.eng.network
+            U = self.act("g." + y.name + ".loraU", rows, lora.Rp)
+            out.append(ops.gemm(gemm_args(dy.ptr, lora.up_t, U.ptr, m=rows, n=lora.Rp, k=site.n, lda=dy.ld, ldc=U.ld),
+                                keep=(lora, dy, U)))
+            x0 = xs[0]
+            gn = site.group_n
+            for g, mod in enumerate(lora.mods):
+                if mod is None:
+                    continue
+                s = float(mod.scale)  # multiplier == 1 inside the training pass
+                r = lora.r
+                # d lora_down[j][k] = s * sum_m U[m][g r + j] x[m][k]
+                assert len(xs) == 1 and amode == A_PLAIN
+                out.append(ops.lora_wgrad(U.ptr + 2 * g * r, U.ld, x0.ptr, x0.ld, net.grad.data_ptr() + 4 * mod.down_off,
+                                          site.k, 1, rows, r, site.k, s))
+                # d lora_up[n][j] = s * sum_m dy[m][g gn + n] T[m][g r + j]
+                out.append(ops.lora_wgrad(T.ptr + 2 * g * r, T.ld, dy.ptr + 2 * g * gn, dy.ld,
+                                          net.grad.data_ptr() + 4 * mod.up_off, 1, r, rows, r, gn, s))
+        need = [t for t in xs if t.rg]
+        if not need:
+            return
+        kin = sum(t.cols for t in xs)
+        if amode == A_PLAIN:
+            dx = self.act("g." + y.name + ".dx", rows, kin)
+            g = gemm_args(dy.ptr, site.wt, dx.ptr, m=rows, n=kin, k=site.n, lda=dy.ld, ldc=dx.ld,
+                          a_ext=U.ptr if U is not None else None, w_ext=lora.dn_p if lora is not None else None,
+                          ext_k=lora.Rp if lora is not None else 0, ld_aext=U.ld if U is not None else 0,
+                          ld_wext=lora.Rp if lora is not None else 0)
+            out.append(ops.gemm(g, keep=(site, dy, dx, U)))
+        else:
+            B, ho, wo, hi, wi = conv
+            if amode == A_CONV3_S1:
+                dmode, dconv, drows = A_CONV3_S1, (B, hi, wi, ho, wo), B * hi * wi
+            elif amode == A_CONV3_S2:
+                dmode, dconv, drows = A_CONV3_TR2, (B, hi, wi, ho, wo), B * hi * wi
+            else:  # UP2: dgrad w.r.t. the upsampled image, then fold 2x2
+                dmode, dconv, drows = A_CONV3_S1, (B, ho, wo, ho, wo), B * ho * wo
+            dxa = self.act("g." + y.name + ".dx", drows, kin)
+            g = gemm_args(dy.ptr, site.wt, dxa.ptr, m=drows, n=kin, k=9 * site.n, lda=dy.ld, ldc=dxa.ld, a_mode=dmode,
+                          conv=dconv)
+            out.append(ops.gemm(g, keep=(site, dy, dxa)))
+            if amode == A_CONV3_UP2:
+                dx = self.act("g." + y.name + ".dxlo", B * hi * wi, kin)
+                out.append(ops.upsample2x_bwd(dxa.t, dx.t, B, hi, wi, kin))
+            else:
+                dx = dxa
+        c = 0
+        for t in xs:
+            if t.rg:
+                t.gparts.append(dx.cols_view(c, c + t.cols))
+            c += t.cols
+
+    # ---- norms ---------------------------------------------------------------------------------
+    def groupnorm(self, norm_name: str, x: Union[TRef, Tuple[TRef, TRef]], hw: int, act: int, eps: float, name: str) -> TRef:
+        xs = x if isinstance(x, tuple) else (x,)
+        gamma, beta = self.eng.norm_p[norm_name]
+        Cc = sum(t.cols for t in xs)
+        G = self.cfg.norm_num_groups
+        rows = xs[0].rows
+        y = self.act(name, rows, Cc, rg=any(t.rg for t in xs))
+        stats = self.buf(name + ".stats", (self.B, G, 2), torch.float32)
+        x1 = xs[1] if len(xs) == 2 else None
+        self.both(ops.Op("leco_groupnorm_fwd", (xs[0].ptr, xs[0].ld, x1.ptr if x1 else None, x1.ld if x1 else 0,
+                                                xs[0].cols if x1 else 0, gamma.data_ptr(), beta.data_ptr(), self.B, hw,
+                                                Cc, G, eps, act, stats.data_ptr(), y.ptr, y.ld), keep=(xs, y, stats)))
+        if y.rg:
+            def bwd():
+                out = self.plan.bwd
+                dy = self.total_grad(y, out)
+                if dy is None:
+                    return
+                dx = self.act("g." + name + ".dx", rows, Cc)
+                bst = self.buf("g." + name + ".bstats", (self.B, G, 2), torch.float32)
+                out.append(ops.Op("leco_groupnorm_bwd", (xs[0].ptr, xs[0].ld, x1.ptr if x1 else None,
+                                                         x1.ld if x1 else 0, xs[0].cols if x1 else 0, dy.ptr, dy.ld,
+                                                         gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), self.B,
+                                                         hw, Cc, G, eps, act, bst.data_ptr(), dx.ptr, dx.ld),
+                                  keep=(xs, dy, dx)))
+                c = 0
+                for t in xs:
+                    if t.rg:
+                        t.gparts.append(dx.cols_view(c, c + t.cols))
+                    c += t.cols
+            self.tape.append(bwd)
+        return y
+
+    def layernorm(self, norm_name: str, x: TRef, name: str) -> TRef:
+        gamma, beta = self.eng.norm_p[norm_name]
+        y = self.act(name, x.rows, x.cols, rg=x.rg)
+        mean = self.buf(name + ".mean", (x.rows,), torch.float32)
+        rstd = self.buf(name + ".rstd", (x.rows,), torch.float32)
+        self.both(ops.Op("leco_layernorm_fwd", (x.ptr, x.ld, gamma.data_ptr(), beta.data_ptr(), 1e-5, x.rows, x.cols,
+                                                y.ptr, y.ld, mean.data_ptr(), rstd.data_ptr()), keep=(x, y)))
+        if y.rg:
+            def bwd():
+                out = self.plan.bwd
+                dy = self.total_grad(y, out)
+                if dy is None:
+                    return
+                # fold the other gradient contributions of x (the residual branch) into this kernel
+                dres = self.total_grad(x, out)
+                dx = self.act("g." + name + ".dx", x.rows, x.cols)
+                out.append(ops.Op("leco_layernorm_bwd", (x.ptr, x.ld, dy.ptr, dy.ld, gamma.data_ptr(), mean.data_ptr(),
+                                                         rstd.data_ptr(), dres.ptr if dres else None,
+                                                         dres.ld if dres else 0, x.rows, x.cols, dx.ptr, dx.ld),
+                                  keep=(x, dy, dres, dx)))
+                x.gparts = [dx]
+            self.tape.append(bwd)
+        return y
+
+    # ---- attention -----------------------------------------------------------------------------
+    def attention(self, qsrc: TRef, kvsrc: TRef, heads: int, sq: int, skv: int, name: str) -> TRef:
+        """Self-attention: ``qsrc is kvsrc`` = the fused [rows][q|k|v] buffer.  Cross-attention:
+        ``qsrc`` = [rows][C] queries, ``kvsrc`` = [B*skv][k|v]."""
+        fused = qsrc is kvsrc
+        Cc = qsrc.cols // 3 if fused else qsrc.cols
+        d = Cc // heads
+        B = self.B
+        q = qsrc.cols_view(0, Cc)
+        k = kvsrc.cols_view(Cc, 2 * Cc) if fused else kvsrc.cols_view(0, Cc)
+        v = kvsrc.cols_view(2 * Cc, 3 * Cc) if fused else kvsrc.cols_view(Cc, 2 * Cc)
+        o = self.act(name, qsrc.rows, Cc, rg=qsrc.rg or kvsrc.rg)
+        lse = self.buf(name + ".lse", (B, heads, sq), torch.float32)
+        scale = d ** -0.5
+        self.both(ops.Op("leco_attention_fwd", (q.ptr, q.ld, sq * q.ld, k.ptr, k.ld, skv * k.ld, v.ptr, v.ld, skv * v.ld,
+                                                o.ptr, o.ld, sq * o.ld, lse.data_ptr(), B, heads, sq, skv, d, scale),
+                         keep=(qsrc, kvsrc, o)))
+        if o.rg:
+            def bwd():
+                out = self.plan.bwd
+                do = self.total_grad(o, out)
+                if do is None:
+                    return
+                delta = self.buf("g." + name + ".delta", (B, heads, sq), torch.float32)
+                if fused:
+                    dqkv = self.act("g." + name + ".dqkv", qsrc.rows, 3 * Cc)
+                    dq, dk, dv = dqkv.cols_view(0, Cc), dqkv.cols_view(Cc, 2 * Cc), dqkv.cols_view(2 * Cc, 3 * Cc)
+                    dqs, dkvs = dqkv, dqkv
+                else:
+                    dqs = self.act("g." + name + ".dq", qsrc.rows, Cc)
+                    dkvs = self.act("g." + name + ".dkv", kvsrc.rows, 2 * Cc)
+                    dq, dk, dv = dqs, dkvs.cols_view(0, Cc), dkvs.cols_view(Cc, 2 * Cc)
+                out.append(ops.Op("leco_attention_bwd", (
+                    q.ptr, q.ld, sq * q.ld, k.ptr, k.ld, skv * k.ld, v.ptr, v.ld, skv * v.ld, o.ptr, o.ld, sq * o.ld,
+                    do.ptr, do.ld, sq * do.ld, lse.data_ptr(), delta.data_ptr(), dq.ptr, dq.ld, sq * dq.ld,
+                    dk.ptr, dk.ld, skv * dk.ld, dv.ptr, dv.ld, skv * dv.ld, B, heads, sq, skv, d, scale),
+                    keep=(qsrc, kvsrc, o, do, dqs, dkvs)))
+                qsrc.gparts.append(dqs)
+                if not fused:
+                    kvsrc.gparts.append(dkvs)
+            self.tape.append(bwd)
+        return o
+
+    # ---- layers --------------------------------------------------------------------------------
+    def resnet(self, rname: str, x: Union[TRef, Tuple[TRef, TRef]], hs: int, ws: int) -> TRef:
+        eng, m = self.eng, self.eng.named[rname]
+        hw, rows = hs * ws, self.B * hs * ws
+        conv = (self.B, hs, ws, hs, ws)
+        n1 = self.groupnorm(rname + ".norm1", x, hw, ACT_SILU, self.cfg.norm_eps, rname + ".n1")
+        off = eng.temb_off[rname]
+        temb = self.temb_all  # fp32 [B][temb_total]
+        h1 = self.gemm_fwd(eng.sites[rname + ".conv1"], n1, rname + ".h1", conv=conv, amode=A_CONV3_S1, rows=rows,
+                           rowbias=temb.data_ptr() + 4 * off, rows_per_group=hw, ld_rowbias=eng.temb_total, bias=None)
+        n2 = self.groupnorm(rname + ".norm2", h1, hw, ACT_SILU, self.cfg.norm_eps, rname + ".n2")
+        if m.conv_shortcut is not None:
+            sc = self.gemm_fwd(eng.sites[rname + ".conv_shortcut"], x, rname + ".sc", rows=rows)
+        else:
+            assert not isinstance(x, tuple)
+            sc = x
+        return self.gemm_fwd(eng.sites[rname + ".conv2"], n2, rname + ".out", conv=conv, amode=A_CONV3_S1, rows=rows,
+                             residual=sc)
+
+    def basic_block(self, bname: str, hcur: TRef, ctx: TRef, heads: int, hw: int) -> TRef:
+        eng = self.eng
+        rows, Cc = hcur.rows, hcur.cols
+        S = eng.sites
+        l1 = self.layernorm(bname + ".norm1", hcur, bname + ".l1")
+        qkv = self.gemm_fwd(S[bname + ".attn1.qkv"], l1, bname + ".qkv", rows=rows)
+        a1 = self.attention(qkv, qkv, heads, hw, hw, bname + ".a1")
+        h1 = self.gemm_fwd(S[bname + ".attn1.to_out.0"], a1, bname + ".h1", rows=rows, residual=hcur)
+        l2 = self.layernorm(bname + ".norm2", h1, bname + ".l2")
+        q2 = self.gemm_fwd(S[bname + ".attn2.to_q"], l2, bname + ".q2", rows=rows)
+        kv = self.gemm_fwd(S[bname + ".attn2.kv"], ctx, bname + ".kv", rows=ctx.rows)
+        a2 = self.attention(q2, kv, heads, hw, ctx.rows // self.B, bname + ".a2")
+        h2 = self.gemm_fwd(S[bname + ".attn2.to_out.0"], a2, bname + ".h2", rows=rows, residual=h1)
+        l3 = self.layernorm(bname + ".norm3", h2, bname + ".l3")
+        u = self.gemm_fwd(S[bname + ".ff.net.0.proj"], l3, bname + ".u", rows=rows)
+        gg = self.act(bname + ".geglu", rows, 4 * Cc, rg=u.rg)
+        self.both(ops.Op("leco_geglu_fwd", (u.ptr, u.ld, gg.ptr, gg.ld, rows, 4 * Cc), keep=(u, gg)))
+        if gg.rg:
+            def bwd():
+                out = self.plan.bwd
+                dg = self.total_grad(gg, out)
+                if dg is None:
+                    return
+                du = self.act("g." + bname + ".du", rows, 8 * Cc)
+                out.append(ops.Op("leco_geglu_bwd", (u.ptr, u.ld, dg.ptr, dg.ld, du.ptr, du.ld, rows, 4 * Cc),
+                                  keep=(u, dg, du)))
+                u.gparts.append(du)
+            self.tape.append(bwd)
+        return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2)
+
+    def transformer(self, tname: str, x: TRef, ctx: TRef, level: int, hs: int, ws: int) -> TRef:
+        eng, m = self.eng, self.eng.named[tname]
+        hw, rows = hs * ws, self.B * hs * ws
+        n = self.groupnorm(tname + ".norm", x, hw, ACT_NONE, 1e-6, tname + ".n")
+        p = self.gemm_fwd(eng.sites[tname + ".proj_in"], n, tname + ".pin", rows=rows)
+        for i in range(len(m.transformer_blocks)):
+            p = self.basic_block(f"{tname}.transformer_blocks.{i}", p, ctx, self.cfg.heads(level), hw)
+        return self.gemm_fwd(eng.sites[tname + ".proj_out"], p, tname + ".out", rows=rows, residual=x)
+
+    # ---- whole network ---------------------------------------------------------------------------
+    def build(self) -> Plan:
+        eng, cfg, B, h, w, dev = self.eng, self.cfg, self.B, self.h, self.w, self.dev
+        P = self.plan
+        ch = cfg.block_out_channels
+        S = eng.sites
+        xl = cfg.addition_embed_type == "text_time"
+        # -- dynamic inputs
+        P.x_in = self.buf("x_in", (B, cfg.in_channels, h, w))
+        P.ctx = self.buf("ctx", (B, 77, cfg.cross_attention_dim))
+        P.t_table = self.buf("t_table", (1024,), torch.float32, zero=True)  # timesteps; entry t_idx is used
+        P.t_idx = self.buf("t_idx", (1,), torch.int32, zero=True)
+        P.pred = self.buf("pred", (B, cfg.out_channels, h, w), torch.float32)
+        P.dpred = self.buf("dpred", (B, cfg.out_channels, h, w), torch.float32, zero=True)
+        ctx = TRef(P.ctx, B * 77, cfg.cross_attention_dim, name="ctx")
+        # -- time embedding
+        tsin = self.act("t_sin", B, ch[0])
+        self.both(ops.timestep_embedding(P.t_table, P.t_idx, 0, B, ch[0], tsin.t))
+        e1 = self.gemm_fwd(S["time_embedding.linear_1"], tsin, "t_e1", rows=B, act=ACT_SILU)
+        if not xl:
+            emb_silu = self.gemm_fwd(S["time_embedding.linear_2"], e1, "t_emb_silu", rows=B, act=ACT_SILU)
+        else:
+            emb = self.gemm_fwd(S["time_embedding.linear_2"], e1, "t_emb", rows=B)
+            P.text_embeds = self.buf("text_embeds", (B, cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim))
+            P.time_ids = self.buf("time_ids", (B * 6,), torch.float32, zero=True)
+            asin = self.act("add_sin", B, 6 * cfg.addition_time_embed_dim)
+            self.both(ops.timestep_embedding(P.time_ids, None, 1, B * 6, cfg.addition_time_embed_dim, asin.t))
+            te = TRef(P.text_embeds, B, P.text_embeds.shape[1], name="text_embeds")
+            a1 = self.gemm_fwd(S["add_embedding.linear_1"], (te, asin), "add_e1", rows=B, act=ACT_SILU)
+            emb_silu = self.gemm_fwd(S["add_embedding.linear_2"], a1, "t_emb_silu", rows=B, residual=emb, act=ACT_SILU)
+        self.temb_all = self.buf("temb_all", (B, eng.temb_total), torch.float32)
+        self.gemm_fwd(S["time_emb_proj_all"], emb_silu, "temb_all_g", rows=B, out_f32=self.temb_all)
+        # -- conv_in
+        h0 = self.act("conv_in", B * h * w, ch[0])
+        self.both(ops.conv_in(P.x_in, eng.conv_in_w, eng.conv_in_b, h0.t, B, h, w, cfg.in_channels, ch[0]))
+        cur, hs, ws = h0, h, w
+        skips = [h0]
+        for i, blk in enumerate(eng.unet.down_blocks):
+            bn = f"down_blocks.{i}"
+            for j in range(len(blk.resnets)):
+                cur = self.resnet(f"{bn}.resnets.{j}", cur, hs, ws)
+                if blk.has_attn:
+                    cur = self.transformer(f"{bn}.attentions.{j}", cur, ctx, i, hs, ws)
+                skips.append(cur)
+            if blk.downsamplers is not None:
+                ho, wo = (hs + 1) // 2, (ws + 1) // 2
+                cur = self.gemm_fwd(S[f"{bn}.downsamplers.0.conv"], cur, f"{bn}.down", conv=(B, ho, wo, hs, ws),
+                                    amode=A_CONV3_S2, rows=B * ho * wo)
+                hs, ws = ho, wo
+                skips.append(cur)
+        lvl = len(ch) - 1
+        cur = self.resnet("mid_block.resnets.0", cur, hs, ws)
+        cur = self.transformer("mid_block.attentions.0", cur, ctx, lvl, hs, ws)
+        cur = self.resnet("mid_block.resnets.1", cur, hs, ws)
+        for i, blk in enumerate(eng.unet.up_blocks):
+            bn = f"up_blocks.{i}"
+            level = len(ch) - 1 - i
+            for j in range(len(blk.resnets)):
+                skip = skips.pop()
+                cur = self.resnet(f"{bn}.resnets.{j}", (cur, skip), hs, ws)
+                if blk.has_attn:
+                    cur = self.transformer(f"{bn}.attentions.{j}", cur, ctx, level, hs, ws)
+            if blk.upsamplers is not None:
+                cur = self.gemm_fwd(S[f"{bn}.upsamplers.0.conv"], cur, f"{bn}.up", conv=(B, 2 * hs, 2 * ws, hs, ws),
+                                    amode=A_CONV3_UP2, rows=B * 4 * hs * ws)
+                hs, ws = 2 * hs, 2 * ws
+        assert (hs, ws) == (h, w), "latent size must be divisible by the down-sampling factor"
+        nout = self.groupnorm("conv_norm_out", cur, h * w, ACT_SILU, cfg.norm_eps, "norm_out")
+        self.both(ops.conv_out(nout.t, eng.conv_out_w, eng.conv_out_b, P.pred, B, h, w, ch[0], cfg.out_channels))
+        P.final = nout
+        # -- backward: conv_out dgrad seeds the tape
+        if nout.rg:
+            dn = self.act("g.norm_out", B * h * w, ch[0])
+            P.bwd.append(ops.conv_out_bwd(P.dpred, eng.conv_out_w, dn.t, B, h, w, ch[0], cfg.out_channels))
+            nout.gparts.append(dn)
+            for fn in reversed(self.tape):
+                fn()
+        self.tape = []
+        return P
+
+
+# =============================================================================================
+# public module
+# =============================================================================================
+_GRAPH_API_DECLARED = False
+
+
+def _graph_api():
+    global _GRAPH_API_DECLARED
+    lib = hip.lib()
+    if not _GRAPH_API_DECLARED:
+        for nm, at in [("leco_graph_begin_capture", [C.c_void_p]),
+                       ("leco_graph_end_capture", [C.c_void_p, C.POINTER(C.c_void_p)]),
+                       ("leco_graph_launch", [C.c_void_p, C.c_void_p]), ("leco_graph_destroy", [C.c_void_p])]:
+            getattr(lib, nm).argtypes = at
+            getattr(lib, nm).restype = C.c_int
+        _GRAPH_API_DECLARED = True
+    return lib
+
+
+class _UNetFn(torch.autograd.Function):
+    """Ties a plan's forward/backward launch lists into torch autograd so that the reference's
+    ``loss.backward()`` (train_lora.py:279) works unchanged: the LoRA slab is the only input that
+    receives a gradient."""
+
+    @staticmethod
+    def forward(ctx, slab, unet, plan, dtype):
+        ctx.unet, ctx.plan = unet, plan
+        unet._run(plan, "fwd_on")
+        return plan.pred.to(dtype)
+
+    @staticmethod
+    def backward(ctx, gout):
+        unet, plan = ctx.unet, ctx.plan
+        net = unet._engine.network
+        plan.dpred.copy_(gout.reshape(plan.dpred.shape))
+        if net.grads_cleared():      # optimizer.zero_grad(set_to_none=True) semantics; else accumulate
+            net.grad.zero_()
+        unet._run(plan, "bwd")
+        net.attach_grads()           # per-parameter .grad views into the flat gradient slab
+        net.mark_updated()           # an optimizer step follows: re-pack before the next LoRA-on pass
+        return None, None, None, None
+
+
+class UNet2DConditionModel(nn.Module):
+    """Drop-in for the object ``model_util.load_models`` returns (model_util.py:104-129): callable as
+    ``unet(sample, timestep, encoder_hidden_states=..., [added_cond_kwargs=...]).sample``
+    (train_util.py:156-160, 239-244)."""
+
+    def __init__(self, cfg: Optional[UNetConfig] = None):
+        super().__init__()
+        cfg = cfg or UNetConfig()
+        self.cfg = cfg
+        ch = cfg.block_out_channels
+        temb = ch[0] * 4
+        self.conv_in = nn.Conv2d(cfg.in_channels, ch[0], 3, 1, 1)
+        self.time_embedding = TimestepEmbedding(ch[0], temb)
+        if cfg.addition_embed_type == "text_time":
+            self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, temb)
+        self.down_blocks = nn.ModuleList()
+        self.up_blocks = nn.ModuleList()
+        cout = ch[0]
+        for i, t in enumerate(cfg.down_block_types):
+            cin, cout = cout, ch[i]
+            attn = t.startswith("CrossAttn")
+            self.down_blocks.append((CrossAttnDownBlock2D if attn else DownBlock2D)(
+                cfg, i, cin, cout, temb, attn, i == len(ch) - 1))
+        self.mid_block = UNetMidBlock2DCrossAttn(cfg, ch[-1], temb)
+        rev = list(reversed(ch))
+        cout = rev[0]
+        for i, t in enumerate(cfg.up_block_types):
+            prev, cout = cout, rev[i]
+            attn = t.startswith("CrossAttn")
+            self.up_blocks.append((CrossAttnUpBlock2D if attn else UpBlock2D)(
+                cfg, len(ch) - 1 - i, prev, cout, rev[min(i + 1, len(ch) - 1)], temb, attn, i == len(ch) - 1))
+        self.conv_norm_out = nn.GroupNorm(cfg.norm_num_groups, ch[0], eps=cfg.norm_eps)
+        self.conv_out = nn.Conv2d(ch[0], cfg.out_channels, 3, 1, 1)
+        self._engine: Optional[Engine] = None
+        self.use_graphs = False
+
+    # ---- reference call sites that are no-ops here (train_lora.py:68) ------------------------------
+    def enable_xformers_memory_efficient_attention(self, *a, **k):
+        return None
+
+    @property
+    def dtype(self):
+        return self.conv_in.weight.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.weight.device
+
+    def engine(self) -> Engine:
+        if self._engine is None:
+            self._engine = Engine(self, self.device)
+        return self._engine
+
+    # ---- execution ----------------------------------------------------------------------------------
+    def _run(self, plan: Plan, which: str) -> None:
+        oplist = plan.lists[which]
+        if not (self.use_graphs and self.device.type == "cuda" and not hip.is_emulated()):
+            ops.run_plan(oplist)
+            return
+        lib = _graph_api()
+        g = plan.graphs.get(which)
+        cur = torch.cuda.current_stream()
+        if g is None:
+            side = getattr(self, "_capture_stream", None)
+            if side is None:
+                side = self._capture_stream = torch.cuda.Stream()
+            side.wait_stream(cur)
+            sp = side.cuda_stream
+            hip.check(lib.leco_graph_begin_capture(sp), "graph begin")
+            try:
+                ops.run_plan(oplist, sp)
+            finally:
+                gh = C.c_void_p()
+                hip.check(lib.leco_graph_end_capture(sp, C.byref(gh)), "graph end")
+            g = plan.graphs[which] = gh
+        hip.check(lib.leco_graph_launch(g, cur.cuda_stream), "graph launch")
+
+    def prepare(self, sample_shape, lora_on: bool) -> Plan:
+        B, _, h, w = sample_shape
+        eng = self.engine()
+        net = eng.network
+        if net is not None and lora_on and (net._packed_version != net.version or eng._pack_scale != net.multiplier):
+            net.sync_shadow()
+            eng.refresh_lora(net.multiplier)
+        return eng.plan(B, h, w)
+
+    def lora_active(self) -> bool:
+        net = self.engine().network
+        return net is not None and net.multiplier != 0
+
+    def forward(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None):
+        eng = self.engine()
+        lora_on = self.lora_active()
+        plan = self.prepare(sample.shape, lora_on)
+        plan.x_in.copy_(sample)
+        plan.ctx.copy_(encoder_hidden_states)
+        t = torch.as_tensor(timestep)
+        plan.t_table[:1].copy_(t.reshape(-1)[:1].to(torch.float32))
+        plan.t_idx.zero_()
+        if self.cfg.addition_embed_type == "text_time":
+            plan.text_embeds.copy_(added_cond_kwargs["text_embeds"])
+            plan.time_ids.copy_(added_cond_kwargs["time_ids"].reshape(-1).to(torch.float32))
+        net = eng.network
+        if lora_on and torch.is_grad_enabled() and net is not None and net.slab.requires_grad:
+            return UNetOutput(_UNetFn.apply(net.slab, self, plan, sample.dtype))
+        self._run(plan, "fwd_on" if lora_on else "fwd_off")
+        return UNetOutput(plan.pred.to(sample.dtype))
