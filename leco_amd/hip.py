@@ -75,6 +75,14 @@ def declare(name: str, argtypes, restype=C.c_int):
 def lib() -> C.CDLL:
     global _lib, _lib_path
     if _lib is None:
+        if os.environ.get("LECO_AUTOBUILD", "1") != "0":
+            # incremental (content-hashed) in-tree rebuild so a stale .so can never be loaded
+            try:
+                from . import build as _build
+                _build.build()
+            except Exception as e:  # no hipcc on this machine: fall through to the existence check
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(f"leco_amd: cannot build the HIP extension ({e!r}); there is no CPU fallback")
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
                 f"leco_amd: HIP extension {LIB_PATH} is missing. Build it with "

@@ -133,6 +133,9 @@ class LoRANetwork(nn.Module):
             lora.up_off = off
             off += lora.lora_up.weight.numel()
         self.numel = off
+        if self.unet_loras and self.unet_loras[0].lora_down.weight.device.type == "meta":
+            self.slab = None   # shape-only instance (built under torch.device("meta")): names / census only
+            return
         pad = (-off) % 64
         slab = torch.zeros(off + pad, dtype=torch.float32, device=device)
         for lora in self.unet_loras:

@@ -20,10 +20,8 @@ def _bind_emu():
 
 
 def _bind_hip():
-    from leco_amd import hip
-    if not os.path.exists(hip.LIB_PATH):
-        import __graft_entry__
-        __graft_entry__.build()
+    from leco_amd import build, hip
+    build.build()          # incremental, content-hashed: never test a stale .so
     hip._use_library(hip.LIB_PATH)
     hip._lib_path = hip.LIB_PATH
 

@@ -1,0 +1,135 @@
+"""Cross-checks against the reference's OWN files, imported read-only from /root/reference through
+the stub `diffusers` (build container only; skipped where /root/reference does not exist, e.g. the
+GPU box).  Covers what can be pinned exactly without diffusers."""
+import contextlib
+import importlib
+import io
+import os
+import sys
+
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.path.insert(0, os.path.join(ROOT, "oracle", "stub_diffusers"))
+    sys.path.insert(0, REF)
+    mods = {n: importlib.import_module(n) for n in ("lora", "prompt_util", "config_util", "train_util")}
+    yield mods
+    sys.path.remove(REF)
+
+
+def test_lora_network_names_shapes_and_save_format(ref, tmp_path):
+    from safetensors.torch import load_file
+    from leco_amd import model_util
+    from leco_amd.lora import LoRANetwork
+    from leco_amd.unet import UNet2DConditionModel
+    from oracle import unet_ref as R
+    with torch.device("meta"):
+        ru = R.UNet2DConditionModel(R.tiny_config())
+        m = UNet2DConditionModel(model_util.tiny_config())
+    torch.manual_seed(42)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rnet = ref["lora"].LoRANetwork(ru, rank=4, multiplier=1.0, alpha=1.0)
+    torch.manual_seed(42)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
+    rs, s = rnet.state_dict(), net.state_dict()
+    assert list(rs.keys()) == list(s.keys())
+    for k in rs:
+        assert rs[k].shape == s[k].shape, k
+        assert torch.equal(rs[k], s[k].float().cpu()), f"init stream differs at {k}"
+    assert len(rnet.prepare_optimizer_params()[0]["params"]) == len(net.prepare_optimizer_params()[0]["params"])
+    a, b = tmp_path / "ref.safetensors", tmp_path / "ours.safetensors"
+    rnet.save_weights(str(a), dtype=torch.bfloat16)
+    net.save_weights(str(b), dtype=torch.bfloat16)
+    fa, fb = load_file(str(a)), load_file(str(b))
+    assert list(fa.keys()) == list(fb.keys())
+    for k in fa:
+        assert fa[k].dtype == fb[k].dtype == torch.bfloat16 and torch.equal(fa[k], fb[k]), k
+
+
+@pytest.mark.parametrize("arch,n_mods,n_params,rank", [("sd15", 192, 1695744, 4), ("sdxl", 722, 42557440, 16)])
+def test_lora_census_full_size(ref, arch, n_mods, n_params, rank):
+    from leco_amd import model_util
+    from leco_amd.lora import LoRANetwork
+    from leco_amd.unet import UNet2DConditionModel
+    with torch.device("meta"):
+        m = UNet2DConditionModel(model_util.SYNTHETIC[arch]())
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = LoRANetwork(m, rank=rank)
+    assert len(net.unet_loras) == n_mods and net.numel == n_params
+
+
+def test_training_method_filter_quirk_is_reproduced(ref):
+    """lora.py:169-187 filters on the OUTER module name, so selfattn / xattn select nothing (SURVEY F-2)."""
+    from leco_amd import model_util
+    from leco_amd.lora import LoRANetwork
+    from leco_amd.unet import UNet2DConditionModel
+    from oracle import unet_ref as R
+    for method in ("full", "noxattn", "innoxattn", "selfattn", "xattn"):
+        with torch.device("meta"), contextlib.redirect_stdout(io.StringIO()):
+            want = len(ref["lora"].LoRANetwork(R.UNet2DConditionModel(R.tiny_config()), rank=4, train_method=method).unet_loras)
+            got = len(LoRANetwork(UNet2DConditionModel(model_util.tiny_config()), rank=4, train_method=method).unet_loras)
+        assert got == want, method
+
+
+def test_example_yaml_schemas_parse_identically(ref):
+    from leco_amd import config_util, prompt_util
+    ex = os.path.join(REF, "examples")
+    for name in ("prompts.yaml", "cat_ears_prompts.yaml", "unreal_prompts.yaml"):
+        a = ref["prompt_util"].load_prompts_from_yaml(os.path.join(ex, name))
+        b = prompt_util.load_prompts_from_yaml(os.path.join(ex, name))
+        assert [x.dict() for x in a] == [x.model_dump() for x in b]
+    for name in ("config.yaml", "cat_ears_config.yaml", "unreal_config.yaml"):
+        a = ref["config_util"].load_config_from_yaml(os.path.join(ex, name))
+        b = config_util.load_config_from_yaml(os.path.join(ex, name))
+        assert a.dict() == b.model_dump()
+
+
+def test_loss_and_step_primitives_equal_reference(ref):
+    from leco_amd import prompt_util, train_util
+    g = torch.Generator().manual_seed(0)
+    t, p, n, u = [torch.randn(2, 4, 8, 8, generator=g) for _ in range(4)]
+    for action in ("erase", "enhance"):
+        rs = ref["prompt_util"].PromptSettings(target="x", action=action, guidance_scale=1.7)
+        s = prompt_util.PromptSettings(target="x", action=action, guidance_scale=1.7)
+        a = ref["prompt_util"].PromptEmbedsPair(torch.nn.MSELoss(), None, None, None, None, rs)
+        b = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), None, None, None, None, s)
+        kw = dict(target_latents=t, positive_latents=p, neutral_latents=n, unconditional_latents=u)
+        assert torch.equal(a.loss(**kw), b.loss(**kw))
+    e1, e2 = torch.randn(1, 77, 8, generator=g), torch.randn(1, 77, 8, generator=g)
+    assert torch.equal(ref["train_util"].concat_embeddings(e1, e2, 3), train_util.concat_embeddings(e1, e2, 3))
+
+    class Toy:
+        def __call__(self, x, t, encoder_hidden_states=None):
+            class O:
+                sample = x * 0.5 + encoder_hidden_states.mean() + float(t) * 1e-3
+            return O
+
+    from leco_amd.scheduler import DDIMScheduler
+    from oracle.ddim_ref import DDIMSchedulerRef
+    sa, sb = DDIMSchedulerRef(), DDIMScheduler()
+    sa.set_timesteps(10)
+    sb.set_timesteps(10)
+    lat = torch.randn(2, 4, 8, 8, generator=g)
+    emb = torch.randn(4, 77, 8, generator=g)
+    with contextlib.redirect_stderr(io.StringIO()):
+        da = ref["train_util"].diffusion(Toy(), sa, lat, emb, start_timesteps=0, total_timesteps=4, guidance_scale=3)
+    db = train_util.diffusion(Toy(), sb, lat, emb, start_timesteps=0, total_timesteps=4, guidance_scale=3)
+    assert torch.allclose(da, db, rtol=1e-5, atol=1e-6)
+    torch.manual_seed(5)
+    ra = ref["train_util"].get_random_resolution_in_bucket(512)
+    torch.manual_seed(5)
+    assert ra == train_util.get_random_resolution_in_bucket(512)
+    torch.manual_seed(6)
+    la = ref["train_util"].get_initial_latents(sa, 2, 512, 512, 1)
+    torch.manual_seed(6)
+    assert torch.equal(la, train_util.get_initial_latents(sb, 2, 512, 512, 1))
+    assert torch.equal(ref["train_util"].get_add_time_ids(1024, 1024), train_util.get_add_time_ids(1024, 1024))
