@@ -52,22 +52,25 @@ __device__ __forceinline__ u32x4 gn_load(const GnSrc& s, int64_t row, int c) {
 }
 
 constexpr int GN_MAX_GROUPS = 32;
+constexpr int GN_MAX_PARTS = 64;   // pixel-range blocks per sample
+constexpr int GN_LDS_FLOATS = 2 * 2560 * 2;  // [rows_par][C][2] staging, rows_par * C <= 5120
 
-// MODE 0: forward stats of x.  MODE 1: backward stats (needs dy, fwd stats, gamma, beta).
+// Deterministic two-stage statistics (no atomics: results are bitwise reproducible run to run).
+// stage 1 (gn_stats): block (part, b) reduces its pixel range to part[b][part][g][2];
+// stage 2 (prologue of gn_apply): every apply block re-reduces the <= 64 partials of its sample.
+// MODE 0: forward stats {sum x, sum x^2}.  MODE 1: backward stats {sum dxhat, sum dxhat*xhat}.
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc src, const bf16_t* dy, int64_t lddy,
                                                         const float* fstats, const float* gamma,
                                                         const float* beta, int act, float eps, int hw,
-                                                        int C, int G, int pix_per_block, float* stats) {
-    __shared__ float bins[GN_MAX_GROUPS * 2];
+                                                        int C, int G, int pix_per_block, float* part) {
+    __shared__ float stage[GN_LDS_FLOATS];
     const int tid = (int)threadIdx.x;
-    const int b = (int)blockIdx.y;
+    const int b = (int)blockIdx.y, nparts = (int)gridDim.x;
     const int p0 = (int)blockIdx.x * pix_per_block;
     const int p1 = min(p0 + pix_per_block, hw);
     const int nvec = C / 8, cg = C / G;
     const int cols = nvec < 256 ? nvec : 256, rows_par = 256 / cols;
-    if (tid < 2 * GN_MAX_GROUPS) bins[tid] = 0.f;
-    __syncthreads();
     const float inv_n = 1.f / ((float)hw * (float)cg);
     if (tid < rows_par * cols) {
         const int r = tid / cols;
@@ -111,14 +114,29 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc src, const bf16_t* 
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                int g = (c + i) / cg;
-                atomicAdd(&bins[2 * g], s1[i]);
-                atomicAdd(&bins[2 * g + 1], s2[i]);
+                stage[((r * C) + c + i) * 2] = s1[i];
+                stage[((r * C) + c + i) * 2 + 1] = s2[i];
             }
         }
     }
     __syncthreads();
-    if (tid < 2 * G) atomicAdd(&stats[(int64_t)b * G * 2 + tid], bins[tid]);
+    if (tid < 2 * G) {   // fixed-order reduction of group g, component (tid & 1)
+        const int g = tid >> 1, comp = tid & 1;
+        float acc = 0.f;
+        for (int r = 0; r < rows_par; ++r)
+            for (int c = g * cg; c < (g + 1) * cg; ++c) acc += stage[((r * C) + c) * 2 + comp];
+        part[(((int64_t)b * nparts + blockIdx.x) * G + g) * 2 + comp] = acc;
+    }
+}
+
+// finishes the statistics: stats[b][g][2] = sum over parts (fixed order); one block per sample
+__global__ void gn_finish_kernel(const float* part, int nparts, int G, float* stats) {
+    const int b = (int)blockIdx.x, t = (int)threadIdx.x;
+    if (t < 2 * G) {
+        float acc = 0.f;
+        for (int p = 0; p < nparts; ++p) acc += part[((int64_t)b * nparts + p) * G * 2 + t];
+        stats[(int64_t)b * G * 2 + t] = acc;
+    }
 }
 
 // MODE 0: forward apply.  MODE 1: backward apply (dx).
@@ -260,15 +278,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, int64_t ld
 }
 
 int gn_check(int C, int G, int c0, const void* x1) {
-    if (G <= 0 || G > GN_MAX_GROUPS || C % G || C % 8) return fail(-EINVAL, "groupnorm: bad C=%d G=%d", C, G);
+    if (G <= 0 || G > GN_MAX_GROUPS || C % G || C % 8 || C > 5120) return fail(-EINVAL, "groupnorm: bad C=%d G=%d", C, G);
     if (x1 && (c0 % 8 || c0 <= 0 || c0 >= C)) return fail(-EINVAL, "groupnorm: bad concat split %d of %d", c0, C);
     return 0;
 }
-int pix_per_block(int batch, int hw) {
-    int nblk = 1024 / (batch > 0 ? batch : 1);
+int pix_per_block(int batch, int hw, int c) {
+    // <= GN_MAX_PARTS pixel ranges per sample; at least 16 pixels each
+    int nblk = 512 / (batch > 0 ? batch : 1);
     if (nblk < 1) nblk = 1;
+    if (nblk > GN_MAX_PARTS) nblk = GN_MAX_PARTS;
     int ppb = cdiv(hw, nblk);
-    return ppb < 8 ? 8 : ppb;
+    return ppb < 16 ? 16 : ppb;
 }
 }  // namespace
 }  // namespace leco
@@ -283,11 +303,13 @@ extern "C" int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, i
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
-    (void)hipMemsetAsync(stats, 0, sizeof(float) * 2 * batch * groups, s);
-    const int ppb = pix_per_block(batch, hw);
-    hipLaunchKernelGGL((gn_stats_kernel<0>), dim3(cdiv(hw, ppb), batch), dim3(256), 0, s, src,
+    const int ppb = pix_per_block(batch, hw, c);
+    const int nparts = cdiv(hw, ppb);
+    float* part = stats + (int64_t)batch * groups * 2;   // scratch tail of the stats buffer
+    hipLaunchKernelGGL((gn_stats_kernel<0>), dim3(nparts, batch), dim3(256), 0, s, src,
                        (const bf16_t*)nullptr, (int64_t)0, (const float*)nullptr, gamma, beta, act, eps, hw, c,
-                       groups, ppb, stats);
+                       groups, ppb, part);
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(batch), dim3(64), 0, s, (const float*)part, nparts, groups, stats);
     const int64_t total = (int64_t)batch * hw * (c / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(grid), dim3(256), 0, s, src, (const bf16_t*)nullptr,
@@ -305,10 +327,12 @@ extern "C" int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, i
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
-    (void)hipMemsetAsync(bstats, 0, sizeof(float) * 2 * batch * groups, s);
-    const int ppb = pix_per_block(batch, hw);
-    hipLaunchKernelGGL((gn_stats_kernel<1>), dim3(cdiv(hw, ppb), batch), dim3(256), 0, s, src,
-                       (const bf16_t*)dy, lddy, stats, gamma, beta, act, eps, hw, c, groups, ppb, bstats);
+    const int ppb = pix_per_block(batch, hw, c);
+    const int nparts = cdiv(hw, ppb);
+    float* part = bstats + (int64_t)batch * groups * 2;
+    hipLaunchKernelGGL((gn_stats_kernel<1>), dim3(nparts, batch), dim3(256), 0, s, src,
+                       (const bf16_t*)dy, lddy, stats, gamma, beta, act, eps, hw, c, groups, ppb, part);
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(batch), dim3(64), 0, s, (const float*)part, nparts, groups, bstats);
     const int64_t total = (int64_t)batch * hw * (c / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(grid), dim3(256), 0, s, src, (const bf16_t*)dy, lddy,

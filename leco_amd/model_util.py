@@ -51,6 +51,13 @@ def init_synthetic_(unet: torch.nn.Module, seed: int = 1234) -> torch.nn.Module:
     return unet
 
 
+class _PromptIds(list):
+    """Stand-in for the token-id tensor: the prompt strings themselves."""
+
+    def to(self, *a, **k):
+        return self
+
+
 class SyntheticTokenizer:
     model_max_length = 77
 
@@ -58,7 +65,7 @@ class SyntheticTokenizer:
         class _Out:
             pass
         o = _Out()
-        o.input_ids = list(prompts)
+        o.input_ids = _PromptIds(prompts)
         return o
 
 
