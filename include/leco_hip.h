@@ -109,6 +109,12 @@ int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, floa
 /* same as leco_gemm with an explicit tile choice: 0 heuristic, 1 = 128x128, 2 = 128x160,
  * 3 = 64x64 (tests / tuning). */
 int leco_gemm_tile(const leco_gemm_args* args, int tile, leco_stream_t stream);
+/* full form: additionally split_k (0 = heuristic, 1 = none, n = that many K slices) with a
+ * caller-owned fp32 workspace for the partial slabs (split_k * m * n * 4 bytes; a too small
+ * workspace only reduces the split).  Deep-K / small-M problems (the 8x8 and 16x16 UNet levels)
+ * need this to fill 256 CUs. */
+int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* workspace,
+                 int64_t workspace_bytes, leco_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Normalisation (diffusers GroupNorm(32) in ResnetBlock2D / Transformer2DModel / conv_norm_out,
@@ -170,7 +176,7 @@ int leco_add(const void* a, int64_t lda, const void* b, int64_t ldb, const void*
 /* dgrad of F.interpolate(scale=2, nearest) (Upsample2D): dx = 2x2 block sums of dy */
 int leco_upsample2x_bwd(const void* dy, void* dx, int32_t batch, int32_t h, int32_t w, int32_t c,
                         leco_stream_t stream);
-/* UNet conv_in: NCHW bf16 (batch,cin,h,w) -> channels-last bf16; w fp32 [cout][cin][3][3] */
+/* UNet conv_in: NCHW bf16 (batch,cin,h,w) -> channels-last bf16; w fp32 [cin][3][3][cout] */
 int leco_conv_in(const void* x, const float* w, const float* bias, void* y, int32_t batch, int32_t h,
                  int32_t wd, int32_t cin, int32_t cout, leco_stream_t stream);
 /* UNet conv_out: channels-last bf16 -> NCHW fp32 (batch,4,h,w); w bf16 [4][3][3][c]; and its dgrad */

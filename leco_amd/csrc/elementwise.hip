@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const bf16_t* dy, bf1
 }
 
 // ---- conv_in: 3x3 pad 1, Cin (<=8) -> Cout, NCHW bf16 in, channels-last bf16 out -------------------
-// weights fp32 [Cout][Cin][3][3] (PyTorch layout), bias fp32.
+// weights fp32 [Cin][3][3][Cout] (Cout contiguous: 8 adjacent outputs = two float4 loads), bias fp32.
 __global__ __launch_bounds__(256) void conv_in_kernel(const bf16_t* x, const float* w, const float* bias,
                                                        bf16_t* y, int B, int H, int W, int Cin, int Cout) {
     const int nv = Cout / 8;
@@ -130,19 +130,21 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const bf16_t* x, const flo
         const int co = (int)(e - pix * nv) * 8;
         const int px = (int)(pix % W), py = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
         float acc[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[i] = bias[co + i];
+        {
+            f32x4 b0 = *(const f32x4*)(bias + co), b1 = *(const f32x4*)(bias + co + 4);
+            acc[0] = b0[0]; acc[1] = b0[1]; acc[2] = b0[2]; acc[3] = b0[3];
+            acc[4] = b1[0]; acc[5] = b1[1]; acc[6] = b1[2]; acc[7] = b1[3];
+        }
         for (int c = 0; c < Cin; ++c)
-            for (int kh = 0; kh < 3; ++kh) {
-                const int iy = py + kh - 1;
-                if (iy < 0 || iy >= H) continue;
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ix = px + kw - 1;
-                    if (ix < 0 || ix >= W) continue;
-                    const float xv = bf2f(x[((int64_t)(b * Cin + c) * H + iy) * W + ix]);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) acc[i] += xv * w[((co + i) * Cin + c) * 9 + kh * 3 + kw];
-                }
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+                if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+                const float xv = bf2f(x[((int64_t)(b * Cin + c) * H + iy) * W + ix]);
+                const float* wr = w + (int64_t)(c * 9 + tap) * Cout + co;
+                f32x4 w0 = *(const f32x4*)wr, w1 = *(const f32x4*)(wr + 4);
+                acc[0] += xv * w0[0]; acc[1] += xv * w0[1]; acc[2] += xv * w0[2]; acc[3] += xv * w0[3];
+                acc[4] += xv * w1[0]; acc[5] += xv * w1[1]; acc[6] += xv * w1[2]; acc[7] += xv * w1[3];
             }
         *(u32x4*)(y + pix * Cout + co) = pack8(acc);
     }
@@ -350,34 +352,39 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const leco_lora_site* si
 }
 
 // ---- LoRA weight gradients: G[j][c] += scale * sum_m P[m][j] Q[m][c] -----------------------------------
-// block = 256 threads: thread owns column c of a 256-wide column tile; blockIdx.y walks 256-row slabs of M;
-// P slab staged in LDS (fp32).  r <= 16.
-constexpr int WG_ROWS = 256;
+// block = 256 threads; thread owns column c of a 256-wide column tile; blockIdx.y walks WG_ROWS-row slabs
+// of M (P slab staged in LDS as fp32); 8 independent Q loads in flight per thread.  r <= 16.
+constexpr int WG_ROWS = 128;
+template <int R>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_t ldp, const bf16_t* Q, int64_t ldq,
                                                           float* G, int64_t g_sj, int64_t g_sc, int M, int r,
                                                           int cols, float scale) {
-    __shared__ float sp[WG_ROWS * 16];
+    __shared__ float sp[WG_ROWS * R];
     const int tid = (int)threadIdx.x;
     const int c = (int)blockIdx.x * 256 + tid;
     const int m0 = (int)blockIdx.y * WG_ROWS;
     const int rows = min(WG_ROWS, M - m0);
-    for (int e = tid; e < rows * r; e += 256) {
-        const int mm = e / r, j = e - mm * r;
-        sp[mm * 16 + j] = bf2f(P[(int64_t)(m0 + mm) * ldp + j]);
+    for (int e = tid; e < WG_ROWS * R; e += 256) {
+        const int mm = e / R, j = e - mm * R;
+        sp[e] = (mm < rows && j < r) ? bf2f(P[(int64_t)(m0 + mm) * ldp + j]) : 0.f;
     }
     __syncthreads();
     if (c >= cols) return;
-    float acc[16];
+    float acc[R];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    for (int mm = 0; mm < rows; ++mm) {
-        const float q = bf2f(Q[(int64_t)(m0 + mm) * ldq + c]);
+    for (int j = 0; j < R; ++j) acc[j] = 0.f;
+    const bf16_t* qc = Q + (int64_t)m0 * ldq + c;
+    for (int mm = 0; mm < WG_ROWS; mm += 8) {   // rows beyond `rows` contribute 0 through sp
+        float q[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
-            if (j < r) acc[j] += sp[mm * 16 + j] * q;
+        for (int u = 0; u < 8; ++u) q[u] = (mm + u < rows) ? bf2f(qc[(int64_t)(mm + u) * ldq]) : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < R; ++j) acc[j] += sp[(mm + u) * R + j] * q[u];
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < R; ++j)
         if (j < r) atomicAdd(&G[j * g_sj + c * g_sc], acc[j] * scale);
 }
 }  // namespace
@@ -485,7 +492,15 @@ extern "C" int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_
                                int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
                                leco_stream_t stream) {
     if (r <= 0 || r > 16) return fail(-EINVAL, "lora_wgrad: rank %d unsupported (1..16)", r);
-    hipLaunchKernelGGL(lora_wgrad_kernel, dim3(cdiv(cols, 256), cdiv(m, WG_ROWS)), dim3(256), 0, LECO_STREAM,
-                       (const bf16_t*)p, ldp, (const bf16_t*)q, ldq, g, g_sj, g_sc, m, r, cols, scale);
+    const dim3 grid(cdiv(cols, 256), cdiv(m, WG_ROWS));
+    if (r <= 4)
+        hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, LECO_STREAM, (const bf16_t*)p, ldp,
+                           (const bf16_t*)q, ldq, g, g_sj, g_sc, m, r, cols, scale);
+    else if (r <= 8)
+        hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, LECO_STREAM, (const bf16_t*)p, ldp,
+                           (const bf16_t*)q, ldq, g, g_sj, g_sc, m, r, cols, scale);
+    else
+        hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, LECO_STREAM, (const bf16_t*)p, ldp,
+                           (const bf16_t*)q, ldq, g, g_sj, g_sc, m, r, cols, scale);
     return check_launch("leco_lora_wgrad");
 }

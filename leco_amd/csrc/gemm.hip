@@ -12,12 +12,17 @@
 //     it is accumulated in fp32 inside the same MFMA accumulator (lora.py:102-106).
 //   * epilogue: + bias[n] + rowbias[sample][n] (time embedding) + residual, SiLU, bf16 store.
 //
-// Tiling: 256 threads = 4 waves in a 2x2 grid over a BM x BN tile, BK = 64.  Global -> VGPR
-// prefetch of tile t+1 is issued before the MFMAs of tile t; LDS is single-buffered, XOR
-// swizzled on 16-byte chunks (chunk ^= row & 7) so that the ds_read_b128 fragment reads are
-// conflict-free.  Operands are fed "swapped" (W fragment as MFMA-A, activation fragment as
-// MFMA-B) so each lane ends up with 4 consecutive n of one output row -> 8-byte stores.
-// Workgroup ids are remapped so each XCD (private L2) owns a contiguous run of tiles.
+// Structure: 256 threads = 4 waves in a 2x2 grid over a BM x BN tile, BK = 64.  Operand tiles
+// go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write): each wave
+// instruction fills 8 tile rows (64 lanes x 16 B); the 16-byte-chunk XOR swizzle
+// (chunk ^= row & 7, which makes the ds_read_b128 fragment reads conflict-free) is applied on
+// the per-lane SOURCE address because the LDS destination of the DMA is lane-linear.  Rows
+// outside the problem / conv padding read a 16-byte zero page.  Two LDS buffers: the DMA of tile
+// t+1 is in flight while the MFMAs of tile t run; one barrier per K step.
+// Operands are fed "swapped" (W fragment as MFMA-A, activation fragment as MFMA-B) so each
+// lane ends up with 4 consecutive n of one output row -> 8-byte stores.  Workgroup ids are
+// remapped so each XCD (private L2) owns a contiguous run of tiles.  Deep-K / small-M problems
+// (the 8x8 and 16x16 levels) are split over K into fp32 partial slabs + a finishing kernel.
 #include <errno.h>
 #include <hip/hip_runtime.h>
 #include <leco_prims.h>
@@ -29,48 +34,62 @@ namespace {
 
 constexpr int BK = 64;
 
+__device__ const u32x4 g_zero_page[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * BK + ((chunk ^ (row & 7)) << 3);
 }
 
+struct GemmRt {      // launch-time extras (not part of the C ABI struct)
+    int tiles_n;
+    int split_k;     // >1: write raw fp32 partials to ws[split][M][N], epilogue done by splitk_finish
+    float* ws;
+};
+
 template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, int tiles_n) {
+__global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const GemmRt rt) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-    constexpr int NA = BM / 32, NW = BN / 32;
-    __shared__ __attribute__((aligned(16))) bf16_t smem[(BM + BN) * BK];
-    bf16_t* sA = smem;
-    bf16_t* sB = smem + BM * BK;
+    constexpr int GA = BM / 32, GW = BN / 32;  // 8-row groups staged per wave (A / W)
+    constexpr int TILE = (BM + BN) * BK;       // elements per LDS buffer
+    bf16_t* smem = (bf16_t*)dyn_lds();
 
     // XCD-aware bijective remap: hardware places workgroup b on XCD b % 8; give each XCD a
     // contiguous run of logical tiles (tile_n fastest) so A/W panels are re-used in its L2.
     const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tile_m = wg / tiles_n, tile_n = wg % tiles_n;
+    const int tile_m = wg / rt.tiles_n, tile_n = wg % rt.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_m = wave >> 1, wave_n = wave & 1;
-    const int ld_row = tid >> 3, ld_c = tid & 7;
+    const int st_row = lane >> 3;           // row inside an 8-row group this lane stages
+    const int st_pos = lane & 7;            // 16-byte slot it fills
 
     const bf16_t* a0 = (const bf16_t*)p.a0;
     const bf16_t* a1 = (const bf16_t*)p.a1;
     const bf16_t* wp = (const bf16_t*)p.w;
     const bf16_t* aext = (const bf16_t*)p.a_ext;
     const bf16_t* wext = (const bf16_t*)p.w_ext;
+    const bf16_t* zero = (const bf16_t*)g_zero_page;
     const int M = p.m, N = p.n;
     const int nk_main = p.k / BK;
-    const int nk = nk_main + ((aext != nullptr && p.ext_k > 0) ? 1 : 0);
+    const bool has_ext = aext != nullptr && p.ext_k > 0;
+    // K range of this split (the LoRA extension tile belongs to the last split)
+    const int split = (int)blockIdx.y;
+    const int kt_begin = (int)(((int64_t)nk_main * split) / rt.split_k);
+    const int kt_end = (int)(((int64_t)nk_main * (split + 1)) / rt.split_k);
+    const int nk = (kt_end - kt_begin) + ((has_ext && split == rt.split_k - 1) ? 1 : 0);
     const int k_split = a1 ? p.k_split : 0x7fffffff;
 
-    // conv: decompose this thread's NA output rows once
-    int pb[NA], py[NA], px[NA];
+    // conv: decompose this lane's GA staged output rows once
+    int pb[GA], py[GA], px[GA];
     const int cin = CONV ? p.k / 9 : 1;
     if (CONV) {
         const int hw = p.h_out * p.w_out;
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            int m = m0 + ld_row + 32 * i;
+        for (int i = 0; i < GA; ++i) {
+            int m = m0 + (wave + 4 * i) * 8 + st_row;
             int mm = m < M ? m : 0;
             pb[i] = mm / hw;
             int rem = mm - pb[i] * hw;
@@ -79,11 +98,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, int t
         }
     }
 
-    u32x4 ra[NA], rw[NW];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-
-    auto load_tile = [&](int kt) {
-        if (kt < nk_main) {
+    auto stage = [&](int it, int buf) {
+        bf16_t* sA = smem + buf * TILE;
+        bf16_t* sB = sA + BM * BK;
+        const int kt = kt_begin + it;
+        if (it < kt_end - kt_begin) {
             const int k0 = kt * BK;
             if (!CONV) {
                 const bf16_t* src;
@@ -92,21 +111,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, int t
                 if (k0 < k_split) { src = a0; ld = p.lda0; kk = k0; }
                 else { src = a1; ld = p.lda1; kk = k0 - k_split; }
 #pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    int m = m0 + ld_row + 32 * i;
-                    ra[i] = (m < M) ? *(const u32x4*)(src + (int64_t)m * ld + kk + ld_c * 8) : zero4;
+                for (int i = 0; i < GA; ++i) {
+                    const int r = (wave + 4 * i) * 8 + st_row, m = m0 + r;
+                    const int c = st_pos ^ (r & 7);
+                    const bf16_t* g = (m < M) ? src + (int64_t)m * ld + kk + c * 8 : zero;
+                    glds16(g, sA + (wave + 4 * i) * 8 * BK);
                 }
             } else {
-                const int tap = k0 / cin, c = k0 - tap * cin;
+                const int tap = k0 / cin, cch = k0 - tap * cin;
                 const int kh = tap / 3, kw = tap - kh * 3;
                 const bf16_t* src;
                 int64_t ld;
                 int cc;
-                if (c < k_split) { src = a0; ld = p.lda0; cc = c; }
-                else { src = a1; ld = p.lda1; cc = c - k_split; }
+                if (cch < k_split) { src = a0; ld = p.lda0; cc = cch; }
+                else { src = a1; ld = p.lda1; cc = cch - k_split; }
 #pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    int m = m0 + ld_row + 32 * i;
+                for (int i = 0; i < GA; ++i) {
+                    const int r = (wave + 4 * i) * 8 + st_row, m = m0 + r;
+                    const int c = st_pos ^ (r & 7);
                     int uy = py[i] + kh - 1, ux = px[i] + kw - 1;
                     bool ok = m < M;
                     int iy, ix;
@@ -124,35 +146,33 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, int t
                         iy = uy >> 1; ix = ux >> 1;
                         ok = ok && iy < p.h_in && ix < p.w_in;
                     }
-                    ra[i] = ok ? *(const u32x4*)(src + ((int64_t)(pb[i] * p.h_in + iy) * p.w_in + ix) * ld +
-                                                 cc + ld_c * 8)
-                               : zero4;
+                    const bf16_t* g = ok ? src + ((int64_t)(pb[i] * p.h_in + iy) * p.w_in + ix) * ld + cc + c * 8 : zero;
+                    glds16(g, sA + (wave + 4 * i) * 8 * BK);
                 }
             }
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                int n = n0 + ld_row + 32 * i;
-                rw[i] = (n < N) ? *(const u32x4*)(wp + (int64_t)n * p.ldw + k0 + ld_c * 8) : zero4;
+            for (int i = 0; i < GW; ++i) {
+                const int r = (wave + 4 * i) * 8 + st_row, n = n0 + r;
+                const int c = st_pos ^ (r & 7);
+                const bf16_t* g = (n < N) ? wp + (int64_t)n * p.ldw + k0 + c * 8 : zero;
+                glds16(g, sB + (wave + 4 * i) * 8 * BK);
             }
         } else {  // LoRA K-extension tile
-            const bool cok = ld_c * 8 < p.ext_k;
 #pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                int m = m0 + ld_row + 32 * i;
-                ra[i] = (cok && m < M) ? *(const u32x4*)(aext + (int64_t)m * p.ld_aext + ld_c * 8) : zero4;
+            for (int i = 0; i < GA; ++i) {
+                const int r = (wave + 4 * i) * 8 + st_row, m = m0 + r;
+                const int c = st_pos ^ (r & 7);
+                const bf16_t* g = (c * 8 < p.ext_k && m < M) ? aext + (int64_t)m * p.ld_aext + c * 8 : zero;
+                glds16(g, sA + (wave + 4 * i) * 8 * BK);
             }
 #pragma unroll
-            for (int i = 0; i < NW; ++i) {
-                int n = n0 + ld_row + 32 * i;
-                rw[i] = (cok && n < N) ? *(const u32x4*)(wext + (int64_t)n * p.ld_wext + ld_c * 8) : zero4;
+            for (int i = 0; i < GW; ++i) {
+                const int r = (wave + 4 * i) * 8 + st_row, n = n0 + r;
+                const int c = st_pos ^ (r & 7);
+                const bf16_t* g = (c * 8 < p.ext_k && n < N) ? wext + (int64_t)n * p.ld_wext + c * 8 : zero;
+                glds16(g, sB + (wave + 4 * i) * 8 * BK);
             }
         }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < NA; ++i) *(u32x4*)(sA + lds_off(ld_row + 32 * i, ld_c)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NW; ++i) *(u32x4*)(sB + lds_off(ld_row + 32 * i, ld_c)) = rw[i];
     };
 
     f32x4 acc[FM][FN];
@@ -161,15 +181,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, int t
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_tile(0);
-    store_tile();
+    if (nk > 0) stage(0, 0);
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) load_tile(kt + 1);
-        const int ksteps = (kt >= nk_main && p.ext_k <= 32) ? 1 : 2;
+    for (int it = 0; it < nk; ++it) {
+        if (it + 1 < nk) stage(it + 1, (it + 1) & 1);
+        const bf16_t* sA = smem + (it & 1) * TILE;
+        const bf16_t* sB = sA + BM * BK;
+        const bool ext_tile = it >= kt_end - kt_begin;
+        const int ksteps = (ext_tile && p.ext_k <= 32) ? 1 : 2;
         for (int ks = 0; ks < ksteps; ++ks) {
             bf16x8 af[FM], wf[FN];
 #pragma unroll
@@ -184,13 +205,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, int t
                 for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
         }
         __syncthreads();
-        if (more) {
-            store_tile();
-            __syncthreads();
-        }
     }
 
-    // epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + r], r = 0..3
+    // lane holds C[m = .. + fr][n = .. + 4*fg + r], r = 0..3
+    if (rt.split_k > 1) {
+        float* ws = rt.ws + (int64_t)split * M * N;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = m0 + wave_m * WM + i * 16 + fr;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int n = n0 + wave_n * WN + j * 16 + 4 * fg;
+                if (n < N) *(f32x4*)(ws + (int64_t)m * N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
     bf16_t* cp = (bf16_t*)p.c;
     const bf16_t* res = (const bf16_t*)p.residual;
 #pragma unroll
@@ -232,14 +263,72 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, int t
     }
 }
 
+// sums the split-K partial slabs and applies the epilogue (4 consecutive n per thread)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const leco_gemm_args p, const float* ws, int splits) {
+    const int M = p.m, N = p.n, nq = N / 4;
+    const int64_t total = (int64_t)M * nq;
+    bf16_t* cp = (bf16_t*)p.c;
+    const bf16_t* res = (const bf16_t*)p.residual;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int m = (int)(e / nq), n = (int)(e - (int64_t)m * nq) * 4;
+        f32x4 a = *(const f32x4*)(ws + (int64_t)m * N + n);
+        for (int s = 1; s < splits; ++s) {
+            f32x4 b = *(const f32x4*)(ws + ((int64_t)s * M + m) * N + n);
+            a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+        }
+        float v[4] = {a[0], a[1], a[2], a[3]};
+        if (p.bias) {
+            f32x4 b = *(const f32x4*)(p.bias + n);
+            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+        }
+        if (p.rowbias) {
+            f32x4 b = *(const f32x4*)(p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias + n);
+            v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+        }
+        if (res) {
+            u32x2 rr = *(const u32x2*)(res + (int64_t)m * p.ldr + n);
+            v[0] += bf2f((bf16_t)(rr[0] & 0xffffu)); v[1] += bf2f((bf16_t)(rr[0] >> 16));
+            v[2] += bf2f((bf16_t)(rr[1] & 0xffffu)); v[3] += bf2f((bf16_t)(rr[1] >> 16));
+        }
+        if (p.act == LECO_ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
+        }
+        if (cp) {
+            u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *(u32x2*)(cp + (int64_t)m * p.ldc + n) = o;
+        }
+        if (p.c_f32) {
+            f32x4 o = {v[0], v[1], v[2], v[3]};
+            *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n) = o;
+        }
+    }
+}
+
+template <int BM, int BN, bool CONV>
+void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
+    constexpr int lds_bytes = 2 * (BM + BN) * BK * (int)sizeof(bf16_t);
+    static bool attr_set = false;
+    if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV>), grid, dim3(256), lds_bytes, s, a, rt);
+}
+
 template <int BM, int BN>
-int launch(const leco_gemm_args& a, hipStream_t s) {
+int launch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s) {
     const int tm = cdiv(a.m, BM), tn = cdiv(a.n, BN);
-    dim3 grid((unsigned)(tm * tn)), block(256);
-    if (a.a_mode == LECO_A_PLAIN)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, false>), grid, block, 0, s, a, tn);
-    else
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, true>), grid, block, 0, s, a, tn);
+    GemmRt rt{tn, split_k, ws};
+    dim3 grid((unsigned)(tm * tn), (unsigned)split_k);
+    if (a.a_mode == LECO_A_PLAIN) launch_one<BM, BN, false>(a, rt, grid, s);
+    else launch_one<BM, BN, true>(a, rt, grid, s);
+    if (split_k > 1) {
+        const int64_t quads = (int64_t)a.m * a.n / 4;
+        const int g = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_finish_kernel, dim3(g), dim3(256), 0, s, a, (const float*)ws, split_k);
+    }
     return check_launch("leco_gemm");
 }
 
@@ -253,6 +342,8 @@ int validate(const leco_gemm_args& a) {
     if (a.a_ext && !a.w_ext) return fail(-EINVAL, "leco_gemm: a_ext without w_ext");
     if (a.rowbias && a.rows_per_group <= 0) return fail(-EINVAL, "leco_gemm: rowbias needs rows_per_group");
     if (a.a_mode < LECO_A_PLAIN || a.a_mode > LECO_A_CONV3_TR2) return fail(-EINVAL, "leco_gemm: bad a_mode %d", a.a_mode);
+    if ((a.lda0 | a.ldw | (a.a1 ? a.lda1 : 0) | (a.a_ext ? (a.ld_aext | a.ld_wext) : 0)) % 8)
+        return fail(-EINVAL, "leco_gemm: operand strides must be multiples of 8 elements (16-byte DMA)");
     if (a.a_mode != LECO_A_PLAIN) {
         if (a.k % 9 || (a.k / 9) % BK) return fail(-EINVAL, "leco_gemm: conv needs k = 9*Cin, Cin %% 64 == 0 (k=%d)", a.k);
         if ((int64_t)a.batch * a.h_out * a.w_out != a.m) return fail(-EINVAL, "leco_gemm: conv m != batch*h_out*w_out");
@@ -265,30 +356,56 @@ int validate(const leco_gemm_args& a) {
 }  // namespace
 }  // namespace leco
 
-// tile: 0 = heuristic, 1 = 128x128, 2 = 128x160, 3 = 64x64 (exposed for tests/tuning)
-extern "C" int leco_gemm_tile(const leco_gemm_args* args, int tile, leco_stream_t stream) {
+// tile: 0 = heuristic, 1 = 128x128, 2 = 128x160, 3 = 64x64.  split_k: 0 = heuristic (needs a
+// workspace), 1 = none, >1 = that many K slices.  workspace: fp32 scratch for split-K partials.
+extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* workspace,
+                            int64_t workspace_bytes, leco_stream_t stream) {
     using namespace leco;
     if (!args) return fail(-EINVAL, "leco_gemm: null args");
     int rc = validate(*args);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
+    const int m = args->m, n = args->n, nk = args->k / BK;
     if (tile == 0) {
-        const int m = args->m, n = args->n;
         if (n <= 64 || m <= 64) tile = 3;
         else {
             const int bn = (n % 128 == 0) ? 128 : ((n % 160 == 0) ? 160 : 128);
             const long blocks = (long)cdiv(m, 128) * cdiv(n, bn);
-            tile = blocks >= 192 ? (bn == 160 ? 2 : 1) : 3;
+            const bool can_split = workspace != nullptr && nk >= 16;
+            tile = (blocks >= 192 || (can_split && m >= 128)) ? (bn == 160 ? 2 : 1) : 3;
         }
     }
+    const int bm = tile == 3 ? 64 : 128, bn = tile == 3 ? 64 : (tile == 2 ? 160 : 128);
+    const long tiles = (long)cdiv(m, bm) * cdiv(n, bn);
+    if (split_k == 0) {
+        split_k = 1;
+        if (workspace && tiles < 160 && nk >= 16) {
+            split_k = (int)((320 + tiles - 1) / tiles);
+            if (split_k > nk / 8) split_k = nk / 8;
+            if (split_k > 16) split_k = 16;
+        }
+    }
+    if (split_k > 1) {
+        const int64_t need = (int64_t)split_k * m * n * 4;
+        if (!workspace || need > workspace_bytes) {
+            const int fit = workspace ? (int)(workspace_bytes / ((int64_t)m * n * 4)) : 1;
+            split_k = fit < 1 ? 1 : (fit < split_k ? fit : split_k);
+        }
+        if (split_k > nk) split_k = nk;
+    }
+    if (split_k < 1) split_k = 1;
     switch (tile) {
-        case 1: return launch<128, 128>(*args, s);
-        case 2: return launch<128, 160>(*args, s);
-        case 3: return launch<64, 64>(*args, s);
+        case 1: return launch<128, 128>(*args, split_k, (float*)workspace, s);
+        case 2: return launch<128, 160>(*args, split_k, (float*)workspace, s);
+        case 3: return launch<64, 64>(*args, split_k, (float*)workspace, s);
         default: return fail(-EINVAL, "leco_gemm: bad tile id %d", tile);
     }
 }
 
+extern "C" int leco_gemm_tile(const leco_gemm_args* args, int tile, leco_stream_t stream) {
+    return leco_gemm_ex(args, tile, 1, nullptr, 0, stream);
+}
+
 extern "C" int leco_gemm(const leco_gemm_args* args, leco_stream_t stream) {
-    return leco_gemm_tile(args, 0, stream);
+    return leco_gemm_ex(args, 0, 1, nullptr, 0, stream);
 }

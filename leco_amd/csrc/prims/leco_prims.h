@@ -35,6 +35,17 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
                                                    __builtin_bit_cast(hw_bf16x8, b), c, 0, 0, 0);
 }
 
+// Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): lane l of the wave writes
+// lds_wave_base + 16*l; the SOURCE address is per lane.  Completion is tracked by vmcnt
+// (__syncthreads() drains it).
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+// launch-time sized LDS (up to 160 KB per workgroup on gfx950)
+extern __shared__ __attribute__((aligned(16))) unsigned char leco_dyn_lds_[];
+__device__ __forceinline__ unsigned char* dyn_lds() { return leco_dyn_lds_; }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }

@@ -57,6 +57,7 @@ def _declare(lib: C.CDLL) -> None:
         "leco_last_error": ([], C.c_char_p),
         "leco_gemm": ([C.POINTER(GemmArgs), vp], C.c_int),
         "leco_gemm_tile": ([C.POINTER(GemmArgs), C.c_int, vp], C.c_int),
+        "leco_gemm_ex": ([C.POINTER(GemmArgs), C.c_int, C.c_int, vp, i64, vp], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -166,5 +167,6 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, 
     return g
 
 
-def gemm(args: GemmArgs, stream=None, tile: int = 0) -> None:
-    check(lib().leco_gemm_tile(C.byref(args), tile, stream), "leco_gemm")
+def gemm(args: GemmArgs, stream=None, tile: int = 0, split_k: int = 1, ws: Optional[torch.Tensor] = None) -> None:
+    check(lib().leco_gemm_ex(C.byref(args), tile, split_k, ptr(ws), 0 if ws is None else ws.numel() * ws.element_size(),
+                             stream), "leco_gemm")

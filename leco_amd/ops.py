@@ -26,6 +26,7 @@ _SIGS = {
     "leco_attention_bwd": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
                            _vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64,
                            _i32, _i32, _i32, _i32, _i32, _f32, _vp],
+    "leco_gemm_ex": [C.POINTER(GemmArgs), _i32, _i32, _vp, _i64, _vp],
     "leco_geglu_fwd": [_vp, _i64, _vp, _i64, _i32, _i32, _vp],
     "leco_geglu_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
     "leco_add": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp],
@@ -98,8 +99,12 @@ def run_plan(plan: Sequence[Op], stream=None) -> None:
 
 
 # ---------------------------------------------------------------------------------------------
-def gemm(args: GemmArgs, keep=None) -> Op:
-    return Op("leco_gemm", (C.byref(args),), keep=(args, keep))
+def gemm(args: GemmArgs, keep=None, ws: Optional[torch.Tensor] = None, tile: int = 0, split_k: int = 0) -> Op:
+    """``ws``: fp32 scratch for split-K partial slabs (without it the GEMM never splits)."""
+    if ws is None:
+        return Op("leco_gemm_ex", (C.byref(args), tile, 1, None, 0), keep=(args, keep))
+    return Op("leco_gemm_ex", (C.byref(args), tile, split_k, ws.data_ptr(), ws.numel() * ws.element_size()),
+              keep=(args, keep, ws))
 
 
 def groupnorm_fwd(x0, ld0, x1, ld1, c0, gamma, beta, batch, hw, c, groups, eps, act, stats, y, ldy) -> Op:

@@ -340,6 +340,8 @@ class Engine:
         self.plans: Dict[Tuple[int, int, int], Plan] = {}
         self.network = None  # LoRANetwork (set by attach_lora)
         self.use_graphs = False
+        # shared fp32 scratch for split-K partial slabs (all launches are stream-ordered)
+        self.workspace = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=device)
         self._pack()
 
     # ---- weight packing ------------------------------------------------------------------------
@@ -373,7 +375,7 @@ class Engine:
         if self.cfg.addition_embed_type == "text_time":
             self._site("add_embedding.linear_1", [("add_embedding.linear_1", u.add_embedding.linear_1)])
             self._site("add_embedding.linear_2", [("add_embedding.linear_2", u.add_embedding.linear_2)])
-        self.conv_in_w = self._f32(u.conv_in.weight)
+        self.conv_in_w = self._f32(u.conv_in.weight.detach().permute(1, 2, 3, 0))  # [Cin][3][3][Cout]
         self.conv_in_b = self._f32(u.conv_in.bias)
         self.conv_out_w = u.conv_out.weight.detach().permute(0, 2, 3, 1).contiguous().to(self.device, bf16)
         self.conv_out_b = self._f32(u.conv_out.bias)
@@ -539,7 +541,7 @@ class PlanBuilder:
         yptr = y.ptr if y is not None else None
         ldc = y.ld if y is not None else site.n
         g_off = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, **common)
-        self.f_off.append(ops.gemm(g_off, keep=(site, xs, residual, y)))
+        self.f_off.append(ops.gemm(g_off, keep=(site, xs, residual, y), ws=self.eng.workspace))
         T = None
         if lora is not None:
             T = self.act(name + ".loraT", rows, lora.Rp)
@@ -547,12 +549,12 @@ class PlanBuilder:
             if len(xs) == 2:
                 kw.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
             g_t = gemm_args(a0, lora.dn_s, T.ptr, lda=lda0, ldc=T.ld, **kw)
-            self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T)))
+            self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T), ws=self.eng.workspace))
             g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, a_ext=T.ptr, w_ext=lora.up_p, ext_k=lora.Rp,
                              ld_aext=T.ld, ld_wext=lora.Rp, **common)
-            self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y)))
+            self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y), ws=self.eng.workspace))
         else:
-            self.f_on.append(ops.gemm(g_off))
+            self.f_on.append(ops.gemm(g_off, ws=self.eng.workspace))
         if y is not None:
             y.rg = rg_in or lora is not None
             if y.rg:
@@ -597,7 +599,7 @@ class PlanBuilder:
                           a_ext=U.ptr if U is not None else None, w_ext=lora.dn_p if lora is not None else None,
                           ext_k=lora.Rp if lora is not None else 0, ld_aext=U.ld if U is not None else 0,
                           ld_wext=lora.Rp if lora is not None else 0)
-            out.append(ops.gemm(g, keep=(site, dy, dx, U)))
+            out.append(ops.gemm(g, keep=(site, dy, dx, U), ws=self.eng.workspace))
         else:
             B, ho, wo, hi, wi = conv
             if amode == A_CONV3_S1:
@@ -609,7 +611,7 @@ class PlanBuilder:
             dxa = self.act("g." + y.name + ".dx", drows, kin)
             g = gemm_args(dy.ptr, site.wt, dxa.ptr, m=drows, n=kin, k=9 * site.n, lda=dy.ld, ldc=dxa.ld, a_mode=dmode,
                           conv=dconv)
-            out.append(ops.gemm(g, keep=(site, dy, dxa)))
+            out.append(ops.gemm(g, keep=(site, dy, dxa), ws=self.eng.workspace))
             if amode == A_CONV3_UP2:
                 dx = self.act("g." + y.name + ".dxlo", B * hi * wi, kin)
                 out.append(ops.upsample2x_bwd(dxa.t, dx.t, B, hi, wi, kin))

@@ -50,6 +50,13 @@ static inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return out;
 }
 
+static inline void glds16(const void* gsrc, void* lds_wave_base) {
+    memcpy((unsigned char*)lds_wave_base + 16 * emu::lane(), gsrc, 16);
+}
+static inline unsigned char* dyn_lds() {
+    static thread_local __attribute__((aligned(16))) unsigned char buf[160 * 1024];
+    return buf;
+}
 static inline int lane_id() { return emu::lane(); }
 static inline float shfl_xor(float v, int mask) {
     const unsigned char* all = emu::wave_gather(&v, 4);

@@ -40,6 +40,22 @@ def test_gemm_plain_full_epilogue(dev, tile, M, N, K):
     assert rel_err(out, ref) < TOLBF
 
 
+@pytest.mark.parametrize("tile,split", [(1, 3), (3, 4), (2, 2), (0, 0)])
+def test_gemm_split_k_with_epilogue_and_lora_tile(dev, tile, split):
+    torch.manual_seed(11)
+    M, N, K = 200, 320, 1152
+    a = torch.randn(M, K).to(bf).to(dev); w = (torch.randn(N, K) / K ** 0.5).to(bf).to(dev)
+    ae = torch.randn(M, 64).to(bf).to(dev); we = (torch.randn(N, 64) * 0.1).to(bf).to(dev)
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(bf).to(dev)
+    out = torch.zeros(M, N, dtype=bf, device=dev); o32 = torch.zeros(M, N, device=dev)
+    ws = torch.empty(4 * M * N, device=dev)
+    g = hip.gemm_args(a, w, out, m=M, n=N, k=K, a_ext=ae, w_ext=we, ext_k=64, bias=bias, residual=res, out_f32=o32)
+    hip.gemm(g, ops.default_stream(), tile, split, ws)
+    _sync(dev)
+    ref = a.float() @ w.float().T + ae.float() @ we.float().T + bias + res.float()
+    assert rel_err(o32, ref) < TOL32 and rel_err(out, ref) < TOLBF
+
+
 def test_gemm_mfma_layout_asymmetric(dev):
     """A = I-like / asymmetric-B check (cdna_hip_programming.md: transposes must be caught)."""
     M = N = K = 64
@@ -232,7 +248,8 @@ def test_conv_in_out(dev):
     B, H, W, Ci, Co = 2, 6, 7, 4, 64
     x = torch.randn(B, Ci, H, W).to(bf).to(dev); w = (torch.randn(Co, Ci, 3, 3) * 0.2).to(dev); bias = torch.randn(Co).to(dev)
     y = torch.zeros(B, H, W, Co, dtype=bf, device=dev)
-    ops.conv_in(x, w, bias, y, B, H, W, Ci, Co).run()
+    wt_in = w.permute(1, 2, 3, 0).contiguous()
+    ops.conv_in(x, wt_in, bias, y, B, H, W, Ci, Co).run()
     _sync(dev)
     assert rel_err(y.cpu().permute(0, 3, 1, 2), F.conv2d(x.float().cpu(), w.cpu(), bias.cpu(), padding=1)) < TOLBF
     C = 128
