@@ -81,26 +81,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         for (int fd = 0; fd < NFD; ++fd) acc_o[u][fd] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    // K/V tiles are register-staged one tile ahead: the global loads of tile t+1 are issued before the
+    // MFMAs of tile t and written to LDS after the next barrier (latency hidden behind compute).
+    constexpr int NLD = (KT * NDC + 255) / 256;   // 16-byte chunks per thread per operand
+    u32x4 kreg[NLD], vreg[NLD];
+    auto fetch = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 256 * i;
+            const int key = e / NDC, ch = e - key * NDC;
+            const bool ok = e < KT * NDC && kv0 + key < p.skv;
+            kreg[i] = ok ? *(const u32x4*)(kb + (int64_t)(kv0 + key) * p.ldk + ch * 8) : zero4;
+            vreg[i] = ok ? *(const u32x4*)(vb + (int64_t)(kv0 + key) * p.ldv + ch * 8) : zero4;
+        }
+    };
+    // zero the K columns [D, DK) once (the staged chunks only cover [0, D))
+    for (int e = tid; e < KT * (DK / 8 - NDC); e += 256) {
+        const int key = e / (DK / 8 - NDC), ch = NDC + e % (DK / 8 - NDC);
+        *(u32x4*)(sK + key * KROW + ch * 8) = zero4;
+    }
+    fetch(0);
     for (int kv0 = 0; kv0 < p.skv; kv0 += KT) {
         __syncthreads();
-        // K tile: [key][DK] row-major (zero beyond D / beyond skv)
-        for (int e = tid; e < KT * (DK / 8); e += 256) {
-            const int key = e / (DK / 8), ch = e - key * (DK / 8);
-            u32x4 t = (kv0 + key < p.skv && ch < NDC)
-                          ? *(const u32x4*)(kb + (int64_t)(kv0 + key) * p.ldk + ch * 8) : zero4;
-            *(u32x4*)(sK + key * KROW + ch * 8) = t;
-        }
-        // V tile transposed: sV[d][key]
-        for (int e = tid; e < KT * NDC; e += 256) {
-            const int key = e / NDC, ch = e - key * NDC;
-            u32x4 t = (kv0 + key < p.skv) ? *(const u32x4*)(vb + (int64_t)(kv0 + key) * p.ldv + ch * 8) : zero4;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                sV[(ch * 8 + 2 * i) * VROW + key] = (bf16_t)(t[i] & 0xffffu);
-                sV[(ch * 8 + 2 * i + 1) * VROW + key] = (bf16_t)(t[i] >> 16);
+        for (int i = 0; i < NLD; ++i) {
+            const int e = tid + 256 * i;
+            if (e < KT * NDC) {
+                const int key = e / NDC, ch = e - key * NDC;
+                *(u32x4*)(sK + key * KROW + ch * 8) = kreg[i];
+                const u32x4 t = vreg[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    sV[(ch * 8 + 2 * j) * VROW + key] = (bf16_t)(t[j] & 0xffffu);
+                    sV[(ch * 8 + 2 * j + 1) * VROW + key] = (bf16_t)(t[j] >> 16);
+                }
             }
         }
         __syncthreads();
+        if (kv0 + KT < p.skv) fetch(kv0 + KT);
 
         // S^T = K Q^T : lane holds S[q = fr][key = kv0 + 16 f + 4 fg + r]
         f32x4 acc_s[QF][4];
