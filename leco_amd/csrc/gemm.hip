@@ -17,8 +17,10 @@
 // instruction fills 8 tile rows (64 lanes x 16 B); the 16-byte-chunk XOR swizzle
 // (chunk ^= row & 7, which makes the ds_read_b128 fragment reads conflict-free) is applied on
 // the per-lane SOURCE address because the LDS destination of the DMA is lane-linear.  Rows
-// outside the problem / conv padding read a 16-byte zero page.  Two LDS buffers: the DMA of tile
-// t+1 is in flight while the MFMAs of tile t run; one barrier per K step.
+// outside the problem / conv padding read a 16-byte zero page.  The tiles form a 4-deep LDS ring
+// (up to 144 KB of the 160 KB): three tile DMAs stay in flight across the barriers (counted
+// s_waitcnt vmcnt, raw s_barrier) because with ~1 workgroup per CU the global->LDS latency
+// (~1.5 us under load), not MFMA time, bounds a K step.
 // Operands are fed "swapped" (W fragment as MFMA-A, activation fragment as MFMA-B) so each
 // lane ends up with 4 consecutive n of one output row -> 8-byte stores.  Workgroup ids are
 // remapped so each XCD (private L2) owns a contiguous run of tiles.  Deep-K / small-M problems
@@ -46,10 +48,11 @@ struct GemmRt {      // launch-time extras (not part of the C ABI struct)
     float* ws;
 };
 
-template <int BM, int BN, bool CONV>
+template <int BM, int BN, bool CONV, int NS>   // NS == 4 (the counted waits below assume it)
 __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const GemmRt rt) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int GA = BM / 32, GW = BN / 32;  // 8-row groups staged per wave (A / W)
+    constexpr int PER = GA + GW;               // DMA instructions per wave per tile
     constexpr int TILE = (BM + BN) * BK;       // elements per LDS buffer
     bf16_t* smem = (bf16_t*)dyn_lds();
 
@@ -181,13 +184,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if (nk > 0) stage(0, 0);
-    __syncthreads();
+    // NS-deep DMA ring.  At the top of iteration `it` the DMAs of tiles it .. it+NS-2 are in flight.
+    // A wave waits (counted vmcnt) until ITS pieces of tile `it` have landed; the single barrier of the
+    // iteration then (a) covers the other waves' pieces and (b) proves every wave is done reading the
+    // buffer of tile it-1, which is exactly the one the next DMA (tile it+NS-1) overwrites.  The barrier
+    // does not drain the younger DMAs.
+#pragma unroll
+    for (int s0 = 0; s0 < NS - 1; ++s0)
+        if (s0 < nk) stage(s0, s0);
 
     const int fr = lane & 15, fg = lane >> 4;
     for (int it = 0; it < nk; ++it) {
-        if (it + 1 < nk) stage(it + 1, (it + 1) & 1);
-        const bf16_t* sA = smem + (it & 1) * TILE;
+        const int inflight = nk - it < NS - 1 ? nk - it : NS - 1;   // tiles it .. it+inflight-1
+        if (inflight >= 3) wait_vmcnt<2 * PER>();
+        else if (inflight == 2) wait_vmcnt<PER>();
+        else wait_vmcnt<0>();
+        barrier_keep_dma();
+        if (it + NS - 1 < nk) stage(it + NS - 1, (it + NS - 1) % NS);
+        const bf16_t* sA = smem + (it % NS) * TILE;
         const bf16_t* sB = sA + BM * BK;
         const bool ext_tile = it >= kt_end - kt_begin;
         const int ksteps = (ext_tile && p.ext_k <= 32) ? 1 : 2;
@@ -204,7 +218,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
 #pragma unroll
                 for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
         }
-        __syncthreads();
     }
 
     // lane holds C[m = .. + fr][n = .. + 4*fg + r], r = 0..3
@@ -307,14 +320,15 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const leco_gemm_args
 
 template <int BM, int BN, bool CONV>
 void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
-    constexpr int lds_bytes = 2 * (BM + BN) * BK * (int)sizeof(bf16_t);
+    constexpr int NS = 4;  // DMA ring depth: 4 x 36 KB (128x160) = 144 KB of the 160 KB LDS
+    constexpr int lds_bytes = NS * (BM + BN) * BK * (int)sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, NS>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV>), grid, dim3(256), lds_bytes, s, a, rt);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, NS>), grid, dim3(256), lds_bytes, s, a, rt);
 }
 
 template <int BM, int BN>

@@ -42,6 +42,17 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// Counted wait on this wave's outstanding global/LDS-DMA operations (s_waitcnt vmcnt(N)): the N most
+// recently issued may still be in flight.  Lets several tile DMAs span a barrier.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// workgroup barrier that orders LDS accesses but does NOT drain in-flight LDS-DMA (unlike __syncthreads())
+__device__ __forceinline__ void barrier_keep_dma() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 // launch-time sized LDS (up to 160 KB per workgroup on gfx950)
 extern __shared__ __attribute__((aligned(16))) unsigned char leco_dyn_lds_[];
 __device__ __forceinline__ unsigned char* dyn_lds() { return leco_dyn_lds_; }

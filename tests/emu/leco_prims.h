@@ -53,6 +53,9 @@ static inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 static inline void glds16(const void* gsrc, void* lds_wave_base) {
     memcpy((unsigned char*)lds_wave_base + 16 * emu::lane(), gsrc, 16);
 }
+template <int N>
+static inline void wait_vmcnt() {}          // the emulated DMA completes immediately
+static inline void barrier_keep_dma() { emu::sync_block(); }
 static inline unsigned char* dyn_lds() {
     static thread_local __attribute__((aligned(16))) unsigned char buf[160 * 1024];
     return buf;
