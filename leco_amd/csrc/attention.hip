@@ -83,6 +83,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 
     // K/V tiles are register-staged one tile ahead: the global loads of tile t+1 are issued before the
     // MFMAs of tile t and written to LDS after the next barrier (latency hidden behind compute).
+    // K chunks: thread e -> (key = e / NDC, ch = e % NDC) (coalesced rows, 16-byte LDS stores).
+    // V chunks: thread e -> (ch = e / KT, key = e % KT): a wave's 64 lanes hold 64 consecutive keys of one
+    // channel chunk, so each of the 8 transposing 2-byte LDS stores writes 128 contiguous bytes of one
+    // V^T row (conflict-free); the price is a strided (L2-served) global read.
     constexpr int NLD = (KT * NDC + 255) / 256;   // 16-byte chunks per thread per operand
     u32x4 kreg[NLD], vreg[NLD];
     auto fetch = [&](int kv0) {
@@ -92,7 +96,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             const int key = e / NDC, ch = e - key * NDC;
             const bool ok = e < KT * NDC && kv0 + key < p.skv;
             kreg[i] = ok ? *(const u32x4*)(kb + (int64_t)(kv0 + key) * p.ldk + ch * 8) : zero4;
-            vreg[i] = ok ? *(const u32x4*)(vb + (int64_t)(kv0 + key) * p.ldv + ch * 8) : zero4;
+            const int vch = e / KT, vkey = e - vch * KT;
+            const bool vok = e < KT * NDC && kv0 + vkey < p.skv;
+            vreg[i] = vok ? *(const u32x4*)(vb + (int64_t)(kv0 + vkey) * p.ldv + vch * 8) : zero4;
         }
     };
     // zero the K columns [D, DK) once (the staged chunks only cover [0, D))
@@ -109,11 +115,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             if (e < KT * NDC) {
                 const int key = e / NDC, ch = e - key * NDC;
                 *(u32x4*)(sK + key * KROW + ch * 8) = kreg[i];
+                const int vch = e / KT, vkey = e - vch * KT;
                 const u32x4 t = vreg[i];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    sV[(ch * 8 + 2 * j) * VROW + key] = (bf16_t)(t[j] & 0xffffu);
-                    sV[(ch * 8 + 2 * j + 1) * VROW + key] = (bf16_t)(t[j] >> 16);
+                    sV[(vch * 8 + 2 * j) * VROW + vkey] = (bf16_t)(t[j] & 0xffffu);
+                    sV[(vch * 8 + 2 * j + 1) * VROW + vkey] = (bf16_t)(t[j] >> 16);
                 }
             }
         }

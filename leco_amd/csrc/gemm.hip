@@ -48,7 +48,7 @@ struct GemmRt {      // launch-time extras (not part of the C ABI struct)
     float* ws;
 };
 
-template <int BM, int BN, bool CONV, int NS>   // NS == 4 (the counted waits below assume it)
+template <int BM, int BN, bool CONV, int NS>   // NS in {2, 4}
 __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const GemmRt rt) {
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int GA = BM / 32, GW = BN / 32;  // 8-row groups staged per wave (A / W)
@@ -121,7 +121,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
                     glds16(g, sA + (wave + 4 * i) * 8 * BK);
                 }
             } else {
-                const int tap = k0 / cin, cch = k0 - tap * cin;
+                // K order of a conv is channel-chunk major / tap minor: the 9 taps of one 64-channel chunk
+                // re-read (shifted) the same input pixels back to back, so they hit in L1/L2 instead of
+                // sweeping the whole input patch once per tap.
+                const int chunk = kt / 9, tap = kt - chunk * 9;
+                const int cch = chunk * BK;
                 const int kh = tap / 3, kw = tap - kh * 3;
                 const bf16_t* src;
                 int64_t ld;
@@ -153,11 +157,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
                     glds16(g, sA + (wave + 4 * i) * 8 * BK);
                 }
             }
+            int wcol = k0;
+            if (CONV) { const int chunk = kt / 9, tap = kt - chunk * 9; wcol = tap * cin + chunk * BK; }
 #pragma unroll
             for (int i = 0; i < GW; ++i) {
                 const int r = (wave + 4 * i) * 8 + st_row, n = n0 + r;
                 const int c = st_pos ^ (r & 7);
-                const bf16_t* g = (n < N) ? wp + (int64_t)n * p.ldw + k0 + c * 8 : zero;
+                const bf16_t* g = (n < N) ? wp + (int64_t)n * p.ldw + wcol + c * 8 : zero;
                 glds16(g, sB + (wave + 4 * i) * 8 * BK);
             }
         } else {  // LoRA K-extension tile
@@ -196,8 +202,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
     const int fr = lane & 15, fg = lane >> 4;
     for (int it = 0; it < nk; ++it) {
         const int inflight = nk - it < NS - 1 ? nk - it : NS - 1;   // tiles it .. it+inflight-1
-        if (inflight >= 3) wait_vmcnt<2 * PER>();
-        else if (inflight == 2) wait_vmcnt<PER>();
+        if (NS >= 4 && inflight >= 3) wait_vmcnt<2 * PER>();
+        else if (NS >= 3 && inflight == 2) wait_vmcnt<PER>();
         else wait_vmcnt<0>();
         barrier_keep_dma();
         if (it + NS - 1 < nk) stage(it + NS - 1, (it + NS - 1) % NS);
@@ -318,9 +324,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const leco_gemm_args
     }
 }
 
-template <int BM, int BN, bool CONV>
-void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
-    constexpr int NS = 4;  // DMA ring depth: 4 x 36 KB (128x160) = 144 KB of the 160 KB LDS
+template <int BM, int BN, bool CONV, int NS>
+void launch_ns(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
     constexpr int lds_bytes = NS * (BM + BN) * BK * (int)sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
@@ -329,6 +334,16 @@ void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_
         attr_set = true;
     }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, NS>), grid, dim3(256), lds_bytes, s, a, rt);
+}
+
+// DMA ring depth: with <= ~1 workgroup per CU nothing else hides the global->LDS latency, so use the
+// 4-deep ring (4 x 36 KB for 128x160); with several workgroups per CU keep 2 buffers (<= 72 KB) so
+// two workgroups stay resident and overlap each other.
+template <int BM, int BN, bool CONV>
+void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
+    const long blocks = (long)grid.x * grid.y;
+    if (BM == 64 || blocks <= 384) launch_ns<BM, BN, CONV, 4>(a, rt, grid, s);
+    else launch_ns<BM, BN, CONV, 2>(a, rt, grid, s);
 }
 
 template <int BM, int BN>

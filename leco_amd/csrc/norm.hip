@@ -129,14 +129,22 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc src, const bf16_t* 
     }
 }
 
-// finishes the statistics: stats[b][g][2] = sum over parts (fixed order); one block per sample
-__global__ void gn_finish_kernel(const float* part, int nparts, int G, float* stats) {
+// finishes the statistics: stats[b][g][2] = sum over parts (fixed order); one block per sample.
+// thread (q = t / 64, v = t % 64) sums parts q, q+4, q+8, ... of value v with independent loads in
+// flight, then the four quarter sums are combined in a fixed order.
+__global__ __launch_bounds__(256) void gn_finish_kernel(const float* part, int nparts, int G, float* stats) {
+    __shared__ float quarter[4 * 64];
     const int b = (int)blockIdx.x, t = (int)threadIdx.x;
-    if (t < 2 * G) {
-        float acc = 0.f;
-        for (int p = 0; p < nparts; ++p) acc += part[((int64_t)b * nparts + p) * G * 2 + t];
-        stats[(int64_t)b * G * 2 + t] = acc;
+    const int q = t >> 6, v = t & 63;
+    float acc = 0.f;
+    if (v < 2 * G) {
+        const float* src = part + (int64_t)b * nparts * G * 2 + v;
+#pragma unroll 4
+        for (int p = q; p < nparts; p += 4) acc += src[(int64_t)p * G * 2];
     }
+    quarter[t] = acc;
+    __syncthreads();
+    if (t < 2 * G) stats[(int64_t)b * G * 2 + t] = (quarter[t] + quarter[64 + t]) + (quarter[128 + t] + quarter[192 + t]);
 }
 
 // MODE 0: forward apply.  MODE 1: backward apply (dx).
@@ -148,33 +156,53 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc src, const bf16_t* 
                                                         bf16_t* out, int64_t ldo) {
     const int nvec = C / 8, cg = C / G;
     const float inv_n = 1.f / ((float)hw * (float)cg);
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total_vec; e += (int64_t)gridDim.x * 256) {
-        const int64_t row = e / nvec;
-        const int c = (int)(e - row * nvec) * 8;
-        const int b = (int)(row / hw);
-        float x[8], o[8], d[8];
+    const int total = (int)total_vec;
+    for (int e = (int)(blockIdx.x * 256 + threadIdx.x); e < total; e += (int)(gridDim.x * 256)) {
+        const int row = e / nvec;
+        const int c = (e - row * nvec) * 8;
+        const int b = row / hw;
+        float x[8], o[8], d[8], ga[8], be[8];
         unpack8(gn_load(src, row, c), x);
-        if (MODE == 1) unpack8(*(const u32x4*)(dy + row * lddy + c), d);
+        if (MODE == 1) unpack8(*(const u32x4*)(dy + (int64_t)row * lddy + c), d);
+        {
+            f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+            f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = (c + i) / cg;
+            for (int i = 0; i < 4; ++i) { ga[i] = g0[i]; ga[4 + i] = g1[i]; be[i] = b0[i]; be[4 + i] = b1[i]; }
+        }
+        // the 8 channels c..c+7 lie in groups gA = c/cg .. gB = (c+7)/cg; cache the statistics of up to 4 groups
+        const int gA = c / cg;
+        float mu[4], rs[4], s1[4], s2[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = min(gA + k, G - 1);
             const float m = fstats[(b * G + g) * 2] * inv_n;
             const float var = fstats[(b * G + g) * 2 + 1] * inv_n - m * m;
-            const float rs = rsqrtf(fmaxf(var, 0.f) + eps);
-            const float xh = (x[i] - m) * rs;
-            const float ga = gamma[c + i], be = beta[c + i];
+            mu[k] = m;
+            rs[k] = rsqrtf(fmaxf(var, 0.f) + eps);
+            if (MODE == 1) {
+                s1[k] = bstats[(b * G + g) * 2] * inv_n;
+                s2[k] = bstats[(b * G + g) * 2 + 1] * inv_n;
+            }
+        }
+        int nextb = (gA + 1) * cg - c;   // first channel offset that belongs to the next group
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (i >= nextb) { ++k; nextb += cg; }
+            const int kk = k < 3 ? k : 3;
+            const float xh = (x[i] - mu[kk]) * rs[kk];
             if (MODE == 0) {
-                float z = xh * ga + be;
+                float z = xh * ga[i] + be[i];
                 o[i] = act ? silu(z) : z;
             } else {
                 float dz = d[i];
-                if (act) dz *= dsilu(xh * ga + be);
-                const float dxh = dz * ga;
-                const float s1 = bstats[(b * G + g) * 2] * inv_n, s2 = bstats[(b * G + g) * 2 + 1] * inv_n;
-                o[i] = rs * (dxh - s1 - xh * s2);
+                if (act) dz *= dsilu(xh * ga[i] + be[i]);
+                const float dxh = dz * ga[i];
+                o[i] = rs[kk] * (dxh - s1[kk] - xh * s2[kk]);
             }
         }
-        *(u32x4*)(out + row * ldo + c) = pack8(o);
+        *(u32x4*)(out + (int64_t)row * ldo + c) = pack8(o);
     }
 }
 
@@ -278,7 +306,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* x, int64_t ld
 }
 
 int gn_check(int C, int G, int c0, const void* x1) {
-    if (G <= 0 || G > GN_MAX_GROUPS || C % G || C % 8 || C > 5120) return fail(-EINVAL, "groupnorm: bad C=%d G=%d", C, G);
+    if (G <= 0 || G > GN_MAX_GROUPS || C % G || C % 8 || C > 5120 || C / G < 2)
+        return fail(-EINVAL, "groupnorm: bad C=%d G=%d (need C %% 8 == 0, 2 <= C/G, C <= 5120)", C, G);
     if (x1 && (c0 % 8 || c0 <= 0 || c0 >= C)) return fail(-EINVAL, "groupnorm: bad concat split %d of %d", c0, C);
     return 0;
 }
@@ -309,7 +338,7 @@ extern "C" int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, i
     hipLaunchKernelGGL((gn_stats_kernel<0>), dim3(nparts, batch), dim3(256), 0, s, src,
                        (const bf16_t*)nullptr, (int64_t)0, (const float*)nullptr, gamma, beta, act, eps, hw, c,
                        groups, ppb, part);
-    hipLaunchKernelGGL(gn_finish_kernel, dim3(batch), dim3(64), 0, s, (const float*)part, nparts, groups, stats);
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(batch), dim3(256), 0, s, (const float*)part, nparts, groups, stats);
     const int64_t total = (int64_t)batch * hw * (c / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL((gn_apply_kernel<0>), dim3(grid), dim3(256), 0, s, src, (const bf16_t*)nullptr,
@@ -332,7 +361,7 @@ extern "C" int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, i
     float* part = bstats + (int64_t)batch * groups * 2;
     hipLaunchKernelGGL((gn_stats_kernel<1>), dim3(nparts, batch), dim3(256), 0, s, src,
                        (const bf16_t*)dy, lddy, stats, gamma, beta, act, eps, hw, c, groups, ppb, part);
-    hipLaunchKernelGGL(gn_finish_kernel, dim3(batch), dim3(64), 0, s, (const float*)part, nparts, groups, bstats);
+    hipLaunchKernelGGL(gn_finish_kernel, dim3(batch), dim3(256), 0, s, (const float*)part, nparts, groups, bstats);
     const int64_t total = (int64_t)batch * hw * (c / 8);
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL((gn_apply_kernel<1>), dim3(grid), dim3(256), 0, s, src, (const bf16_t*)dy, lddy,
