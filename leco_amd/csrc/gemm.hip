@@ -36,6 +36,12 @@ namespace {
 
 constexpr int BK = 64;
 
+// Tuning aid (tools/ablate_gemm.py builds side libraries with -DLECO_GEMM_ABLATE=1|2): 1 = no MFMA
+// (DMA + barriers + LDS reads only), 2 = no DMA (MFMA on whatever is in LDS).  0 in the product build.
+#ifndef LECO_GEMM_ABLATE
+#define LECO_GEMM_ABLATE 0
+#endif
+
 __device__ const u32x4 g_zero_page[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
@@ -64,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
     const int tile_m = wg / rt.tiles_n, tile_n = wg % rt.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int st_row = lane >> 3;           // row inside an 8-row group this lane stages
     const int st_pos = lane & 7;            // 16-byte slot it fills
@@ -116,9 +122,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
 #pragma unroll
                 for (int i = 0; i < GA; ++i) {
                     const int r = (wave + 4 * i) * 8 + st_row, m = m0 + r;
-                    const int c = st_pos ^ (r & 7);
+                    const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
                     const bf16_t* g = (m < M) ? src + (int64_t)m * ld + kk + c * 8 : zero;
-                    glds16(g, sA + (wave + 4 * i) * 8 * BK);
+                    if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + 4 * i) * 8 * BK);
                 }
             } else {
                 // K order of a conv is channel-chunk major / tap minor: the 9 taps of one 64-channel chunk
@@ -132,29 +138,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
                 int cc;
                 if (cch < k_split) { src = a0; ld = p.lda0; cc = cch; }
                 else { src = a1; ld = p.lda1; cc = cch - k_split; }
+                // branch-free gather parameters of the four conv modes:
+                //   u = o * sy + k - 1 must lie in [0, h_in << dv) (and be even for the transposed
+                //   stride-2 gather); source pixel = u >> dv.
+                const int sy = (p.a_mode == LECO_A_CONV3_S2) ? 2 : 1;
+                const int dv = (p.a_mode == LECO_A_CONV3_UP2 || p.a_mode == LECO_A_CONV3_TR2) ? 1 : 0;
+                const int odd_mask = (p.a_mode == LECO_A_CONV3_TR2) ? 1 : 0;
+                const int lim_y = p.h_in << dv, lim_x = p.w_in << dv;
 #pragma unroll
                 for (int i = 0; i < GA; ++i) {
                     const int r = (wave + 4 * i) * 8 + st_row, m = m0 + r;
-                    const int c = st_pos ^ (r & 7);
-                    int uy = py[i] + kh - 1, ux = px[i] + kw - 1;
-                    bool ok = m < M;
-                    int iy, ix;
-                    if (p.a_mode == LECO_A_CONV3_S1) {
-                        iy = uy; ix = ux;
-                        ok = ok && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
-                    } else if (p.a_mode == LECO_A_CONV3_S2) {
-                        iy = 2 * py[i] + kh - 1; ix = 2 * px[i] + kw - 1;
-                        ok = ok && iy >= 0 && iy < p.h_in && ix >= 0 && ix < p.w_in;
-                    } else if (p.a_mode == LECO_A_CONV3_UP2) {
-                        ok = ok && uy >= 0 && uy < 2 * p.h_in && ux >= 0 && ux < 2 * p.w_in;
-                        iy = uy >> 1; ix = ux >> 1;
-                    } else {  // LECO_A_CONV3_TR2
-                        ok = ok && uy >= 0 && ux >= 0 && ((uy | ux) & 1) == 0;
-                        iy = uy >> 1; ix = ux >> 1;
-                        ok = ok && iy < p.h_in && ix < p.w_in;
-                    }
-                    const bf16_t* g = ok ? src + ((int64_t)(pb[i] * p.h_in + iy) * p.w_in + ix) * ld + cc + c * 8 : zero;
-                    glds16(g, sA + (wave + 4 * i) * 8 * BK);
+                    const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
+                    const int uy = py[i] * sy + kh - 1, ux = px[i] * sy + kw - 1;
+                    const bool ok = (m < M) & (uy >= 0) & (uy < lim_y) & (ux >= 0) & (ux < lim_x) &
+                                    (((uy | ux) & odd_mask) == 0);
+                    const int iy = uy >> dv, ix = ux >> dv;
+                    const int64_t off = ((int64_t)(pb[i] * p.h_in + iy) * p.w_in + ix) * ld + cc + c * 8;
+                    const bf16_t* g = ok ? src + off : zero;
+                    if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + 4 * i) * 8 * BK);
                 }
             }
             int wcol = k0;
@@ -162,24 +163,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
 #pragma unroll
             for (int i = 0; i < GW; ++i) {
                 const int r = (wave + 4 * i) * 8 + st_row, n = n0 + r;
-                const int c = st_pos ^ (r & 7);
+                const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
                 const bf16_t* g = (n < N) ? wp + (int64_t)n * p.ldw + wcol + c * 8 : zero;
-                glds16(g, sB + (wave + 4 * i) * 8 * BK);
+                if (LECO_GEMM_ABLATE != 4) glds16(g, sB + (wave + 4 * i) * 8 * BK);
             }
         } else {  // LoRA K-extension tile
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
                 const int r = (wave + 4 * i) * 8 + st_row, m = m0 + r;
-                const int c = st_pos ^ (r & 7);
+                const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
                 const bf16_t* g = (c * 8 < p.ext_k && m < M) ? aext + (int64_t)m * p.ld_aext + c * 8 : zero;
-                glds16(g, sA + (wave + 4 * i) * 8 * BK);
+                if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + 4 * i) * 8 * BK);
             }
 #pragma unroll
             for (int i = 0; i < GW; ++i) {
                 const int r = (wave + 4 * i) * 8 + st_row, n = n0 + r;
-                const int c = st_pos ^ (r & 7);
+                const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
                 const bf16_t* g = (c * 8 < p.ext_k && n < N) ? wext + (int64_t)n * p.ld_wext + c * 8 : zero;
-                glds16(g, sB + (wave + 4 * i) * 8 * BK);
+                if (LECO_GEMM_ABLATE != 4) glds16(g, sB + (wave + 4 * i) * 8 * BK);
             }
         }
     };
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
         else if (NS >= 3 && inflight == 2) wait_vmcnt<PER>();
         else wait_vmcnt<0>();
         barrier_keep_dma();
-        if (it + NS - 1 < nk) stage(it + NS - 1, (it + NS - 1) % NS);
+        if (it + NS - 1 < nk && LECO_GEMM_ABLATE != 2) stage(it + NS - 1, (it + NS - 1) % NS);
         const bf16_t* sA = smem + (it % NS) * TILE;
         const bf16_t* sB = sA + BM * BK;
         const bool ext_tile = it >= kt_end - kt_begin;
@@ -222,7 +223,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                for (int j = 0; j < FN; ++j) {
+                    if (LECO_GEMM_ABLATE != 1) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                    else acc[i][j][0] += __uint_as_float((unsigned)(wf[j][0] ^ af[i][0]));  // keep the LDS reads live
+                }
         }
     }
 

@@ -57,6 +57,9 @@ __device__ __forceinline__ void barrier_keep_dma() {
 extern __shared__ __attribute__((aligned(16))) unsigned char leco_dyn_lds_[];
 __device__ __forceinline__ unsigned char* dyn_lds() { return leco_dyn_lds_; }
 
+// tells the compiler a value is wave-uniform (v_readfirstlane): needed for values derived from
+// threadIdx (e.g. the wave index) that feed scalar operands such as the LDS-DMA base (M0)
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }

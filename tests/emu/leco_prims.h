@@ -60,6 +60,7 @@ static inline unsigned char* dyn_lds() {
     static thread_local __attribute__((aligned(16))) unsigned char buf[160 * 1024];
     return buf;
 }
+static inline int uniform(int v) { return v; }
 static inline int lane_id() { return emu::lane(); }
 static inline float shfl_xor(float v, int mask) {
     const unsigned char* all = emu::wave_gather(&v, 4);

@@ -1,0 +1,50 @@
+"""GEMM ablation on the GPU box: builds libleco_hip variants with -DLECO_GEMM_ABLATE=1 (no MFMA) / 2 (no DMA)
+and times a few shapes with each, to see which pipe bounds a K step."""
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from leco_amd import build as B, hip  # noqa: E402
+
+bf = torch.bfloat16
+dev = torch.device("cuda:0")
+
+
+def build_variant(v):
+    out = f"/tmp/libleco_ablate{v}.so"
+    srcs = [os.path.join(B.CSRC, f) for f in sorted(os.listdir(B.CSRC)) if f.endswith((".hip", ".cpp"))]
+    cmd = [B.HIPCC, *B.FLAGS, f"-DLECO_GEMM_ABLATE={v}", "-shared", "-x", "hip", *srcs, "-o", out]
+    subprocess.run(cmd, check=True)
+    return out
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+CASES = [("conv L0 320", 16384, 320, 2880, (4, 64, 64, 64, 64), 0), ("conv L1 640", 4096, 640, 5760, (4, 32, 32, 32, 32), 0),
+         ("ff1 L0", 16384, 2560, 320, None, 0), ("big", 8192, 8192, 1024, None, 1), ("lin L0", 16384, 320, 320, None, 0)]
+
+for v in (0, 4, 5):
+    hip._use_library(build_variant(v) if v else hip.LIB_PATH)
+    for name, M, N, K, conv, tile in CASES:
+        x = torch.randn(M if conv is None else conv[0] * conv[3] * conv[4], K if conv is None else K // 9, device=dev).to(bf)
+        w = (torch.randn(N, K, device=dev) / K ** 0.5).to(bf)
+        out = torch.empty(M, N, dtype=bf, device=dev)
+        kw = dict(a_mode=hip.A_CONV3_S1, conv=conv, lda=K // 9) if conv else {}
+        g = hip.gemm_args(x, w, out, m=M, n=N, k=K, **kw)
+        t = timeit(lambda: hip.gemm(g, None, tile))
+        print(f"ablate={v} {name:12s} {t:8.1f} us  ({2.0*M*N*K/t/1e6:7.1f} TF/s nominal)", flush=True)
