@@ -55,7 +55,7 @@ typedef struct leco_gemm_args {
     int32_t batch, h_out, w_out, h_in, w_in; /* conv modes only */
     const void* w;        /* bf16 [N][K], K contiguous; conv: [N][3][3][Cin] */
     int64_t ldw;
-    int32_t m, n, k;      /* k % 64 == 0 (conv: Cin % 64 == 0), n % 4 == 0 */
+    int32_t m, n, k;      /* k % 64 == 0 (conv: Cin % 64 == 0), n % 8 == 0 */
     const void* a_ext;    /* bf16 [M][ext_k] (row stride ld_aext) or NULL */
     int64_t ld_aext;
     const void* w_ext;    /* bf16 [N][ext_k] (row stride ld_wext) */

@@ -230,57 +230,71 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
         }
     }
 
-    // lane holds C[m = .. + fr][n = .. + 4*fg + r], r = 0..3
-    if (rt.split_k > 1) {
-        float* ws = rt.ws + (int64_t)split * M * N;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int m = m0 + wave_m * WM + i * 16 + fr;
-            if (m >= M) continue;
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int n = n0 + wave_n * WN + j * 16 + 4 * fg;
-                if (n < N) *(f32x4*)(ws + (int64_t)m * N + n) = acc[i][j];
-            }
-        }
-        return;
-    }
+    // ---- epilogue through LDS: the accumulators (lane = one row x 4 consecutive n) are staged as fp32,
+    // 64 tile rows at a time, so that the global side of the epilogue (residual / bias reads, bf16 or
+    // fp32-partial stores) moves whole 16..32-byte row segments per lane with full-line coalescing.
+    constexpr int SROW = BN + 4;                 // padded fp32 row (bank spread for the f32x4 writes)
+    constexpr int NC8 = BN / 8;
+    float* stg = (float*)dyn_lds();
     bf16_t* cp = (bf16_t*)p.c;
     const bf16_t* res = (const bf16_t*)p.residual;
+    float* wsp = rt.split_k > 1 ? rt.ws + (int64_t)split * M * N : nullptr;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-        const int m = m0 + wave_m * WM + i * 16 + fr;
-        if (m >= M) continue;
-        const float* rb = p.rowbias ? p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias : nullptr;
+    for (int h = 0; h < BM / 64; ++h) {
+        barrier_keep_dma();                      // ring buffers / previous half no longer read
+        if (BM == 64 || wave_m == h) {
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = n0 + wave_n * WN + j * 16 + 4 * fg;
-            if (n >= N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-                f32x4 b = *(const f32x4*)(p.bias + n);
-                v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+            for (int i = 0; i < FM; ++i) {
+                const int rl = (BM == 64 ? wave_m * WM : 0) + i * 16 + fr;   // row inside this 64-row half
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    *(f32x4*)(stg + rl * SROW + wave_n * WN + j * 16 + 4 * fg) = acc[i][j];
             }
-            if (rb) {
-                f32x4 b = *(const f32x4*)(rb + n);
-                v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+        }
+        barrier_keep_dma();
+        for (int e = tid; e < 64 * NC8; e += 256) {
+            const int rl = e / NC8, cc = e - rl * NC8;
+            const int m = m0 + h * 64 + rl, n = n0 + cc * 8;
+            if (m >= M || n >= N) continue;
+            const f32x4 v0 = *(const f32x4*)(stg + rl * SROW + cc * 8);
+            const f32x4 v1 = *(const f32x4*)(stg + rl * SROW + cc * 8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (wsp) {   // split-K: raw partial sums, the epilogue runs in splitk_finish_kernel
+                *(f32x4*)(wsp + (int64_t)m * N + n) = v0;
+                *(f32x4*)(wsp + (int64_t)m * N + n + 4) = v1;
+                continue;
+            }
+            if (p.bias) {
+                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
+            }
+            if (p.rowbias) {
+                const float* rb = p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias + n;
+                const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
             }
             if (res) {
-                u32x2 rr = *(const u32x2*)(res + (int64_t)m * p.ldr + n);
-                v[0] += bf2f((bf16_t)(rr[0] & 0xffffu)); v[1] += bf2f((bf16_t)(rr[0] >> 16));
-                v[2] += bf2f((bf16_t)(rr[1] & 0xffffu)); v[3] += bf2f((bf16_t)(rr[1] >> 16));
+                const u32x4 rr = *(const u32x4*)(res + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[2 * r] += bf2f((bf16_t)(rr[r] & 0xffffu));
+                    v[2 * r + 1] += bf2f((bf16_t)(rr[r] >> 16));
+                }
             }
             if (p.act == LECO_ACT_SILU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
+                for (int r = 0; r < 8; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
             }
             if (cp) {
-                u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                *(u32x2*)(cp + (int64_t)m * p.ldc + n) = o;
+                const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                *(u32x4*)(cp + (int64_t)m * p.ldc + n) = o;
             }
             if (p.c_f32) {
-                f32x4 o = {v[0], v[1], v[2], v[3]};
-                *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n) = o;
+                const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n) = o0;
+                *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n + 4) = o1;
             }
         }
     }
@@ -368,7 +382,9 @@ int launch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s) {
 int validate(const leco_gemm_args& a) {
     if (a.m <= 0 || a.n <= 0 || a.k <= 0) return fail(-EINVAL, "leco_gemm: empty problem m=%d n=%d k=%d", a.m, a.n, a.k);
     if (a.k % BK) return fail(-EINVAL, "leco_gemm: k=%d not a multiple of 64", a.k);
-    if (a.n % 4) return fail(-EINVAL, "leco_gemm: n=%d not a multiple of 4", a.n);
+    if (a.n % 8) return fail(-EINVAL, "leco_gemm: n=%d not a multiple of 8", a.n);
+    if ((a.c && a.ldc % 8) || (a.residual && a.ldr % 8) || (a.c_f32 && a.ldc32 % 4) || (a.rowbias && a.ld_rowbias % 4))
+        return fail(-EINVAL, "leco_gemm: output / residual strides must keep 16-byte alignment");
     if (!a.a0 || !a.w) return fail(-EINVAL, "leco_gemm: null operand");
     if (!a.c && !a.c_f32) return fail(-EINVAL, "leco_gemm: no output");
     if (a.a_ext && a.ext_k != 32 && a.ext_k != 64) return fail(-EINVAL, "leco_gemm: ext_k=%d must be 32 or 64", a.ext_k);
