@@ -54,11 +54,17 @@ struct GemmRt {      // launch-time extras (not part of the C ABI struct)
     float* ws;
 };
 
-template <int BM, int BN, bool CONV, int NS>   // NS in {2, 4}
-__global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const GemmRt rt) {
-    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-    constexpr int GA = BM / 32, GW = BN / 32;  // 8-row groups staged per wave (A / W)
-    constexpr int PER = GA + GW;               // DMA instructions per wave per tile
+// NS in {2, 4}: LDS ring depth.  NWM in {2, 4}: waves along M (block = NWM x 2 waves).  With NWM = 4 a
+// 128-row tile runs on 8 waves = 2 per SIMD, so one wave's LDS-read latency hides behind the other's MFMAs
+// even when only one workgroup fits on a CU.
+template <int BM, int BN, bool CONV, int NS, int NWM>
+__global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p, const GemmRt rt) {
+    constexpr int NW = NWM * 2, NT = NW * 64;
+    constexpr int WM = BM / NWM, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int GA = BM / 8 / NW;                       // 8-row groups staged per wave (A), exact
+    constexpr int GWT = BN / 8, GW = (GWT + NW - 1) / NW; // W groups: total / per wave (last may be absent)
+    constexpr bool RAGGED = (GWT % NW) != 0;
+    static_assert((BM / 8) % NW == 0, "A row groups must divide evenly over the waves");
     constexpr int TILE = (BM + BN) * BK;       // elements per LDS buffer
     bf16_t* smem = (bf16_t*)dyn_lds();
 
@@ -72,6 +78,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int wave_m = wave >> 1, wave_n = wave & 1;
+    // DMA instructions this wave issues per tile (ragged: the last W group exists only for the low waves)
+    const bool w_last = !RAGGED || (wave + NW * (GW - 1) < GWT);
     const int st_row = lane >> 3;           // row inside an 8-row group this lane stages
     const int st_pos = lane & 7;            // 16-byte slot it fills
 
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
         const int hw = p.h_out * p.w_out;
 #pragma unroll
         for (int i = 0; i < GA; ++i) {
-            int m = m0 + (wave + 4 * i) * 8 + st_row;
+            int m = m0 + (wave + NW * i) * 8 + st_row;
             int mm = m < M ? m : 0;
             pb[i] = mm / hw;
             int rem = mm - pb[i] * hw;
@@ -121,10 +129,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
                 else { src = a1; ld = p.lda1; kk = k0 - k_split; }
 #pragma unroll
                 for (int i = 0; i < GA; ++i) {
-                    const int r = (wave + 4 * i) * 8 + st_row, m = m0 + r;
+                    const int r = (wave + NW * i) * 8 + st_row, m = m0 + r;
                     const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
                     const bf16_t* g = (m < M) ? src + (int64_t)m * ld + kk + c * 8 : zero;
-                    if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + 4 * i) * 8 * BK);
+                    if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + NW * i) * 8 * BK);
                 }
             } else {
                 // K order of a conv is channel-chunk major / tap minor: the 9 taps of one 64-channel chunk
@@ -147,7 +155,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
                 const int lim_y = p.h_in << dv, lim_x = p.w_in << dv;
 #pragma unroll
                 for (int i = 0; i < GA; ++i) {
-                    const int r = (wave + 4 * i) * 8 + st_row, m = m0 + r;
+                    const int r = (wave + NW * i) * 8 + st_row, m = m0 + r;
                     const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
                     const int uy = py[i] * sy + kh - 1, ux = px[i] * sy + kw - 1;
                     const bool ok = (m < M) & (uy >= 0) & (uy < lim_y) & (ux >= 0) & (ux < lim_x) &
@@ -155,32 +163,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
                     const int iy = uy >> dv, ix = ux >> dv;
                     const int64_t off = ((int64_t)(pb[i] * p.h_in + iy) * p.w_in + ix) * ld + cc + c * 8;
                     const bf16_t* g = ok ? src + off : zero;
-                    if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + 4 * i) * 8 * BK);
+                    if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + NW * i) * 8 * BK);
                 }
             }
             int wcol = k0;
             if (CONV) { const int chunk = kt / 9, tap = kt - chunk * 9; wcol = tap * cin + chunk * BK; }
 #pragma unroll
             for (int i = 0; i < GW; ++i) {
-                const int r = (wave + 4 * i) * 8 + st_row, n = n0 + r;
+                if (RAGGED && i == GW - 1 && !w_last) break;
+                const int r = (wave + NW * i) * 8 + st_row, n = n0 + r;
                 const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
                 const bf16_t* g = (n < N) ? wp + (int64_t)n * p.ldw + wcol + c * 8 : zero;
-                if (LECO_GEMM_ABLATE != 4) glds16(g, sB + (wave + 4 * i) * 8 * BK);
+                if (LECO_GEMM_ABLATE != 4) glds16(g, sB + (wave + NW * i) * 8 * BK);
             }
         } else {  // LoRA K-extension tile
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
-                const int r = (wave + 4 * i) * 8 + st_row, m = m0 + r;
+                const int r = (wave + NW * i) * 8 + st_row, m = m0 + r;
                 const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
                 const bf16_t* g = (c * 8 < p.ext_k && m < M) ? aext + (int64_t)m * p.ld_aext + c * 8 : zero;
-                if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + 4 * i) * 8 * BK);
+                if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + NW * i) * 8 * BK);
             }
 #pragma unroll
             for (int i = 0; i < GW; ++i) {
-                const int r = (wave + 4 * i) * 8 + st_row, n = n0 + r;
+                if (RAGGED && i == GW - 1 && !w_last) break;
+                const int r = (wave + NW * i) * 8 + st_row, n = n0 + r;
                 const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
                 const bf16_t* g = (c * 8 < p.ext_k && n < N) ? wext + (int64_t)n * p.ld_wext + c * 8 : zero;
-                if (LECO_GEMM_ABLATE != 4) glds16(g, sB + (wave + 4 * i) * 8 * BK);
+                if (LECO_GEMM_ABLATE != 4) glds16(g, sB + (wave + NW * i) * 8 * BK);
             }
         }
     };
@@ -203,9 +213,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
     const int fr = lane & 15, fg = lane >> 4;
     for (int it = 0; it < nk; ++it) {
         const int inflight = nk - it < NS - 1 ? nk - it : NS - 1;   // tiles it .. it+inflight-1
-        if (NS >= 4 && inflight >= 3) wait_vmcnt<2 * PER>();
-        else if (NS >= 3 && inflight == 2) wait_vmcnt<PER>();
-        else wait_vmcnt<0>();
+        if (NS >= 4 && inflight >= 3) {
+            if (w_last) wait_vmcnt<2 * (GA + GW)>(); else wait_vmcnt<2 * (GA + GW - 1)>();
+        } else if (NS >= 3 && inflight == 2) {
+            if (w_last) wait_vmcnt<GA + GW>(); else wait_vmcnt<GA + GW - 1>();
+        } else {
+            wait_vmcnt<0>();
+        }
         barrier_keep_dma();
         if (it + NS - 1 < nk && LECO_GEMM_ABLATE != 2) stage(it + NS - 1, (it + NS - 1) % NS);
         const bf16_t* sA = smem + (it % NS) * TILE;
@@ -242,17 +256,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const leco_gemm_args p, const
 #pragma unroll
     for (int h = 0; h < BM / 64; ++h) {
         barrier_keep_dma();                      // ring buffers / previous half no longer read
-        if (BM == 64 || wave_m == h) {
+        if (BM == 64 || (wave_m * WM) / 64 == h) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int rl = (BM == 64 ? wave_m * WM : 0) + i * 16 + fr;   // row inside this 64-row half
+                const int rl = (wave_m * WM) % 64 + i * 16 + fr;   // row inside this 64-row half
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     *(f32x4*)(stg + rl * SROW + wave_n * WN + j * 16 + 4 * fg) = acc[i][j];
             }
         }
         barrier_keep_dma();
-        for (int e = tid; e < 64 * NC8; e += 256) {
+        for (int e = tid; e < 64 * NC8; e += NT) {
             const int rl = e / NC8, cc = e - rl * NC8;
             const int m = m0 + h * 64 + rl, n = n0 + cc * 8;
             if (m >= M || n >= N) continue;
@@ -342,26 +356,27 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const leco_gemm_args
     }
 }
 
-template <int BM, int BN, bool CONV, int NS>
+template <int BM, int BN, bool CONV, int NS, int NWM>
 void launch_ns(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
     constexpr int lds_bytes = NS * (BM + BN) * BK * (int)sizeof(bf16_t);
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, NS>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, NS, NWM>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, NS>), grid, dim3(256), lds_bytes, s, a, rt);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, NS, NWM>), grid, dim3(NWM * 128), lds_bytes, s, a, rt);
 }
 
-// DMA ring depth: with <= ~1 workgroup per CU nothing else hides the global->LDS latency, so use the
-// 4-deep ring (4 x 36 KB for 128x160); with several workgroups per CU keep 2 buffers (<= 72 KB) so
-// two workgroups stay resident and overlap each other.
+// Pipeline shape by grid size.  Grids that put <= ~1.5 workgroups on a CU get the 4-deep DMA ring
+// (4 x 36 KB for 128x160) and, for 128-row tiles, 8 waves (two per SIMD); larger grids keep two
+// 4-wave workgroups per CU with 2 buffers each, which overlap each other.
 template <int BM, int BN, bool CONV>
 void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
     const long blocks = (long)grid.x * grid.y;
-    if (BM == 64 || blocks <= 384) launch_ns<BM, BN, CONV, 4>(a, rt, grid, s);
-    else launch_ns<BM, BN, CONV, 2>(a, rt, grid, s);
+    if (BM == 64) launch_ns<BM, BN, CONV, 4, 2>(a, rt, grid, s);
+    else if (blocks <= 384) launch_ns<BM, BN, CONV, 4, (BM >= 128 ? 4 : 2)>(a, rt, grid, s);
+    else launch_ns<BM, BN, CONV, 2, 2>(a, rt, grid, s);
 }
 
 template <int BM, int BN>
@@ -421,15 +436,16 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
             const int bn = (n % 128 == 0) ? 128 : ((n % 160 == 0) ? 160 : 128);
             const long blocks = (long)cdiv(m, 128) * cdiv(n, bn);
             const bool can_split = workspace != nullptr && nk >= 16;
-            tile = (blocks >= 192 || (can_split && m >= 128)) ? (bn == 160 ? 2 : 1) : 3;
+            tile = (blocks >= 128 || (can_split && m >= 128)) ? (bn == 160 ? 2 : 1) : 3;
         }
     }
     const int bm = tile == 3 ? 64 : 128, bn = tile == 3 ? 64 : (tile == 2 ? 160 : 128);
     const long tiles = (long)cdiv(m, bm) * cdiv(n, bn);
     if (split_k == 0) {
         split_k = 1;
-        if (workspace && tiles < 160 && nk >= 16) {
-            split_k = (int)((320 + tiles - 1) / tiles);
+        if (workspace && tiles <= 128 && nk >= 16) {
+            // one workgroup per CU in this regime: fill the 256 CUs in ONE round (no ragged second wave)
+            split_k = (int)(256 / tiles);
             if (split_k > nk / 8) split_k = nk / 8;
             if (split_k > 16) split_k = 16;
         }

@@ -56,6 +56,17 @@ def test_gemm_split_k_with_epilogue_and_lora_tile(dev, tile, split):
     assert rel_err(o32, ref) < TOL32 and rel_err(out, ref) < TOLBF
 
 
+def test_gemm_large_grid_two_buffer_variant(dev):
+    """> 384 workgroups selects the 4-wave / 2-buffer pipeline (the small cases use the 8-wave / 4-deep ring)."""
+    torch.manual_seed(12)
+    M, N, K = 2560, 2560, 128
+    a = torch.randn(M, K).to(bf).to(dev); w = (torch.randn(N, K) / K ** 0.5).to(bf).to(dev)
+    out = torch.zeros(M, N, dtype=bf, device=dev)
+    hip.gemm(hip.gemm_args(a, w, out, m=M, n=N, k=K), ops.default_stream(), 1)
+    _sync(dev)
+    assert rel_err(out, a.float() @ w.float().T) < TOLBF
+
+
 def test_gemm_mfma_layout_asymmetric(dev):
     """A = I-like / asymmetric-B check (cdna_hip_programming.md: transposes must be caught)."""
     M = N = K = 64

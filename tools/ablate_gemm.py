@@ -36,9 +36,12 @@ def timeit(fn, iters=20):
 
 
 CASES = [("conv L0 320", 16384, 320, 2880, (4, 64, 64, 64, 64), 0), ("conv L1 640", 4096, 640, 5760, (4, 32, 32, 32, 32), 0),
-         ("ff1 L0", 16384, 2560, 320, None, 0), ("big", 8192, 8192, 1024, None, 1), ("lin L0", 16384, 320, 320, None, 0)]
+         ("conv L2 1280", 1024, 1280, 11520, (4, 16, 16, 16, 16), 0), ("conv L3 1280", 256, 1280, 11520, (4, 8, 8, 8, 8), 0),
+         ("ff1 L0", 16384, 2560, 320, None, 0), ("lin L2 1280", 1024, 1280, 1280, None, 0)]
+ws = torch.empty(32 * 1024 * 1024, device=dev)
+VARIANTS = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 4, 5]
 
-for v in (0, 4, 5):
+for v in VARIANTS:
     hip._use_library(build_variant(v) if v else hip.LIB_PATH)
     for name, M, N, K, conv, tile in CASES:
         x = torch.randn(M if conv is None else conv[0] * conv[3] * conv[4], K if conv is None else K // 9, device=dev).to(bf)
@@ -46,5 +49,5 @@ for v in (0, 4, 5):
         out = torch.empty(M, N, dtype=bf, device=dev)
         kw = dict(a_mode=hip.A_CONV3_S1, conv=conv, lda=K // 9) if conv else {}
         g = hip.gemm_args(x, w, out, m=M, n=N, k=K, **kw)
-        t = timeit(lambda: hip.gemm(g, None, tile))
+        t = timeit(lambda: hip.gemm(g, None, tile, 0, ws))
         print(f"ablate={v} {name:12s} {t:8.1f} us  ({2.0*M*N*K/t/1e6:7.1f} TF/s nominal)", flush=True)
