@@ -35,6 +35,11 @@ struct AttnArgs {
 
 constexpr int KT = 64;  // keys per tile
 
+// Tuning aid (tools/ablate_attn.py): 1 = no exp2, 2 = no K/V staging, 3 = no PV MFMA, 4 = no QK MFMA.
+#ifndef LECO_ATTN_ABLATE
+#define LECO_ATTN_ABLATE 0
+#endif
+
 template <int D, int QF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
@@ -112,7 +117,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + 256 * i;
-            if (e < KT * NDC) {
+            if (e < KT * NDC && LECO_ATTN_ABLATE != 2) {
                 const int key = e / NDC, ch = e - key * NDC;
                 *(u32x4*)(sK + key * KROW + ch * 8) = kreg[i];
                 const int vch = e / KT, vkey = e - vch * KT;
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             }
         }
         __syncthreads();
-        if (kv0 + KT < p.skv) fetch(kv0 + KT);
+        if (kv0 + KT < p.skv && LECO_ATTN_ABLATE != 2) fetch(kv0 + KT);
 
         // S^T = K Q^T : lane holds S[q = fr][key = kv0 + 16 f + 4 fg + r]
         f32x4 acc_s[QF][4];
@@ -139,7 +144,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             for (int u = 0; u < QF; ++u) {
                 f32x4 a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int ks = 0; ks < NKS; ++ks) a = mfma16(kf[ks], qf[u][ks], a);
+                for (int ks = 0; ks < NKS; ++ks) {
+                    if (LECO_ATTN_ABLATE != 4) a = mfma16(kf[ks], qf[u][ks], a);
+                    else a[0] += __uint_as_float((unsigned)(kf[ks][0] ^ qf[u][ks][0]));
+                }
                 acc_s[u][f] = a;
             }
         }
@@ -167,8 +175,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             float rs = 0.f;
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                float e0 = fast_exp2(acc_s[u][f][0] - m_new), e1 = fast_exp2(acc_s[u][f][1] - m_new);
-                float e2 = fast_exp2(acc_s[u][f][2] - m_new), e3 = fast_exp2(acc_s[u][f][3] - m_new);
+                float e0, e1, e2, e3;
+                if (LECO_ATTN_ABLATE != 1) {
+                    e0 = fast_exp2(acc_s[u][f][0] - m_new); e1 = fast_exp2(acc_s[u][f][1] - m_new);
+                    e2 = fast_exp2(acc_s[u][f][2] - m_new); e3 = fast_exp2(acc_s[u][f][3] - m_new);
+                } else {
+                    e0 = acc_s[u][f][0] - m_new; e1 = acc_s[u][f][1] - m_new;
+                    e2 = acc_s[u][f][2] - m_new; e3 = acc_s[u][f][3] - m_new;
+                }
                 rs += (e0 + e1) + (e2 + e3);
                 pw[u][f >> 1][(f & 1) * 2] = pack_bf2(e0, e1);
                 pw[u][f >> 1][(f & 1) * 2 + 1] = pack_bf2(e2, e3);
@@ -193,8 +207,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                 u32x4 t = {lo[0], lo[1], hi[0], hi[1]};
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, t);
 #pragma unroll
-                for (int u = 0; u < QF; ++u)
-                    acc_o[u][fd] = mfma16(vf, __builtin_bit_cast(bf16x8, pw[u][s]), acc_o[u][fd]);
+                for (int u = 0; u < QF; ++u) {
+                    if (LECO_ATTN_ABLATE != 3) acc_o[u][fd] = mfma16(vf, __builtin_bit_cast(bf16x8, pw[u][s]), acc_o[u][fd]);
+                    else acc_o[u][fd][0] += __uint_as_float((unsigned)vf[0] ^ pw[u][s][0]);
+                }
             }
         }
     }

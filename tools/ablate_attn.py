@@ -1,0 +1,45 @@
+"""Attention-forward ablation on the GPU box (variants built with -DLECO_ATTN_ABLATE=n)."""
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from leco_amd import build as B, hip, ops  # noqa: E402
+
+bf = torch.bfloat16
+dev = torch.device("cuda:0")
+
+
+def build_variant(v):
+    out = f"/tmp/libleco_attn{v}.so"
+    srcs = [os.path.join(B.CSRC, f) for f in sorted(os.listdir(B.CSRC)) if f.endswith((".hip", ".cpp"))]
+    subprocess.run([B.HIPCC, *B.FLAGS, f"-DLECO_ATTN_ABLATE={v}", "-shared", "-x", "hip", *srcs, "-o", out], check=True)
+    return out
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+for v in [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4]:
+    hip._use_library(build_variant(v) if v else hip.LIB_PATH)
+    for (Bq, H, Sq, Skv, D) in [(4, 8, 4096, 4096, 40), (4, 8, 1024, 1024, 80), (4, 5, 9216, 9216, 64)]:
+        C = H * D
+        q = torch.randn(Bq, Sq, C, device=dev).to(bf); k = torch.randn(Bq, Skv, C, device=dev).to(bf)
+        vv = torch.randn(Bq, Skv, C, device=dev).to(bf); o = torch.empty_like(q); lse = torch.empty(Bq, H, Sq, device=dev)
+        op = ops.attention_fwd(q.data_ptr(), C, Sq * C, k.data_ptr(), C, Skv * C, vv.data_ptr(), C, Skv * C, o.data_ptr(), C,
+                               Sq * C, lse, Bq, H, Sq, Skv, D, D ** -0.5)
+        t = timeit(lambda: op.run(None))
+        print(f"ablate={v} S={Sq} D={D}: {t:8.1f} us ({4.0*Bq*H*Sq*Skv*D/t/1e6:7.1f} TF/s nominal)", flush=True)
