@@ -376,7 +376,7 @@ void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_
     const long blocks = (long)grid.x * grid.y;
     if (BM == 64) launch_ns<BM, BN, CONV, 4, 2>(a, rt, grid, s);
     else if (blocks <= 384) launch_ns<BM, BN, CONV, 4, (BM >= 128 ? 4 : 2)>(a, rt, grid, s);
-    else launch_ns<BM, BN, CONV, 2, 2>(a, rt, grid, s);
+    else launch_ns<BM, BN, CONV, 2, (BM >= 128 ? 4 : 2)>(a, rt, grid, s);
 }
 
 template <int BM, int BN>

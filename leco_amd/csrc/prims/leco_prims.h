@@ -16,16 +16,15 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 hw_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
-// round-to-nearest-even; NaN stays NaN (quiet)
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+// float -> bf16, round-to-nearest-even, through the gfx950 hardware converter (v_cvt_pk_bf16_f32:
+// one instruction per PAIR of values; a hand-rolled integer rounding costs ~7 VALU ops per value).
+typedef __bf16 hw_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    f32x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, hw_bf16x2));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 
 // D(16x16,f32) = A(16x32,bf16) * B(32x16,bf16) + C   -- v_mfma_f32_16x16x32_bf16.
 // Lane l supplies A[l&15][8*(l>>4)+t] and B[8*(l>>4)+t][l&15], t=0..7, and holds
