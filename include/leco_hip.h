@@ -123,7 +123,7 @@ int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* worksp
  * fp32 [batch][groups][2] scratch ({sum, sumsq} resp. {sum dxhat, sum dxhat*xhat}); the
  * forward stats must be kept for the backward.  act: LECO_ACT_NONE / LECO_ACT_SILU.
  * ---------------------------------------------------------------------- */
-#define LECO_GN_STATS_FLOATS(batch, groups) ((int64_t)(batch) * (groups) * 2 * 65)
+#define LECO_GN_STATS_FLOATS(batch, groups) ((int64_t)(batch) * (groups) * 2 * 257)
 int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
                        const float* gamma, const float* beta, int32_t batch, int32_t hw, int32_t c,
                        int32_t groups, float eps, int32_t act, float* stats, void* y, int64_t ldy,

@@ -52,7 +52,7 @@ __device__ __forceinline__ u32x4 gn_load(const GnSrc& s, int64_t row, int c) {
 }
 
 constexpr int GN_MAX_GROUPS = 32;
-constexpr int GN_MAX_PARTS = 64;   // pixel-range blocks per sample
+constexpr int GN_MAX_PARTS = 256;  // pixel-range blocks per sample
 constexpr int GN_LDS_FLOATS = 2 * 2560 * 2;  // [rows_par][C][2] staging, rows_par * C <= 5120
 
 // Deterministic two-stage statistics (no atomics: results are bitwise reproducible run to run).
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void gn_finish_kernel(const float* part, int n
     float acc = 0.f;
     if (v < 2 * G) {
         const float* src = part + (int64_t)b * nparts * G * 2 + v;
-#pragma unroll 4
+#pragma unroll 8
         for (int p = q; p < nparts; p += 4) acc += src[(int64_t)p * G * 2];
     }
     quarter[t] = acc;
@@ -313,11 +313,11 @@ int gn_check(int C, int G, int c0, const void* x1) {
 }
 int pix_per_block(int batch, int hw, int c) {
     // <= GN_MAX_PARTS pixel ranges per sample; at least 16 pixels each
-    int nblk = 512 / (batch > 0 ? batch : 1);
+    int nblk = 2048 / (batch > 0 ? batch : 1);
     if (nblk < 1) nblk = 1;
     if (nblk > GN_MAX_PARTS) nblk = GN_MAX_PARTS;
     int ppb = cdiv(hw, nblk);
-    return ppb < 16 ? 16 : ppb;
+    return ppb < 12 ? 12 : ppb;
 }
 }  // namespace
 }  // namespace leco

@@ -631,7 +631,7 @@ class PlanBuilder:
         G = self.cfg.norm_num_groups
         rows = xs[0].rows
         y = self.act(name, rows, Cc, rg=any(t.rg for t in xs))
-        stats = self.buf(name + ".stats", (self.B * G * 2 * 65,), torch.float32)
+        stats = self.buf(name + ".stats", (self.B * G * 2 * 257,), torch.float32)
         x1 = xs[1] if len(xs) == 2 else None
         self.both(ops.Op("leco_groupnorm_fwd", (xs[0].ptr, xs[0].ld, x1.ptr if x1 else None, x1.ld if x1 else 0,
                                                 xs[0].cols if x1 else 0, gamma.data_ptr(), beta.data_ptr(), self.B, hw,
@@ -643,7 +643,7 @@ class PlanBuilder:
                 if dy is None:
                     return
                 dx = self.act("g." + name + ".dx", rows, Cc)
-                bst = self.buf("g." + name + ".bstats", (self.B * G * 2 * 65,), torch.float32)
+                bst = self.buf("g." + name + ".bstats", (self.B * G * 2 * 257,), torch.float32)
                 out.append(ops.Op("leco_groupnorm_bwd", (xs[0].ptr, xs[0].ld, x1.ptr if x1 else None,
                                                          x1.ld if x1 else 0, xs[0].cols if x1 else 0, dy.ptr, dy.ld,
                                                          gamma.data_ptr(), beta.data_ptr(), stats.data_ptr(), self.B,

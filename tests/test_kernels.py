@@ -144,12 +144,12 @@ def test_groupnorm_fwd_bwd(dev, act):
     C = C0 + C1
     x0 = torch.randn(B * HW, C0).to(bf).to(dev); x1 = (torch.randn(B * HW, C1) * 2 + 0.5).to(bf).to(dev)
     gamma = torch.randn(C).to(dev); beta = torch.randn(C).to(dev)
-    stats = torch.zeros(B * G * 2 * 65, device=dev); y = torch.zeros(B * HW, C, dtype=bf, device=dev)
+    stats = torch.zeros(B * G * 2 * 257, device=dev); y = torch.zeros(B * HW, C, dtype=bf, device=dev)
     ops.groupnorm_fwd(x0, C0, x1, C1, C0, gamma, beta, B, HW, C, G, 1e-5, act, stats, y, C).run()
     xc = torch.cat([x0, x1], 1).float().cpu().reshape(B, HW, C).permute(0, 2, 1).requires_grad_(True)
     ref = F.group_norm(xc, G, gamma.cpu(), beta.cpu(), 1e-5)
     ref = F.silu(ref) if act else ref
-    dy = torch.randn(B * HW, C).to(bf).to(dev); bstats = torch.zeros(B * G * 2 * 65, device=dev)
+    dy = torch.randn(B * HW, C).to(bf).to(dev); bstats = torch.zeros(B * G * 2 * 257, device=dev)
     dx = torch.zeros(B * HW, C, dtype=bf, device=dev)
     ops.groupnorm_bwd(x0, C0, x1, C1, C0, dy, C, gamma, beta, stats, B, HW, C, G, 1e-5, act, bstats, dx, C).run()
     _sync(dev)
