@@ -201,47 +201,59 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // NS-deep DMA ring.  At the top of iteration `it` the DMAs of tiles it .. it+NS-2 are in flight.
-    // A wave waits (counted vmcnt) until ITS pieces of tile `it` have landed; the single barrier of the
-    // iteration then (a) covers the other waves' pieces and (b) proves every wave is done reading the
-    // buffer of tile it-1, which is exactly the one the next DMA (tile it+NS-1) overwrites.  The barrier
-    // does not drain the younger DMAs.
+    // NS-deep DMA ring + software-pipelined fragment reads.  A K tile is consumed in two 32-wide half
+    // steps; the ds_read_b128 of half step h+1 are issued BEFORE the MFMAs of half step h (two fragment
+    // register sets), so LDS latency overlaps MFMA issue inside a wave.  Per iteration `it`:
+    //     read frags(it, ks1)           | MFMA frags(it, ks0)
+    //     wait "tile it+1 landed" (counted vmcnt: this wave's pieces) ; barrier
+    //         -> every wave has now finished reading tile `it` (both halves are in registers), so its ring
+    //            slot can be re-filled; the barrier does not drain the younger DMAs
+    //     issue DMA(tile it+NS) into that slot ; read frags(it+1, ks0) | MFMA frags(it, ks1)
 #pragma unroll
-    for (int s0 = 0; s0 < NS - 1; ++s0)
+    for (int s0 = 0; s0 < NS; ++s0)
         if (s0 < nk) stage(s0, s0);
 
     const int fr = lane & 15, fg = lane >> 4;
-    for (int it = 0; it < nk; ++it) {
-        const int inflight = nk - it < NS - 1 ? nk - it : NS - 1;   // tiles it .. it+inflight-1
-        if (NS >= 4 && inflight >= 3) {
-            if (w_last) wait_vmcnt<2 * (GA + GW)>(); else wait_vmcnt<2 * (GA + GW - 1)>();
-        } else if (NS >= 3 && inflight == 2) {
-            if (w_last) wait_vmcnt<GA + GW>(); else wait_vmcnt<GA + GW - 1>();
-        } else {
-            wait_vmcnt<0>();
-        }
-        barrier_keep_dma();
-        if (it + NS - 1 < nk && LECO_GEMM_ABLATE != 2) stage(it + NS - 1, (it + NS - 1) % NS);
+    bf16x8 afA[FM], wfA[FN], afB[FM], wfB[FN];
+    auto read_frags = [&](int it, int ks, bf16x8 (&af)[FM], bf16x8 (&wf)[FN]) {
         const bf16_t* sA = smem + (it % NS) * TILE;
         const bf16_t* sB = sA + BM * BK;
-        const bool ext_tile = it >= kt_end - kt_begin;
-        const int ksteps = (ext_tile && p.ext_k <= 32) ? 1 : 2;
-        for (int ks = 0; ks < ksteps; ++ks) {
-            bf16x8 af[FM], wf[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
-                af[i] = *(const bf16x8*)(sA + lds_off(wave_m * WM + i * 16 + fr, ks * 4 + fg));
+        for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(sA + lds_off(wave_m * WM + i * 16 + fr, ks * 4 + fg));
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-                wf[j] = *(const bf16x8*)(sB + lds_off(wave_n * WN + j * 16 + fr, ks * 4 + fg));
+        for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(sB + lds_off(wave_n * WN + j * 16 + fr, ks * 4 + fg));
+    };
+    auto mma = [&](const bf16x8 (&af)[FM], const bf16x8 (&wf)[FN]) {
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    if (LECO_GEMM_ABLATE != 1) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-                    else acc[i][j][0] += __uint_as_float((unsigned)(wf[j][0] ^ af[i][0]));  // keep the LDS reads live
-                }
-        }
+            for (int j = 0; j < FN; ++j) {
+                if (LECO_GEMM_ABLATE != 1) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                else acc[i][j][0] += __uint_as_float((unsigned)(wf[j][0] ^ af[i][0]));  // keep the LDS reads live
+            }
+    };
+    // wait until this wave's DMA pieces of tile `t` have landed, given that tiles [0, staged) were issued:
+    // the `staged - 1 - t` younger tiles may stay in flight
+    auto wait_tile = [&](int t, int staged) {
+        const int younger = staged - 1 - t;
+        if (NS >= 4 && younger >= 3) { if (w_last) wait_vmcnt<3 * (GA + GW)>(); else wait_vmcnt<3 * (GA + GW - 1)>(); }
+        else if (NS >= 3 && younger == 2) { if (w_last) wait_vmcnt<2 * (GA + GW)>(); else wait_vmcnt<2 * (GA + GW - 1)>(); }
+        else if (NS >= 2 && younger == 1) { if (w_last) wait_vmcnt<GA + GW>(); else wait_vmcnt<GA + GW - 1>(); }
+        else wait_vmcnt<0>();
+    };
+    if (nk > 0) {
+        wait_tile(0, nk < NS ? nk : NS);
+        barrier_keep_dma();
+        read_frags(0, 0, afA, wfA);
+    }
+    for (int it = 0; it < nk; ++it) {
+        read_frags(it, 1, afB, wfB);
+        mma(afA, wfA);
+        if (it + 1 < nk) wait_tile(it + 1, nk < it + NS ? nk : it + NS);
+        barrier_keep_dma();
+        if (it + NS < nk && LECO_GEMM_ABLATE != 2) stage(it + NS, it % NS);
+        if (it + 1 < nk) read_frags(it + 1, 0, afA, wfA);
+        mma(afB, wfB);
     }
 
     // ---- epilogue through LDS: the accumulators (lane = one row x 4 consecutive n) are staged as fp32,
@@ -435,7 +447,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         else {
             const int bn = (n % 128 == 0) ? 128 : ((n % 160 == 0) ? 160 : 128);
             const long blocks = (long)cdiv(m, 128) * cdiv(n, bn);
-            const bool can_split = workspace != nullptr && nk >= 16;
+            const bool can_split = workspace != nullptr && nk >= 32;
             tile = (blocks >= 128 || (can_split && m >= 128)) ? (bn == 160 ? 2 : 1) : 3;
         }
     }
@@ -443,7 +455,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
     const long tiles = (long)cdiv(m, bm) * cdiv(n, bn);
     if (split_k == 0) {
         split_k = 1;
-        if (workspace && tiles <= 128 && nk >= 16) {
+        if (workspace && tiles <= 128 && nk >= 32) {
             // one workgroup per CU in this regime: fill the 256 CUs in ONE round (no ragged second wave)
             split_k = (int)(256 / tiles);
             if (split_k > nk / 8) split_k = nk / 8;

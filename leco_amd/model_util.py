@@ -92,6 +92,34 @@ class SyntheticTextEncoder(torch.nn.Module):
         return (emb,)
 
 
+class _XLOut:
+    def __init__(self, pooled, hidden):
+        self.pooled, self.hidden_states = pooled, [hidden, hidden, hidden]
+
+    def __getitem__(self, i):
+        return (self.pooled, self.hidden_states[-1])[i]
+
+
+class SyntheticTextEncoderXL(SyntheticTextEncoder):
+    """Stand-in for the two SDXL text encoders: ``hidden_states[-2]`` is (1,77,dim), ``[0]`` the pooled vector."""
+
+    def forward(self, tokens, output_hidden_states=False, **kw):
+        hid = torch.cat([self.embed(p) for p in tokens]).to(self._p.device, self._p.dtype)
+        g = torch.Generator().manual_seed(991)
+        proj = torch.randn(self.dim, self.pooled_dim or self.dim, generator=g) / self.dim ** 0.5
+        pooled = (hid.float().mean(1).cpu() @ proj).to(self._p.device, self._p.dtype)
+        return _XLOut(pooled, hid)
+
+
+def tiny_xl_config() -> UNetConfig:
+    return UNetConfig(block_out_channels=(64, 128, 128),
+                      down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                      up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"), layers_per_block=1,
+                      transformer_layers_per_block=(1, 1, 2), attention_head_dim=(2, 2, 2), cross_attention_dim=64,
+                      use_linear_projection=True, sample_size=16, addition_embed_type="text_time",
+                      addition_time_embed_dim=32, projection_class_embeddings_input_dim=6 * 32 + 64)
+
+
 def _load_unet_folder(path: str) -> UNet2DConditionModel:
     with open(os.path.join(path, "config.json")) as f:
         cfg = UNetConfig.from_dict(json.load(f))
@@ -142,3 +170,30 @@ def load_models(pretrained_model_name_or_path: str, scheduler_name: str, v2: boo
                                 f"use a local path or synthetic:<sd15|sd21|sdxl|tiny>")
     scheduler = create_noise_scheduler(scheduler_name, prediction_type="v_prediction" if v_pred else "epsilon")
     return tokenizer, text_encoder, unet, scheduler
+
+
+def load_models_xl(pretrained_model_name_or_path: str, scheduler_name: str, weight_dtype: torch.dtype = torch.float32):
+    """model_util.py:205-227: returns ([tokenizer, tokenizer_2], [text_encoder, text_encoder_2], unet, scheduler)."""
+    p = pretrained_model_name_or_path
+    if p.startswith("synthetic:"):
+        kind = p.split(":", 1)[1]
+        cfg = tiny_xl_config() if kind in ("tiny_xl", "tinyxl") else SYNTHETIC[kind]()
+        if cfg.addition_embed_type != "text_time":
+            raise ValueError(f"{p} is not an SDXL-style architecture")
+        unet = init_synthetic_(UNet2DConditionModel(cfg), 1234)
+        pooled = cfg.projection_class_embeddings_input_dim - 6 * cfg.addition_time_embed_dim
+        d1 = cfg.cross_attention_dim * 3 // 8
+        d2 = cfg.cross_attention_dim - d1           # 768 + 1280 = 2048 for SDXL
+        tokenizers = [SyntheticTokenizer(), SyntheticTokenizer()]
+        text_encoders = [SyntheticTextEncoderXL(d1, pooled), SyntheticTextEncoderXL(d2, pooled)]
+    elif os.path.isdir(p):
+        from transformers import CLIPTextModel, CLIPTextModelWithProjection, CLIPTokenizer
+        tokenizers = [CLIPTokenizer.from_pretrained(p, subfolder="tokenizer"),
+                      CLIPTokenizer.from_pretrained(p, subfolder="tokenizer_2", pad_token_id=0)]
+        text_encoders = [CLIPTextModel.from_pretrained(p, subfolder="text_encoder", torch_dtype=weight_dtype),
+                         CLIPTextModelWithProjection.from_pretrained(p, subfolder="text_encoder_2",
+                                                                     torch_dtype=weight_dtype)]
+        unet = _load_unet_folder(os.path.join(p, "unet")).to(weight_dtype)
+    else:
+        raise FileNotFoundError(f"{p}: not a local diffusers folder; use a local path or synthetic:<sdxl|tiny_xl>")
+    return tokenizers, text_encoders, unet, create_noise_scheduler(scheduler_name)

@@ -67,9 +67,10 @@ def _fn(name: str):
 
 class Op:
     """One enqueue-only C-ABI call: ``fn(*args, stream)``."""
-    __slots__ = ("name", "fn", "args", "keep")
+    __slots__ = ("name", "fn", "args", "keep", "tag")
 
     def __init__(self, name: str, args: tuple, keep=None):
+        self.tag = None   # plan builders label ops (e.g. "ctx": depends only on the prompt embeddings)
         self.name = name
         self.fn = _fn(name)
         self.args = args

@@ -86,23 +86,53 @@ class FusedStep:
         st = self._state.get(key)
         if st is None:
             plan = self.unet.prepare((2 * bs, 4, h, w), lora_on=True)
-            st = dict(plan=plan,
+            # the three LoRA-off predictions (positive / neutral / unconditional) run as ONE forward-only pass of
+            # batch 3 x 2bs: same arithmetic per sample (GroupNorm / attention are per sample), three times
+            # the rows per GEMM, a third of the launches
+            fplan = self.unet.engine().plan(6 * bs, h, w, need_bwd=False)
+            st = dict(plan=plan, fplan=fplan,
                       x=torch.zeros(bs, 4, h, w, dtype=torch.float32, device=self.dev),
-                      preds={n: torch.zeros_like(plan.pred) for n in ("positive", "neutral", "unconditional")},
+                      preds={n: fplan.pred[2 * bs * i:2 * bs * (i + 1)]
+                             for i, n in enumerate(("positive", "neutral", "unconditional"))},
                       half_n=bs * 4 * h * w)
             tail = [ops.cfg_ddim_step(plan.pred, st["x"], plan.x_in, self.coef, plan.t_idx, DENOISE_GUIDANCE,
                                       st["half_n"]),
                     ops.advance(plan.t_idx)]
-            plan.lists["denoise"] = plan.lists["fwd_on"] + tail
+            # cross-attention K/V (+ their LoRA down projections) depend only on the prompt embeddings: the k
+            # denoising passes of a step share one evaluation ("ctx_on"), the per-pass list skips those ops
+            plan.lists["ctx_on"] = [op for op in plan.lists["fwd_on"] if op.tag == "ctx"]
+            plan.lists["denoise"] = [op for op in plan.lists["fwd_on"] if op.tag != "ctx"] + tail
             self._state[key] = st
         return st
+
+    @staticmethod
+    def _text(e):      # SD1/2: a tensor; SDXL: PromptEmbedsXL(text_embeds, pooled_embeds)
+        return e.text_embeds if hasattr(e, "text_embeds") else e
 
     def _ctx(self, pair: PromptEmbedsPair, which: str, bs: int) -> torch.Tensor:
         key = (id(pair), which, bs)
         c = self._ctx_cache.get(key)
         if c is None:
-            c = train_util.concat_embeddings(pair.unconditional, getattr(pair, which), bs)
+            c = train_util.concat_embeddings(self._text(pair.unconditional), self._text(getattr(pair, which)), bs)
             c = c.to(self.dev, torch.bfloat16).contiguous()
+            self._ctx_cache[key] = c
+        return c
+
+    def _pooled(self, pair: PromptEmbedsPair, which: str, bs: int) -> torch.Tensor:
+        """SDXL add_text_embeddings = concat(uncond.pooled, cond.pooled) (train_lora_xl.py:214-218)."""
+        key = (id(pair), "pooled." + which, bs)
+        c = self._ctx_cache.get(key)
+        if c is None:
+            c = train_util.concat_embeddings(pair.unconditional.pooled_embeds, getattr(pair, which).pooled_embeds, bs)
+            c = c.to(self.dev, torch.bfloat16).contiguous()
+            self._ctx_cache[key] = c
+        return c
+
+    def _ctx3(self, pair: PromptEmbedsPair, bs: int) -> torch.Tensor:
+        key = (id(pair), "frozen3", bs)
+        c = self._ctx_cache.get(key)
+        if c is None:
+            c = torch.cat([self._ctx(pair, w, bs) for w in ("positive", "neutral", "unconditional")]).contiguous()
             self._ctx_cache[key] = c
         return c
 
@@ -110,9 +140,11 @@ class FusedStep:
         self.unet._run(plan, which)
 
     @torch.no_grad()
-    def step(self, pair: PromptEmbedsPair, timesteps_to: int, latents: torch.Tensor, lr: Optional[float] = None):
+    def step(self, pair: PromptEmbedsPair, timesteps_to: int, latents: torch.Tensor, lr: Optional[float] = None,
+             add_time_ids: Optional[torch.Tensor] = None):
         """``latents``: (bs,4,h,w) initial noise (any device / dtype), as returned by
-        ``train_util.get_initial_latents``.  Returns the loss as a 1-element device tensor."""
+        ``train_util.get_initial_latents``.  SDXL: ``add_time_ids`` = ``train_util.get_add_time_ids(...)`` (1,6).
+        Returns the loss as a 1-element device tensor."""
         net, unet = self.net, self.unet
         bs, _, h, w = latents.shape
         st = self._bucket(bs, h, w)
@@ -126,8 +158,14 @@ class FusedStep:
         x.copy_(latents.to(self.dev, torch.float32))
         plan.x_in.copy_(torch.cat([x, x]).to(torch.bfloat16))
         plan.ctx.copy_(self._ctx(pair, "target", bs))
+        xl = self.unet.cfg.addition_embed_type == "text_time"
+        if xl:
+            ids = add_time_ids.reshape(1, 6).to(self.dev, torch.float32)
+            plan.time_ids.copy_(ids.repeat(2 * bs, 1).reshape(-1))
+            plan.text_embeds.copy_(self._pooled(pair, "target", bs))
         plan.t_table[:n].copy_(self.ts_f)
         plan.t_idx.zero_()
+        self._run(plan, "ctx_on")
         for _ in range(k):
             self._run(plan, "denoise")
         # 2. frozen predictions at the "current" timestep (train_lora.py:195-237)
@@ -135,10 +173,15 @@ class FusedStep:
         plan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])
         plan.t_idx.copy_(self.slot_idx)
         net.multiplier = 0
-        for which in ("positive", "neutral", "unconditional"):
-            plan.ctx.copy_(self._ctx(pair, which, bs))
-            self._run(plan, "fwd_off")
-            st["preds"][which].copy_(plan.pred)
+        fplan = st["fplan"]
+        fplan.x_in.copy_(plan.x_in.repeat(3, 1, 1, 1))
+        fplan.ctx.copy_(self._ctx3(pair, bs))
+        if xl:
+            fplan.time_ids.copy_(ids.repeat(6 * bs, 1).reshape(-1))
+            fplan.text_embeds.copy_(torch.cat([self._pooled(pair, w_, bs) for w_ in ("positive", "neutral", "unconditional")]))
+        fplan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])
+        fplan.t_idx.copy_(self.slot_idx)
+        self._run(fplan, "fwd_off")
         # 3. target prediction with LoRA on; activations stay resident for the backward
         net.multiplier = 1.0
         plan.ctx.copy_(self._ctx(pair, "target", bs))
@@ -183,9 +226,9 @@ def _parse_optimizer_args(s: str) -> dict:
 
 
 def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[torch.device] = None,
-          use_graphs: bool = True, progress: bool = True):
-    """Reference entry point ``train(config, prompts)`` (train_lora.py:34).  Extra keyword
-    arguments only select the device and execution mode."""
+          use_graphs: bool = True, progress: bool = True, xl: bool = False):
+    """Reference entry point ``train(config, prompts)`` (train_lora.py:34; ``xl=True``: train_lora_xl.py:40).
+    Extra keyword arguments only select the device and execution mode."""
     rank, world, local = init_distributed()
     if device is None:
         device = torch.device(f"cuda:{local}" if torch.cuda.is_available() else "cpu")
@@ -208,11 +251,19 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
         print(f"note: the MI355X path computes in bf16 MFMA with fp32 accumulation; train.precision="
               f"{config.train.precision} only selects the dtype of the saved LoRA.")
 
-    tokenizer, text_encoder, unet, noise_scheduler = model_util.load_models(
-        config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler,
-        v2=config.pretrained_model.v2, v_pred=config.pretrained_model.v_pred)
-    text_encoder.to(device, dtype=torch.bfloat16)
-    text_encoder.eval()
+    if xl:
+        tokenizers, text_encoders, unet, noise_scheduler = model_util.load_models_xl(
+            config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler)
+        for text_encoder in text_encoders:
+            text_encoder.to(device, dtype=torch.bfloat16)
+            text_encoder.eval()
+        tokenizer = None
+    else:
+        tokenizer, text_encoder, unet, noise_scheduler = model_util.load_models(
+            config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler,
+            v2=config.pretrained_model.v2, v_pred=config.pretrained_model.v_pred)
+        text_encoder.to(device, dtype=torch.bfloat16)
+        text_encoder.eval()
     unet.to(device, dtype=torch.bfloat16)
     unet.enable_xformers_memory_efficient_attention()
     unet.requires_grad_(False)
@@ -248,11 +299,14 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
             print(settings)
             for prompt in [settings.target, settings.positive, settings.neutral, settings.unconditional]:
                 if cache[prompt] is None:
-                    cache[prompt] = train_util.encode_prompts(tokenizer, text_encoder, [prompt])
+                    if xl:   # (text_embeds, pooled) -- the reference passes the tuple un-unpacked and crashes
+                        cache[prompt] = prompt_util.PromptEmbedsXL(
+                            *train_util.encode_prompts_xl(tokenizers, text_encoders, [prompt], num_images_per_prompt=1))
+                    else:
+                        cache[prompt] = train_util.encode_prompts(tokenizer, text_encoder, [prompt])
             prompt_pairs.append(PromptEmbedsPair(criteria, cache[settings.target], cache[settings.positive],
                                                  cache[settings.unconditional], cache[settings.neutral], settings))
-    del tokenizer
-    del text_encoder
+    tokenizer = text_encoder = tokenizers = text_encoders = None
     flush()
 
     it = range(config.train.iterations)
@@ -274,7 +328,8 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
             print("gudance_scale:", pair.guidance_scale, "resolution:", pair.resolution, "dynamic_resolution:",
                   pair.dynamic_resolution, (height, width), "batch_size:", pair.batch_size)
         latents = train_util.get_initial_latents(noise_scheduler, pair.batch_size, height, width, 1)
-        loss = fused.step(pair, timesteps_to, latents, lr=lr_scheduler.get_last_lr()[0])
+        add_time_ids = train_util.get_add_time_ids(height, width, dynamic_crops=pair.dynamic_crops) if xl else None
+        loss = fused.step(pair, timesteps_to, latents, lr=lr_scheduler.get_last_lr()[0], add_time_ids=add_time_ids)
         if pbar is not None and (i % 10 == 0 or config.logging.verbose):
             pbar.set_description(f"Loss*1k: {loss.item() * 1000:.4f}")
         if wandb is not None:
@@ -294,7 +349,7 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
     return network, (loss.item() if loss is not None else None)
 
 
-def main(args):
+def main(args, xl: bool = False):
     config = config_util.load_config_from_yaml(args.config_file)
     prompts = prompt_util.load_prompts_from_yaml(config.prompts_file)
-    train(config, prompts)
+    train(config, prompts, xl=xl)

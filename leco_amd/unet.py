@@ -337,7 +337,7 @@ class Engine:
         self.unet, self.cfg, self.device = unet, unet.cfg, device
         self.sites: Dict[str, GemmSite] = {}      # by site name
         self.leaf_site: Dict[str, Tuple[GemmSite, int]] = {}  # leaf qualified name -> (site, group)
-        self.plans: Dict[Tuple[int, int, int], Plan] = {}
+        self.plans: Dict[tuple, Plan] = {}
         self.network = None  # LoRANetwork (set by attach_lora)
         self.use_graphs = False
         # shared fp32 scratch for split-K partial slabs (all launches are stream-ordered)
@@ -467,17 +467,20 @@ class Engine:
         net._packed_version = net.version
 
     # ---- plan construction ---------------------------------------------------------------------
-    def plan(self, B: int, h: int, w: int) -> Plan:
-        key = (B, h, w)
+    def plan(self, B: int, h: int, w: int, need_bwd: bool = True) -> Plan:
+        """``need_bwd=False`` builds a forward-only plan (no gradient buffers): used for the batched
+        LoRA-off passes, which never run a backward."""
+        key = (B, h, w, need_bwd)
         if key not in self.plans:
-            self.plans[key] = PlanBuilder(self, B, h, w).build()
+            self.plans[key] = PlanBuilder(self, B, h, w, need_bwd).build()
         return self.plans[key]
 
 
 class PlanBuilder:
-    def __init__(self, eng: Engine, B: int, h: int, w: int):
+    def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True):
         self.eng, self.cfg, self.dev = eng, eng.cfg, eng.device
         self.B, self.h, self.w = B, h, w
+        self.need_bwd = need_bwd
         self.plan = Plan()
         self.f_on: List[ops.Op] = self.plan.fwd[True]
         self.f_off: List[ops.Op] = self.plan.fwd[False]
@@ -757,7 +760,12 @@ class PlanBuilder:
         h1 = self.gemm_fwd(S[bname + ".attn1.to_out.0"], a1, bname + ".h1", rows=rows, residual=hcur)
         l2 = self.layernorm(bname + ".norm2", h1, bname + ".l2")
         q2 = self.gemm_fwd(S[bname + ".attn2.to_q"], l2, bname + ".q2", rows=rows)
+        # K/V of cross-attention depend only on the prompt embeddings (and the LoRA weights): tag their ops
+        # so that callers replaying the same prompt (the k denoising passes of a step) can run them once
+        n_on, n_off = len(self.f_on), len(self.f_off)
         kv = self.gemm_fwd(S[bname + ".attn2.kv"], ctx, bname + ".kv", rows=ctx.rows)
+        for op in self.f_on[n_on:] + self.f_off[n_off:]:
+            op.tag = "ctx"
         a2 = self.attention(q2, kv, heads, hw, ctx.rows // self.B, bname + ".a2")
         h2 = self.gemm_fwd(S[bname + ".attn2.to_out.0"], a2, bname + ".h2", rows=rows, residual=h1)
         l3 = self.layernorm(bname + ".norm3", h2, bname + ".l3")
@@ -857,7 +865,7 @@ class PlanBuilder:
         self.both(ops.conv_out(nout.t, eng.conv_out_w, eng.conv_out_b, P.pred, B, h, w, ch[0], cfg.out_channels))
         P.final = nout
         # -- backward: conv_out dgrad seeds the tape
-        if nout.rg:
+        if nout.rg and self.need_bwd:
             dn = self.act("g.norm_out", B * h * w, ch[0])
             P.bwd.append(ops.conv_out_bwd(P.dpred, eng.conv_out_w, dn.t, B, h, w, ch[0], cfg.out_channels))
             nout.gparts.append(dn)
