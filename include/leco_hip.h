@@ -99,12 +99,6 @@ typedef struct leco_lora_site {
 
 int leco_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_stream_t stream);
 
-/* T[m][j] = sum_k X[m][k] * D[j][k], j < rp (32 or 64; D = the packed dn_s / up_t image, zero rows
- * beyond the true rank), bf16 out with row stride ldt.  Skinny MFMA kernel for the LoRA "down"
- * projection lora_down(x) (lora.py:104) and its backward twin U = dY * up. */
-int leco_lora_down(const void* x, int64_t ldx, const void* d, int64_t ldd, void* t, int64_t ldt,
-                   int32_t m, int32_t k, int32_t rp, leco_stream_t stream);
-
 /* G[j*g_sj + c*g_sc] += scale * sum_m P[m][p_off+j] * Q[m][q_off+c], j<r, c<cols (LoRA weight
  * gradients; fp32 atomics into the flat gradient slab).  P, Q bf16.  Replaces autograd's
  * wgrad of lora_down / lora_up (train_lora.py:279). */

@@ -351,49 +351,6 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const leco_lora_site* si
     }
 }
 
-// ---- LoRA down projection T[m][j] = sum_k X[m][k] * D[j][k] (j < rp = 32 or 64), bf16 out ------------------
-// Skinny GEMM (N = rp): one wave per 16 rows, MFMA operands straight from global memory (X is read once,
-// D is a few KB and stays in L1/L2), no LDS, no barriers.  Swapped operands: lane ends up with 4 consecutive j
-// of one row -> 8-byte stores.
-template <int RP>
-__global__ __launch_bounds__(256) void lora_down_kernel(const bf16_t* x, int64_t ldx, const bf16_t* d, int64_t ldd,
-                                                         bf16_t* t, int64_t ldt, int M, int K) {
-    constexpr int NF = RP / 16;
-    const int lane = lane_id();
-    const int fr = lane & 15, fg = lane >> 4;
-    const int row0 = ((int)blockIdx.x * 4 + ((int)threadIdx.x >> 6)) * 16;
-    if (row0 >= M) return;
-    const int m = row0 + fr;
-    const bool ok = m < M;
-    const bf16_t* xr = x + (int64_t)(ok ? m : 0) * ldx + fg * 8;
-    f32x4 acc[NF];
-#pragma unroll
-    for (int j = 0; j < NF; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    for (int k0 = 0; k0 < K; k0 += 128) {   // 4 MFMA k-steps per iteration: 4 independent X loads in flight
-        u32x4 xa[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) xa[u] = (ok && k0 + 32 * u < K) ? *(const u32x4*)(xr + k0 + 32 * u) : zero4;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (k0 + 32 * u < K) {
-#pragma unroll
-                for (int j = 0; j < NF; ++j) {
-                    const u32x4 df = *(const u32x4*)(d + (int64_t)(16 * j + fr) * ldd + k0 + 32 * u + fg * 8);
-                    acc[j] = mfma16(__builtin_bit_cast(bf16x8, df), __builtin_bit_cast(bf16x8, xa[u]), acc[j]);
-                }
-            }
-        }
-    }
-    if (ok) {
-#pragma unroll
-        for (int j = 0; j < NF; ++j) {
-            u32x2 o = {pack_bf2(acc[j][0], acc[j][1]), pack_bf2(acc[j][2], acc[j][3])};
-            *(u32x2*)(t + (int64_t)m * ldt + 16 * j + 4 * fg) = o;
-        }
-    }
-}
-
 // ---- LoRA weight gradients: G[j][c] += scale * sum_m P[m][j] Q[m][c] -----------------------------------
 // block = 256 threads; thread owns column c of a 256-wide column tile; blockIdx.y walks WG_ROWS-row slabs
 // of M (P slab staged in LDS as fp32); 8 independent Q loads in flight per thread.  r <= 16.
@@ -548,16 +505,3 @@ extern "C" int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_
     return check_launch("leco_lora_wgrad");
 }
 
-extern "C" int leco_lora_down(const void* x, int64_t ldx, const void* d, int64_t ldd, void* t, int64_t ldt,
-                              int32_t m, int32_t k, int32_t rp, leco_stream_t stream) {
-    if ((rp != 32 && rp != 64) || k % 32 || ldx % 8 || ldd % 8 || ldt % 4)
-        return fail(-EINVAL, "lora_down: rp=%d must be 32/64, k=%d %% 32 == 0, 16-byte aligned rows", rp, k);
-    const dim3 grid(cdiv(m, 64));
-    if (rp == 32)
-        hipLaunchKernelGGL((lora_down_kernel<32>), grid, dim3(256), 0, LECO_STREAM, (const bf16_t*)x, ldx,
-                           (const bf16_t*)d, ldd, (bf16_t*)t, ldt, m, k);
-    else
-        hipLaunchKernelGGL((lora_down_kernel<64>), grid, dim3(256), 0, LECO_STREAM, (const bf16_t*)x, ldx,
-                           (const bf16_t*)d, ldd, (bf16_t*)t, ldt, m, k);
-    return check_launch("leco_lora_down");
-}

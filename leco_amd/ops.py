@@ -42,7 +42,6 @@ _SIGS = {
     "leco_cast_f32_bf16": [_vp, _vp, _i64, _vp],
     "leco_memset": [_vp, _i32, _i64, _vp],
     "leco_lora_pack": [_vp, _i32, _vp],
-    "leco_lora_down": [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp],
     "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
 }
 _fn_cache = {}
@@ -208,7 +207,3 @@ def lora_wgrad(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale) -> Op:
     """p, q, g are raw device addresses (ints)."""
     return Op("leco_lora_wgrad", (p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale))
 
-
-def lora_down(x, ldx, d, ldd, t, ldt, m, k, rp) -> Op:
-    """x, d, t: tensors or raw device addresses."""
-    return Op("leco_lora_down", (ptr(x), ldx, ptr(d), ldd, ptr(t), ldt, m, k, rp))

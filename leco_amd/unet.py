@@ -551,12 +551,8 @@ class PlanBuilder:
             kw = dict(m=rows, n=lora.Rp, k=site.k, a_mode=amode, conv=conv)
             if len(xs) == 2:
                 kw.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
-            if amode == A_PLAIN and len(xs) == 1:
-                self.f_on.append(ops.Op("leco_lora_down", (a0, lda0, lora.dn_s.data_ptr(), site.k, T.ptr, T.ld, rows,
-                                                           site.k, lora.Rp), keep=(lora, xs, T)))
-            else:
-                g_t = gemm_args(a0, lora.dn_s, T.ptr, lda=lda0, ldc=T.ld, **kw)
-                self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T), ws=self.eng.workspace))
+            g_t = gemm_args(a0, lora.dn_s, T.ptr, lda=lda0, ldc=T.ld, **kw)
+            self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T), ws=self.eng.workspace))
             g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, a_ext=T.ptr, w_ext=lora.up_p, ext_k=lora.Rp,
                              ld_aext=T.ld, ld_wext=lora.Rp, **common)
             self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y), ws=self.eng.workspace))
@@ -580,8 +576,8 @@ class PlanBuilder:
         if lora is not None:
             net = self.eng.network
             U = self.act("g." + y.name + ".loraU", rows, lora.Rp)
-            out.append(ops.Op("leco_lora_down", (dy.ptr, dy.ld, lora.up_t.data_ptr(), site.n, U.ptr, U.ld, rows, site.n,
-                                                 lora.Rp), keep=(lora, dy, U)))
+            out.append(ops.gemm(gemm_args(dy.ptr, lora.up_t, U.ptr, m=rows, n=lora.Rp, k=site.n, lda=dy.ld, ldc=U.ld),
+                                keep=(lora, dy, U)))
             x0 = xs[0]
             gn = site.group_n
             for g, mod in enumerate(lora.mods):

@@ -322,16 +322,6 @@ def test_timestep_ddim_loss_adamw(dev):
     assert rel_err(pp.cpu(), pt.data) < 1e-5 and rel_err(sh.cpu(), pt.data) < TOLBF
 
 
-@pytest.mark.parametrize("M,K,Rp", [(70, 64, 32), (1000, 320, 32), (130, 1280, 64), (16, 96, 32)])
-def test_lora_down_skinny(dev, M, K, Rp):
-    torch.manual_seed(13)
-    x = torch.randn(M, K).to(bf).to(dev); d = (torch.randn(Rp, K) / K ** 0.5).to(bf).to(dev)
-    t = torch.zeros(M, Rp, dtype=bf, device=dev)
-    ops.lora_down(x, K, d, K, t, Rp, M, K, Rp).run()
-    _sync(dev)
-    assert rel_err(t, x.float() @ d.float().T) < TOLBF
-
-
 def test_lora_pack_forward_wgrad(dev):
     torch.manual_seed(10)
     r, K, N_, groups, M = 4, 64, 192, 3, 70
