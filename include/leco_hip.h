@@ -90,7 +90,8 @@ typedef struct leco_lora_site {
     const void* up[3];   /* bf16 */
     int32_t groups, r, k, n;
     float scale;         /* multiplier * alpha / r  (lora.py:87,105) */
-    int32_t _pad;
+    int32_t taps;        /* 0/1: Linear or 1x1 conv; 9: 3x3 conv LoRA (k = 9*Cin, lora_down is [r][Cin][3][3]):
+                            Rp = 64, dn_s[j][tap*Cin+c], dn_p[c][tap][j] = scale*down[j][c][8-tap] (dgrad operand) */
     void* dn_s;
     void* up_p;
     void* up_t;
@@ -115,6 +116,17 @@ int leco_gemm_tile(const leco_gemm_args* args, int tile, leco_stream_t stream);
  * need this to fill 256 CUs. */
 int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* workspace,
                  int64_t workspace_bytes, leco_stream_t stream);
+
+/* same with Q gathered like the A operand of a 3x3 conv (one call per tap; a_mode LECO_A_CONV3_S1/S2/UP2):
+ * the wgrad of a conv lora_down (c3lier, lora.py:72-81).  m = batch*h_out*w_out output rows. */
+int leco_lora_wgrad_conv(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj,
+                         int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale, int32_t a_mode,
+                         int32_t h_out, int32_t w_out, int32_t h_in, int32_t w_in, int32_t kh, int32_t kw,
+                         leco_stream_t stream);
+/* out[b][c] = sum of the rows_per_group rows of sample b of x[.][c] (fp32): gradient of the per-sample
+ * time-embedding bias added by ResnetBlock2D (needed only when time_emb_proj carries a LoRA). */
+int leco_rowgroup_sum(const void* x, int64_t ldx, float* out, int64_t ldo, int32_t groups,
+                      int32_t rows_per_group, int32_t cols, leco_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Normalisation (diffusers GroupNorm(32) in ResnetBlock2D / Transformer2DModel / conv_norm_out,

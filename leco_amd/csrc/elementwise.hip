@@ -315,18 +315,23 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* x, bf16
 // ---- LoRA operand packing (see leco_hip.h) -------------------------------------------------------------
 __global__ __launch_bounds__(256) void lora_pack_kernel(const leco_lora_site* sites) {
     const leco_lora_site s = sites[blockIdx.y];
-    const int R = s.groups * s.r, R16 = (R + 15) / 16 * 16, Rp = (R + 31) / 32 * 32;
-    const int gn = s.n / s.groups;
-    const int64_t n0 = (int64_t)R16 * s.k, n1 = (int64_t)s.n * Rp, n2 = (int64_t)R16 * s.n, n3 = (int64_t)s.k * Rp;
+    const bool conv = s.taps == 9;     // 3x3 conv LoRA: lora_down is [r][Cin][3][3] (lora.py:72-81)
+    const int R = s.groups * s.r, R16 = (R + 15) / 16 * 16, Rp = conv ? 64 : (R + 31) / 32 * 32;
+    const int gn = s.n / s.groups, cin = conv ? s.k / 9 : s.k;
+    const int rows_s = conv ? Rp : R16;   // conv sites use dn_s / up_t as GEMM weight operands of Rp rows
+    const int64_t n0 = (int64_t)rows_s * s.k, n1 = (int64_t)s.n * Rp, n2 = (int64_t)rows_s * s.n, n3 = (int64_t)s.k * Rp;
     bf16_t* dn_s = (bf16_t*)s.dn_s;
     bf16_t* up_p = (bf16_t*)s.up_p;
     bf16_t* up_t = (bf16_t*)s.up_t;
     bf16_t* dn_p = (bf16_t*)s.dn_p;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n0 + n1 + n2 + n3; e += (int64_t)gridDim.x * 256) {
-        if (e < n0) {  // dn_s[j][k] = down[g][jj][k]
+        if (e < n0) {  // dn_s[j][k]: linear k = column; conv k = tap * Cin + c  <-  down[j][c][tap]
             const int j = (int)(e / s.k), k = (int)(e - (int64_t)j * s.k);
             bf16_t val = 0;
-            if (j < R) val = ((const bf16_t*)s.down[j / s.r])[(int64_t)(j % s.r) * s.k + k];
+            if (j < R) {
+                const int src = conv ? (k % cin) * 9 + k / cin : k;
+                val = ((const bf16_t*)s.down[j / s.r])[(int64_t)(j % s.r) * s.k + src];
+            }
             dn_s[e] = val;
         } else if (e < n0 + n1) {  // up_p[n][j] = scale * up[g][n - g*gn][jj] if j in group(n)
             const int64_t t = e - n0;
@@ -341,11 +346,16 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const leco_lora_site* si
             bf16_t val = 0;
             if (j < R && j / s.r == g) val = ((const bf16_t*)s.up[g])[(int64_t)(n - g * gn) * s.r + (j % s.r)];
             up_t[t] = val;
-        } else {  // dn_p[k][j] = scale * down[g][jj][k]
+        } else {
+            // linear: dn_p[k][j] = scale * down[j][k]
+            // conv:   dn_p[c][tap'][j] = scale * down[j][c][8 - tap']  (flipped, in/out swapped: the dgrad operand)
             const int64_t t = e - n0 - n1 - n2;
-            const int k = (int)(t / Rp), j = (int)(t - (int64_t)k * Rp);
+            const int kk = (int)(t / Rp), j = (int)(t - (int64_t)kk * Rp);
             float val = 0.f;
-            if (j < R) val = s.scale * bf2f(((const bf16_t*)s.down[j / s.r])[(int64_t)(j % s.r) * s.k + k]);
+            if (j < R) {
+                const int src = conv ? (kk / 9) * 9 + (8 - kk % 9) : kk;
+                val = s.scale * bf2f(((const bf16_t*)s.down[j / s.r])[(int64_t)(j % s.r) * s.k + src]);
+            }
             dn_p[t] = f2bf(val);
         }
     }
@@ -355,11 +365,15 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const leco_lora_site* si
 // block = 256 threads; thread owns column c of a 256-wide column tile; blockIdx.y walks WG_ROWS-row slabs
 // of M (P slab staged in LDS as fp32); 8 independent Q loads in flight per thread.  r <= 16.
 constexpr int WG_ROWS = 128;
+struct WgradConv {   // a_mode == LECO_A_PLAIN: Q row = m.  Otherwise Q row = source pixel of output row m for tap (kh, kw)
+    int a_mode, h_out, w_out, h_in, w_in, kh, kw;
+};
 template <int R>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_t ldp, const bf16_t* Q, int64_t ldq,
                                                           float* G, int64_t g_sj, int64_t g_sc, int M, int r,
-                                                          int cols, float scale) {
+                                                          int cols, float scale, WgradConv cv) {
     __shared__ float sp[WG_ROWS * R];
+    __shared__ int srow[WG_ROWS];
     const int tid = (int)threadIdx.x;
     const int c = (int)blockIdx.x * 256 + tid;
     const int m0 = (int)blockIdx.y * WG_ROWS;
@@ -368,16 +382,36 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_
         const int mm = e / R, j = e - mm * R;
         sp[e] = (mm < rows && j < r) ? bf2f(P[(int64_t)(m0 + mm) * ldp + j]) : 0.f;
     }
+    if (tid < WG_ROWS) {   // Q row feeding output row m0 + tid (-1: padding / outside)
+        int src = -1;
+        if (tid < rows) {
+            const int m = m0 + tid;
+            if (cv.a_mode == LECO_A_PLAIN) {
+                src = m;
+            } else {
+                const int hw = cv.h_out * cv.w_out;
+                const int b = m / hw, rem = m - b * hw, oy = rem / cv.w_out, ox = rem - oy * cv.w_out;
+                const int sy = cv.a_mode == LECO_A_CONV3_S2 ? 2 : 1;
+                const int dv = (cv.a_mode == LECO_A_CONV3_UP2) ? 1 : 0;
+                const int uy = oy * sy + cv.kh - 1, ux = ox * sy + cv.kw - 1;
+                if (uy >= 0 && uy < (cv.h_in << dv) && ux >= 0 && ux < (cv.w_in << dv))
+                    src = (b * cv.h_in + (uy >> dv)) * cv.w_in + (ux >> dv);
+            }
+        }
+        srow[tid] = src;
+    }
     __syncthreads();
     if (c >= cols) return;
     float acc[R];
 #pragma unroll
     for (int j = 0; j < R; ++j) acc[j] = 0.f;
-    const bf16_t* qc = Q + (int64_t)m0 * ldq + c;
     for (int mm = 0; mm < WG_ROWS; mm += 8) {   // rows beyond `rows` contribute 0 through sp
         float q[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) q[u] = (mm + u < rows) ? bf2f(qc[(int64_t)(mm + u) * ldq]) : 0.f;
+        for (int u = 0; u < 8; ++u) {
+            const int sr = srow[mm + u];
+            q[u] = sr >= 0 ? bf2f(Q[(int64_t)sr * ldq + c]) : 0.f;
+        }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -386,6 +420,23 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_
 #pragma unroll
     for (int j = 0; j < R; ++j)
         if (j < r) atomicAdd(&G[j * g_sj + c * g_sc], acc[j] * scale);
+}
+
+// ---- per-sample column sums: out[b][c] = sum over the rows of sample b of x[row][c] (fp32 out; d time-embedding bias)
+__global__ __launch_bounds__(256) void rowgroup_sum_kernel(const bf16_t* x, int64_t ldx, float* out, int64_t ldo,
+                                                            int rows_per_group, int cols) {
+    const int c = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int b = (int)blockIdx.y;
+    if (c >= cols) return;
+    const bf16_t* src = x + (int64_t)b * rows_per_group * ldx + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int r = 0;
+    for (; r + 4 <= rows_per_group; r += 4) {
+        a0 += bf2f(src[(int64_t)r * ldx]); a1 += bf2f(src[(int64_t)(r + 1) * ldx]);
+        a2 += bf2f(src[(int64_t)(r + 2) * ldx]); a3 += bf2f(src[(int64_t)(r + 3) * ldx]);
+    }
+    for (; r < rows_per_group; ++r) a0 += bf2f(src[(int64_t)r * ldx]);
+    out[(int64_t)b * ldo + c] = (a0 + a1) + (a2 + a3);
 }
 }  // namespace
 }  // namespace leco
@@ -488,20 +539,38 @@ extern "C" int leco_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_
     hipLaunchKernelGGL(lora_pack_kernel, dim3(64, (unsigned)nsites), dim3(256), 0, LECO_STREAM, sites);
     return check_launch("leco_lora_pack");
 }
-extern "C" int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj,
-                               int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
-                               leco_stream_t stream) {
+static int wgrad_launch(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj, int64_t g_sc,
+                        int32_t m, int32_t r, int32_t cols, float scale, WgradConv cv, hipStream_t s) {
     if (r <= 0 || r > 16) return fail(-EINVAL, "lora_wgrad: rank %d unsupported (1..16)", r);
     const dim3 grid(cdiv(cols, 256), cdiv(m, WG_ROWS));
     if (r <= 4)
-        hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, LECO_STREAM, (const bf16_t*)p, ldp,
-                           (const bf16_t*)q, ldq, g, g_sj, g_sc, m, r, cols, scale);
+        hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, (const bf16_t*)p, ldp, (const bf16_t*)q, ldq, g,
+                           g_sj, g_sc, m, r, cols, scale, cv);
     else if (r <= 8)
-        hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, LECO_STREAM, (const bf16_t*)p, ldp,
-                           (const bf16_t*)q, ldq, g, g_sj, g_sc, m, r, cols, scale);
+        hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, (const bf16_t*)p, ldp, (const bf16_t*)q, ldq, g,
+                           g_sj, g_sc, m, r, cols, scale, cv);
     else
-        hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, LECO_STREAM, (const bf16_t*)p, ldp,
-                           (const bf16_t*)q, ldq, g, g_sj, g_sc, m, r, cols, scale);
+        hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, (const bf16_t*)p, ldp, (const bf16_t*)q, ldq, g,
+                           g_sj, g_sc, m, r, cols, scale, cv);
     return check_launch("leco_lora_wgrad");
 }
-
+extern "C" int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj,
+                               int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
+                               leco_stream_t stream) {
+    return wgrad_launch(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, WgradConv{LECO_A_PLAIN, 0, 0, 0, 0, 0, 0},
+                        LECO_STREAM);
+}
+extern "C" int leco_lora_wgrad_conv(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj,
+                                    int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale, int32_t a_mode,
+                                    int32_t h_out, int32_t w_out, int32_t h_in, int32_t w_in, int32_t kh, int32_t kw,
+                                    leco_stream_t stream) {
+    if (a_mode < LECO_A_CONV3_S1 || a_mode > LECO_A_CONV3_UP2) return fail(-EINVAL, "lora_wgrad_conv: bad a_mode %d", a_mode);
+    return wgrad_launch(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, WgradConv{a_mode, h_out, w_out, h_in, w_in, kh, kw},
+                        LECO_STREAM);
+}
+extern "C" int leco_rowgroup_sum(const void* x, int64_t ldx, float* out, int64_t ldo, int32_t groups,
+                                 int32_t rows_per_group, int32_t cols, leco_stream_t stream) {
+    hipLaunchKernelGGL(rowgroup_sum_kernel, dim3(cdiv(cols, 256), groups), dim3(256), 0, LECO_STREAM, (const bf16_t*)x, ldx,
+                       out, ldo, rows_per_group, cols);
+    return check_launch("leco_rowgroup_sum");
+}

@@ -41,7 +41,7 @@ class LoraSite(C.Structure):
     _fields_ = [
         ("down", C.c_void_p * 3), ("up", C.c_void_p * 3),
         ("groups", C.c_int32), ("r", C.c_int32), ("k", C.c_int32), ("n", C.c_int32),
-        ("scale", C.c_float), ("_pad", C.c_int32),
+        ("scale", C.c_float), ("taps", C.c_int32),
         ("dn_s", C.c_void_p), ("up_p", C.c_void_p), ("up_t", C.c_void_p), ("dn_p", C.c_void_p),
     ]
 

@@ -266,7 +266,7 @@ class LoraSiteState:
         g = len(mods)
         self.R = g * r
         self.R16 = (self.R + 15) // 16 * 16
-        self.Rp = (self.R + 31) // 32 * 32
+        self.Rp = 64 if site.conv3 else (self.R + 31) // 32 * 32
         if self.Rp > 64:
             raise ValueError(f"LoRA rank {r} x {g} fused groups exceeds the 64-wide K-extension tile")
         K, N = site.lora_k, site.n
@@ -339,6 +339,7 @@ class Engine:
         self.leaf_site: Dict[str, Tuple[GemmSite, int]] = {}  # leaf qualified name -> (site, group)
         self.plans: Dict[tuple, Plan] = {}
         self.network = None  # LoRANetwork (set by attach_lora)
+        self.temb_lora_sites: Dict[str, GemmSite] = {}
         self.use_graphs = False
         # shared fp32 scratch for split-K partial slabs (all launches are stream-ordered)
         self.workspace = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=device)
@@ -411,14 +412,21 @@ class Engine:
     def attach_lora(self, network) -> None:
         """Bind a LoRANetwork: every LoRA module is matched to (site, group) by its leaf name."""
         self.network = network
+        self.temb_lora_sites: Dict[str, GemmSite] = {}
         per_site: Dict[str, list] = {}
         for lora in network.unet_loras:
             if lora.leaf_name not in self.leaf_site:
                 raise KeyError(f"LoRA target {lora.leaf_name} has no GEMM site")
             site, g = self.leaf_site[lora.leaf_name]
-            if site.conv3 or site.name == "time_emb_proj_all":
-                raise NotImplementedError(
-                    f"LoRA on {lora.leaf_name}: conv3x3 / time_emb_proj LoRA (c3lier) is not wired yet")
+            if site.name == "time_emb_proj_all":
+                # c3lier: a LoRA on ResnetBlock2D.time_emb_proj.  The fused 22-way projection cannot carry 22
+                # independent low-rank terms in one 64-wide K-extension, so those resnets get their own small GEMM.
+                rname = lora.leaf_name[:-len(".time_emb_proj")]
+                m = self.named[rname]
+                site = self._site(lora.leaf_name, [(lora.leaf_name, m.time_emb_proj)])
+                site.bias = (m.time_emb_proj.bias.detach().float() + m.conv1.bias.detach().float()).to(self.device)
+                self.temb_lora_sites[rname] = site
+                g = 0
             per_site.setdefault(site.name, [None] * len(site.leaf_names))[g] = lora
         self.lora_sites: List[GemmSite] = []
         for name, mods in per_site.items():
@@ -448,6 +456,7 @@ class Engine:
                     d.up[g] = net.shadow.data_ptr() + mod.up_off * 2
             d.groups, d.r, d.k, d.n = len(st.mods), st.r, site.k, site.n
             d.scale = 0.0  # filled by refresh_lora
+            d.taps = 9 if site.conv3 else 1
             d.dn_s, d.up_p, d.up_t, d.dn_p = st.dn_s.data_ptr(), st.up_p.data_ptr(), st.up_t.data_ptr(), st.dn_p.data_ptr()
         self._pack_host = sites
         self._pack_dev = torch.zeros(C.sizeof(sites), dtype=torch.uint8, device=self.device)
@@ -527,7 +536,7 @@ class PlanBuilder:
     def gemm_fwd(self, site: GemmSite, x: Union[TRef, Tuple[TRef, TRef]], name: str, *, conv=None, amode=A_PLAIN,
                  rows: int, residual: Optional[TRef] = None, rowbias=None, rows_per_group=0, ld_rowbias=0,
                  act=ACT_NONE, out: Optional[TRef] = None, out_f32: Optional[torch.Tensor] = None,
-                 bias="site") -> TRef:
+                 bias="site", ldc32_override: int = 0) -> TRef:
         xs = x if isinstance(x, tuple) else (x,)
         rg_in = any(t.rg for t in xs) or (residual is not None and residual.rg)
         lora = site.lora
@@ -537,7 +546,7 @@ class PlanBuilder:
                       rows_per_group=rows_per_group, ld_rowbias=ld_rowbias,
                       residual=residual.ptr if residual is not None else None,
                       ldr=residual.ld if residual is not None else 0, act=act, out_f32=out_f32,
-                      ldc32=(out_f32.shape[-1] if out_f32 is not None else 0))
+                      ldc32=(ldc32_override or (out_f32.shape[-1] if out_f32 is not None else 0)))
         if len(xs) == 2:
             common.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
         a0, lda0 = xs[0].ptr, xs[0].ld
@@ -546,8 +555,9 @@ class PlanBuilder:
         g_off = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, **common)
         self.f_off.append(ops.gemm(g_off, keep=(site, xs, residual, y), ws=self.eng.workspace))
         T = None
+        self._last_T = None
         if lora is not None:
-            T = self.act(name + ".loraT", rows, lora.Rp)
+            T = self._last_T = self.act(name + ".loraT", rows, lora.Rp)
             kw = dict(m=rows, n=lora.Rp, k=site.k, a_mode=amode, conv=conv)
             if len(xs) == 2:
                 kw.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
@@ -564,6 +574,38 @@ class PlanBuilder:
                 self.tape.append(lambda: self.gemm_bwd(site, xs, y, T, conv, amode, rows, residual))
         return y
 
+    def lora_bwd(self, site: GemmSite, xs, dy: TRef, T: TRef, conv, amode, rows, name: str) -> TRef:
+        """U = dY * up (per group) and the LoRA weight gradients of one site; returns U [rows][Rp]."""
+        out, lora, net = self.plan.bwd, site.lora, self.eng.network
+        U = self.act("g." + name + ".loraU", rows, lora.Rp)
+        out.append(ops.gemm(gemm_args(dy.ptr, lora.up_t, U.ptr, m=rows, n=lora.Rp, k=site.n, lda=dy.ld, ldc=U.ld),
+                            keep=(lora, dy, U)))
+        gn, r = site.group_n, lora.r
+        cin_total = sum(t.cols for t in xs)
+        for g, mod in enumerate(lora.mods):
+            if mod is None:
+                continue
+            s = float(mod.scale)  # multiplier == 1 inside the training pass
+            gdown = net.grad.data_ptr() + 4 * mod.down_off
+            c_off = 0
+            for t in xs:
+                if amode == A_PLAIN:
+                    # d lora_down[j][c_off + c] = s * sum_m U[m][g r + j] x[m][c]
+                    out.append(ops.lora_wgrad(U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * c_off, cin_total, 1, rows,
+                                              r, t.cols, s))
+                else:
+                    # conv lora_down [r][Cin][3][3]: one gathered product per tap
+                    _, ho, wo, hi, wi = conv
+                    for tap in range(9):
+                        out.append(ops.Op("leco_lora_wgrad_conv", (
+                            U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * (c_off * 9 + tap), cin_total * 9, 9, rows, r,
+                            t.cols, s, amode, ho, wo, hi, wi, tap // 3, tap % 3), keep=(U, t)))
+                c_off += t.cols
+            # d lora_up[n][j] = s * sum_m dy[m][g gn + n] T[m][g r + j]
+            out.append(ops.lora_wgrad(T.ptr + 2 * g * r, T.ld, dy.ptr + 2 * g * gn, dy.ld,
+                                      net.grad.data_ptr() + 4 * mod.up_off, 1, r, rows, r, gn, s))
+        return U
+
     def gemm_bwd(self, site: GemmSite, xs, y: TRef, T: Optional[TRef], conv, amode, rows, residual):
         out = self.plan.bwd
         dy = self.total_grad(y, out)
@@ -572,26 +614,7 @@ class PlanBuilder:
         if residual is not None and residual.rg:
             residual.gparts.append(dy)
         lora = site.lora
-        U = None
-        if lora is not None:
-            net = self.eng.network
-            U = self.act("g." + y.name + ".loraU", rows, lora.Rp)
-            out.append(ops.gemm(gemm_args(dy.ptr, lora.up_t, U.ptr, m=rows, n=lora.Rp, k=site.n, lda=dy.ld, ldc=U.ld),
-                                keep=(lora, dy, U)))
-            x0 = xs[0]
-            gn = site.group_n
-            for g, mod in enumerate(lora.mods):
-                if mod is None:
-                    continue
-                s = float(mod.scale)  # multiplier == 1 inside the training pass
-                r = lora.r
-                # d lora_down[j][k] = s * sum_m U[m][g r + j] x[m][k]
-                assert len(xs) == 1 and amode == A_PLAIN
-                out.append(ops.lora_wgrad(U.ptr + 2 * g * r, U.ld, x0.ptr, x0.ld, net.grad.data_ptr() + 4 * mod.down_off,
-                                          site.k, 1, rows, r, site.k, s))
-                # d lora_up[n][j] = s * sum_m dy[m][g gn + n] T[m][g r + j]
-                out.append(ops.lora_wgrad(T.ptr + 2 * g * r, T.ld, dy.ptr + 2 * g * gn, dy.ld,
-                                          net.grad.data_ptr() + 4 * mod.up_off, 1, r, rows, r, gn, s))
+        U = self.lora_bwd(site, xs, dy, T, conv, amode, rows, y.name) if lora is not None else None
         need = [t for t in xs if t.rg]
         if not need:
             return
@@ -615,6 +638,12 @@ class PlanBuilder:
             g = gemm_args(dy.ptr, site.wt, dxa.ptr, m=drows, n=kin, k=9 * site.n, lda=dy.ld, ldc=dxa.ld, a_mode=dmode,
                           conv=dconv)
             out.append(ops.gemm(g, keep=(site, dy, dxa), ws=self.eng.workspace))
+            if lora is not None:
+                # conv LoRA: dX += conv_dgrad(U, scale * lora_down) -- U is a 64-channel image, the packed dn_p is
+                # the flipped / in-out-swapped [Cin][3][3][64] operand; accumulated through the residual epilogue
+                g2 = gemm_args(U.ptr, lora.dn_p, dxa.ptr, m=drows, n=kin, k=9 * lora.Rp, lda=U.ld, ldc=dxa.ld,
+                               a_mode=dmode, conv=dconv, residual=dxa.ptr, ldr=dxa.ld)
+                out.append(ops.gemm(g2, keep=(lora, U, dxa), ws=self.eng.workspace))
             if amode == A_CONV3_UP2:
                 dx = self.act("g." + y.name + ".dxlo", B * hi * wi, kin)
                 out.append(ops.upsample2x_bwd(dxa.t, dx.t, B, hi, wi, kin))
@@ -735,8 +764,31 @@ class PlanBuilder:
         n1 = self.groupnorm(rname + ".norm1", x, hw, ACT_SILU, self.cfg.norm_eps, rname + ".n1")
         off = eng.temb_off[rname]
         temb = self.temb_all  # fp32 [B][temb_total]
+        tsite = eng.temb_lora_sites.get(rname)
+        temb_T = None
+        if tsite is not None:
+            # c3lier: this resnet's time_emb_proj has a LoRA -> its slice of the time-embedding bias is recomputed
+            # (after the fused projection) by its own GEMM with the K-extension tile
+            cout = m.out_channels
+            n_on = len(self.f_on)
+            self.gemm_fwd(tsite, self.emb_silu, rname + ".temb", rows=self.B,
+                          out_f32=temb[:, off:off + cout], ldc32_override=eng.temb_total)
+            temb_T = self._last_T
         h1 = self.gemm_fwd(eng.sites[rname + ".conv1"], n1, rname + ".h1", conv=conv, amode=A_CONV3_S1, rows=rows,
                            rowbias=temb.data_ptr() + 4 * off, rows_per_group=hw, ld_rowbias=eng.temb_total, bias=None)
+        if tsite is not None and h1.rg:
+            def temb_bwd():
+                out = self.plan.bwd
+                dh = self.total_grad(h1, out)
+                if dh is None:
+                    return
+                cout = m.out_channels
+                dsum = self.buf("g." + rname + ".dtemb32", (self.B, cout), torch.float32)
+                dtb = self.act("g." + rname + ".dtemb", self.B, cout)
+                out.append(ops.Op("leco_rowgroup_sum", (dh.ptr, dh.ld, dsum.data_ptr(), cout, self.B, hw, cout), keep=(dh, dsum)))
+                out.append(ops.cast_f32_bf16(dsum, dtb.t, self.B * cout))
+                self.lora_bwd(tsite, (self.emb_silu,), dtb, temb_T, None, A_PLAIN, self.B, rname + ".temb")
+            self.tape.append(temb_bwd)
         n2 = self.groupnorm(rname + ".norm2", h1, hw, ACT_SILU, self.cfg.norm_eps, rname + ".n2")
         if m.conv_shortcut is not None:
             sc = self.gemm_fwd(eng.sites[rname + ".conv_shortcut"], x, rname + ".sc", rows=rows)
@@ -820,6 +872,7 @@ class PlanBuilder:
             te = TRef(P.text_embeds, B, P.text_embeds.shape[1], name="text_embeds")
             a1 = self.gemm_fwd(S["add_embedding.linear_1"], (te, asin), "add_e1", rows=B, act=ACT_SILU)
             emb_silu = self.gemm_fwd(S["add_embedding.linear_2"], a1, "t_emb_silu", rows=B, residual=emb, act=ACT_SILU)
+        self.emb_silu = emb_silu
         self.temb_all = self.buf("temb_all", (B, eng.temb_total), torch.float32)
         self.gemm_fwd(S["time_emb_proj_all"], emb_silu, "temb_all_g", rows=B, out_f32=self.temb_all)
         # -- conv_in

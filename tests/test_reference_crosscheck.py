@@ -67,6 +67,18 @@ def test_lora_census_full_size(ref, arch, n_mods, n_params, rank):
     assert len(net.unet_loras) == n_mods and net.numel == n_params
 
 
+def test_c3lier_census_sd15(ref):
+    """SD1.5 c3lier: 278 modules / 8 406 528 parameters at rank 8."""
+    from leco_amd import model_util
+    from leco_amd.lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV, LoRANetwork
+    from leco_amd.unet import UNet2DConditionModel
+    with torch.device("meta"):
+        m = UNet2DConditionModel(model_util.SYNTHETIC["sd15"]())
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = LoRANetwork(m, rank=8, target_replace_modules=list(DEFAULT_TARGET_REPLACE) + list(UNET_TARGET_REPLACE_MODULE_CONV))
+    assert len(net.unet_loras) == 278 and net.numel == 8406528
+
+
 def test_training_method_filter_quirk_is_reproduced(ref):
     """lora.py:169-187 filters on the OUTER module name, so selfattn / xattn select nothing (SURVEY F-2)."""
     from leco_amd import model_util

@@ -172,6 +172,38 @@ def test_fused_step_matches_reference_golden(dev):
     assert torch.equal(net.shadow[:net.numel].cpu(), net.slab.detach()[:net.numel].to(bf).cpu())
 
 
+def test_c3lier_conv_and_time_emb_lora_forward_backward(dev):
+    """network.type = c3lier (BASELINE config 4): LoRA on ResnetBlock2D conv1/conv2/conv_shortcut/time_emb_proj and the
+    Down/Upsample2D convs (3x3 conv lora_down, stride 2 and nearest-2x variants included) + the transformer linears."""
+    from leco_amd.lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV
+    ref = oracle_unet()
+    m = hip_unet(dev)
+    targets = list(DEFAULT_TARGET_REPLACE) + list(UNET_TARGET_REPLACE_MODULE_CONV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rnet = lora_ref.LoRANetworkRef(ref, rank=8, targets=targets)
+        net = LoRANetwork(m, rank=8, target_replace_modules=targets)
+    assert [l.lora_name for l in rnet.unet_loras] == [l.lora_name for l in net.unet_loras] and len(net.unet_loras) == 177
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for rl, l in zip(rnet.unet_loras, net.unet_loras):
+            d = (torch.randn(rl.lora_down.weight.shape, generator=g) * 0.05).to(bf).float()
+            u = (torch.randn(rl.lora_up.weight.shape, generator=g) * 0.05).to(bf).float()
+            rl.lora_down.weight.copy_(d); rl.lora_up.weight.copy_(u)
+            l.lora_down.weight.copy_(d); l.lora_up.weight.copy_(u)
+    net.mark_updated()
+    x = torch.randn(2, 4, 16, 16, generator=g).to(bf); ctx = torch.randn(2, 77, 64, generator=g).to(bf)
+    tgt = torch.randn(2, 4, 16, 16, generator=g)
+    with net:
+        y = m(x.to(dev), torch.tensor(500), encoder_hidden_states=ctx.to(dev)).sample
+    ((y.float() - tgt.to(dev)) ** 2).mean().backward()
+    with rnet:
+        yr = ref(x.float(), torch.tensor(500), encoder_hidden_states=ctx.float()).sample
+    ((yr - tgt) ** 2).mean().backward()
+    assert rel_err(y.float().cpu(), yr.detach()) < 3e-2
+    gr = torch.cat([p.grad.reshape(-1) for l in rnet.unet_loras for p in (l.lora_down.weight, l.lora_up.weight)])
+    assert rel_err(flat(net, "grad"), gr) < 6e-2
+
+
 def test_fused_step_sdxl_matches_oracle(dev):
     """One SDXL-style step (pooled text embeds + time ids through the add-embedding) vs the fp32 oracle loop."""
     rcfg = R.tiny_config(xl=True)
