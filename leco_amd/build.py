@@ -31,7 +31,19 @@ def _digest(src: str) -> str:
 
 
 def build(verbose: bool = False) -> str:
+    """Incremental, content-hashed; serialised across processes with a file lock (torchrun starts one
+    process per GPU and each of them imports the package)."""
+    import fcntl
     os.makedirs(OBJ, exist_ok=True)
+    with open(os.path.join(OBJ, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose: bool) -> str:
 
     def one(src):
         obj = os.path.join(OBJ, os.path.basename(src) + "." + _digest(src) + ".o")
@@ -47,7 +59,9 @@ def build(verbose: bool = False) -> str:
     stamp = os.path.join(OBJ, "link.stamp")
     key = " ".join(objs)
     if not (os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read() == key):
-        subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], check=True)
+        tmp = LIB + f".tmp{os.getpid()}"
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs], check=True)
+        os.replace(tmp, LIB)      # atomic: a concurrently loading process never sees a half-written library
         with open(stamp, "w") as f:
             f.write(key)
     return LIB
