@@ -68,12 +68,21 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     constexpr int TILE = (BM + BN) * BK;       // elements per LDS buffer
     bf16_t* smem = (bf16_t*)dyn_lds();
 
-    // XCD-aware bijective remap: hardware places workgroup b on XCD b % 8; give each XCD a
-    // contiguous run of logical tiles (tile_n fastest) so A/W panels are re-used in its L2.
-    const int nwg = (int)gridDim.x, bid = (int)blockIdx.x;
+    // XCD-aware bijective remap.  The hardware places linear workgroup id b on XCD b % 8 (each XCD has a
+    // private 4 MB L2).  Give each XCD a contiguous run of the logical work list, ordered split-major and,
+    // inside a K split, so that the LARGER operand is the one an XCD keeps to itself: for N > M (the deep
+    // 16x16 / 8x8 levels: weights >> activations) tiles are walked m-fastest, i.e. an XCD owns a slice of
+    // W's rows and streams it once instead of every XCD streaming all of W; otherwise n-fastest (an XCD
+    // owns a slice of the activations).
+    const int tiles_m_ = (int)gridDim.x / rt.tiles_n;
+    const int tiles = (int)gridDim.x;
+    const int nwg = tiles * (int)gridDim.y, bid = (int)blockIdx.x + (int)blockIdx.y * tiles;
     const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
     const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    const int tile_m = wg / rt.tiles_n, tile_n = wg % rt.tiles_n;
+    const int split = wg / tiles, t_in = wg - split * tiles;
+    int tile_m, tile_n;
+    if (p.n > p.m) { tile_n = t_in / tiles_m_; tile_m = t_in - tile_n * tiles_m_; }
+    else { tile_m = t_in / rt.tiles_n; tile_n = t_in - tile_m * rt.tiles_n; }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
@@ -93,7 +102,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     const int nk_main = p.k / BK;
     const bool has_ext = aext != nullptr && p.ext_k > 0;
     // K range of this split (the LoRA extension tile belongs to the last split)
-    const int split = (int)blockIdx.y;
     const int kt_begin = (int)(((int64_t)nk_main * split) / rt.split_k);
     const int kt_end = (int)(((int64_t)nk_main * (split + 1)) / rt.split_k);
     const int nk = (kt_end - kt_begin) + ((has_ext && split == rt.split_k - 1) ? 1 : 0);
