@@ -404,8 +404,13 @@ int launch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s) {
     const int tm = cdiv(a.m, BM), tn = cdiv(a.n, BN);
     GemmRt rt{tn, split_k, ws};
     dim3 grid((unsigned)(tm * tn), (unsigned)split_k);
-    if (a.a_mode == LECO_A_PLAIN) launch_one<BM, BN, false>(a, rt, grid, s);
-    else launch_one<BM, BN, true>(a, rt, grid, s);
+    if constexpr (BM == 256) {   // 256x128 tile: 48 KB per ring slot -> 3-deep ring (144 KB), 8 waves (4 x 2)
+        if (a.a_mode == LECO_A_PLAIN) launch_ns<BM, BN, false, 3, 4>(a, rt, grid, s);
+        else launch_ns<BM, BN, true, 3, 4>(a, rt, grid, s);
+    } else {
+        if (a.a_mode == LECO_A_PLAIN) launch_one<BM, BN, false>(a, rt, grid, s);
+        else launch_one<BM, BN, true>(a, rt, grid, s);
+    }
     if (split_k > 1) {
         const int64_t quads = (int64_t)a.m * a.n / 4;
         const int g = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
@@ -440,7 +445,7 @@ int validate(const leco_gemm_args& a) {
 }  // namespace
 }  // namespace leco
 
-// tile: 0 = heuristic, 1 = 128x128, 2 = 128x160, 3 = 64x64.  split_k: 0 = heuristic (needs a
+// tile: 0 = heuristic, 1 = 128x128, 2 = 128x160, 3 = 64x64, 4 = 256x128.  split_k: 0 = heuristic (needs a
 // workspace), 1 = none, >1 = that many K slices.  workspace: fp32 scratch for split-K partials.
 extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* workspace,
                             int64_t workspace_bytes, leco_stream_t stream) {
@@ -459,7 +464,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
             tile = (blocks >= 128 || (can_split && m >= 128)) ? (bn == 160 ? 2 : 1) : 3;
         }
     }
-    const int bm = tile == 3 ? 64 : 128, bn = tile == 3 ? 64 : (tile == 2 ? 160 : 128);
+    const int bm = tile == 3 ? 64 : (tile == 4 ? 256 : 128), bn = tile == 3 ? 64 : (tile == 2 ? 160 : 128);
     const long tiles = (long)cdiv(m, bm) * cdiv(n, bn);
     if (split_k == 0) {
         split_k = 1;
@@ -483,6 +488,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         case 1: return launch<128, 128>(*args, split_k, (float*)workspace, s);
         case 2: return launch<128, 160>(*args, split_k, (float*)workspace, s);
         case 3: return launch<64, 64>(*args, split_k, (float*)workspace, s);
+        case 4: return launch<256, 128>(*args, split_k, (float*)workspace, s);
         default: return fail(-EINVAL, "leco_gemm: bad tile id %d", tile);
     }
 }

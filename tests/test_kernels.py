@@ -40,7 +40,7 @@ def test_gemm_plain_full_epilogue(dev, tile, M, N, K):
     assert rel_err(out, ref) < TOLBF
 
 
-@pytest.mark.parametrize("tile,split", [(1, 3), (3, 4), (2, 2), (0, 0)])
+@pytest.mark.parametrize("tile,split", [(1, 3), (3, 4), (2, 2), (0, 0), (4, 2), (4, 1)])
 def test_gemm_split_k_with_epilogue_and_lora_tile(dev, tile, split):
     torch.manual_seed(11)
     M, N, K = 200, 320, 1152

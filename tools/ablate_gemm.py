@@ -36,8 +36,12 @@ def timeit(fn, iters=20):
 
 
 CASES = [("conv L0 320", 16384, 320, 2880, (4, 64, 64, 64, 64), 0), ("conv L1 640", 4096, 640, 5760, (4, 32, 32, 32, 32), 0),
-         ("conv L2 1280", 1024, 1280, 11520, (4, 16, 16, 16, 16), 0), ("conv L3 1280", 256, 1280, 11520, (4, 8, 8, 8, 8), 0),
-         ("ff1 L0", 16384, 2560, 320, None, 0), ("lin L2 1280", 1024, 1280, 1280, None, 0)]
+         ("conv L1 640 t4", 4096, 640, 5760, (4, 32, 32, 32, 32), 4),
+         ("conv L2 1280", 1024, 1280, 11520, (4, 16, 16, 16, 16), 0), ("conv L2 1280 t4", 1024, 1280, 11520, (4, 16, 16, 16, 16), 4),
+         ("conv L3 1280", 256, 1280, 11520, (4, 8, 8, 8, 8), 0), ("conv L3 1280 t4", 256, 1280, 11520, (4, 8, 8, 8, 8), 4),
+         ("conv up L2 2560", 1024, 1280, 23040, (4, 16, 16, 16, 16), 0), ("conv up L2 2560 t4", 1024, 1280, 23040, (4, 16, 16, 16, 16), 4),
+         ("ff1 L0", 16384, 2560, 320, None, 0), ("ff1 L0 t4", 16384, 2560, 320, None, 4), ("big t4", 8192, 8192, 1024, None, 4),
+         ("lin L2 1280", 1024, 1280, 1280, None, 0)]
 ws = torch.empty(32 * 1024 * 1024, device=dev)
 VARIANTS = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 4, 5]
 
