@@ -462,6 +462,9 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
             const long blocks = (long)cdiv(m, 128) * cdiv(n, bn);
             const bool can_split = workspace != nullptr && nk >= 32;
             tile = (blocks >= 128 || (can_split && m >= 128)) ? (bn == 160 ? 2 : 1) : 3;
+            // deep-K, DMA-bound shapes (the 640/1280-channel convs): the 256-row tile moves ~25% fewer
+            // global->LDS bytes per MFMA and halves the tile count so split-K can fill one round exactly
+            if (tile == 1 && workspace != nullptr && m >= 1024 && nk >= 64) tile = 4;
         }
     }
     const int bm = tile == 3 ? 64 : (tile == 4 ? 256 : 128), bn = tile == 3 ? 64 : (tile == 2 ? 160 : 128);
