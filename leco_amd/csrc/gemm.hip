@@ -26,6 +26,7 @@
 // remapped so each XCD (private L2) owns a contiguous run of tiles.  Deep-K / small-M problems
 // (the 8x8 and 16x16 levels) are split over K into fp32 partial slabs + a finishing kernel.
 #include <errno.h>
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <leco_prims.h>
 
@@ -36,8 +37,10 @@ namespace {
 
 constexpr int BK = 64;
 
-// Tuning aid (tools/ablate_gemm.py builds side libraries with -DLECO_GEMM_ABLATE=1|2): 1 = no MFMA
-// (DMA + barriers + LDS reads only), 2 = no DMA (MFMA on whatever is in LDS).  0 in the product build.
+// Tuning aid (tools/ablate_gemm.py builds side libraries with -DLECO_GEMM_ABLATE=<bit mask>): 1 = no MFMA,
+// 2 = no steady-state DMA, 4 = no W-operand DMA, 8 = no A-operand DMA, 16 = no steady-state fragment
+// reads, 32 = no LDS swizzle, 64 = no steady-state waits / barriers.  Results are garbage with any bit
+// set; only the timing is meaningful.  0 in the product build.
 #ifndef LECO_GEMM_ABLATE
 #define LECO_GEMM_ABLATE 0
 #endif
@@ -107,100 +110,129 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     const int nk = (kt_end - kt_begin) + ((has_ext && split == rt.split_k - 1) ? 1 : 0);
     const int k_split = a1 ? p.k_split : 0x7fffffff;
 
-    // conv: decompose this lane's GA staged output rows once
-    int pb[GA], py[GA], px[GA];
+    // Per-lane addressing state, built once.  Every staged A row of this lane (GA of them) keeps
+    //   plain: its row index;  conv: qy = oy*sy - 1, qx = ox*sy - 1 (tap (kh,kw) reads u = q + k, source
+    //   pixel u >> dv), the sample's first pixel row b*h_in, and a 6-bit validity mask over the 3 vertical /
+    //   3 horizontal taps (padding, stride-2 parity of the transposed gather, m < M) -- so the per-K-step
+    //   address is a few adds / shifts, two 24-bit multiply-adds and one select against the zero page: no
+    //   64-bit multiplies, no divergent branches.
+    // Offsets are 32-bit element offsets (validated on the host: pixels < 2^24, elements < 2^32).
+    const int cpos8 = (st_pos ^ ((LECO_GEMM_ABLATE & 32) ? 0 : st_row)) * 8;   // swizzled 16-byte slot of this lane
+    int qy[GA], qx[GA], pbh[GA];
+    unsigned vmask[GA];
+    unsigned arow[GA];
     const int cin = CONV ? p.k / 9 : 1;
-    if (CONV) {
-        const int hw = p.h_out * p.w_out;
+    const int dv = (CONV && (p.a_mode == LECO_A_CONV3_UP2 || p.a_mode == LECO_A_CONV3_TR2)) ? 1 : 0;
 #pragma unroll
-        for (int i = 0; i < GA; ++i) {
-            int m = m0 + (wave + NW * i) * 8 + st_row;
-            int mm = m < M ? m : 0;
-            pb[i] = mm / hw;
-            int rem = mm - pb[i] * hw;
-            py[i] = rem / p.w_out;
-            px[i] = rem - py[i] * p.w_out;
+    for (int i = 0; i < GA; ++i) {
+        const int m = m0 + (wave + NW * i) * 8 + st_row;
+        arow[i] = (unsigned)(m < M ? m : 0);
+        vmask[i] = m < M ? 0x3fu : 0u;
+        qy[i] = qx[i] = pbh[i] = 0;
+        if (CONV) {
+            const int hw = p.h_out * p.w_out;
+            const int pb = (int)arow[i] / hw;
+            const int rem = (int)arow[i] - pb * hw;
+            const int py = rem / p.w_out, px = rem - py * p.w_out;
+            const int sy = (p.a_mode == LECO_A_CONV3_S2) ? 2 : 1;
+            const int odd_mask = (p.a_mode == LECO_A_CONV3_TR2) ? 1 : 0;
+            const int lim_y = p.h_in << dv, lim_x = p.w_in << dv;
+            qy[i] = py * sy - 1;
+            qx[i] = px * sy - 1;
+            pbh[i] = pb * p.h_in;
+            unsigned vm = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int uy = qy[i] + t, ux = qx[i] + t;
+                const bool vy = (uy >= 0) & (uy < lim_y) & ((uy & odd_mask) == 0);
+                const bool vx = (ux >= 0) & (ux < lim_x) & ((ux & odd_mask) == 0);
+                vm |= (vy ? 1u : 0u) << t | (vx ? 1u : 0u) << (3 + t);
+            }
+            vmask[i] &= vm;
         }
     }
+    // W rows of this lane: row pointers (loop invariant); rows n >= N point at the zero page and ignore the
+    // K offset (mask 0)
+    const bf16_t* wrow[GW];
+    const bf16_t* wxrow[GW];
+    unsigned wmask[GW];
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+        const int n = n0 + (wave + NW * i) * 8 + st_row;
+        wrow[i] = (n < N) ? wp + (int64_t)n * p.ldw + cpos8 : zero;
+        wmask[i] = (n < N) ? 0xffffffffu : 0u;
+        wxrow[i] = (n < N && cpos8 < p.ext_k && wext) ? wext + (int64_t)n * p.ld_wext + cpos8 : zero;
+    }
+    // select "src + off" or the zero page without a branch: zero + ((src - zero) + 2*off) & mask
+    auto pick = [&](const bf16_t* src, unsigned off, unsigned ok) -> const bf16_t* {
+        const long long delta = (const char*)src - (const char*)zero;           // wave-uniform
+        const long long d = (delta + ((long long)off << 1)) & -(long long)ok;
+        return (const bf16_t*)((const char*)zero + d);
+    };
+    const int n_main = kt_end - kt_begin;
 
-    auto stage = [&](int it, int buf) {
-        bf16_t* sA = smem + buf * TILE;
-        bf16_t* sB = sA + BM * BK;
+    struct Addr { const bf16_t* a[GA]; const bf16_t* w[GW]; };
+    // source addresses of main K tile `it` (local index): straight-line VALU/SALU, no memory traffic
+    auto addr_main = [&](int it, Addr& ad) {
         const int kt = kt_begin + it;
-        if (it < kt_end - kt_begin) {
-            const int k0 = kt * BK;
-            if (!CONV) {
-                const bf16_t* src;
-                int64_t ld;
-                int kk;
-                if (k0 < k_split) { src = a0; ld = p.lda0; kk = k0; }
-                else { src = a1; ld = p.lda1; kk = k0 - k_split; }
-#pragma unroll
-                for (int i = 0; i < GA; ++i) {
-                    const int r = (wave + NW * i) * 8 + st_row, m = m0 + r;
-                    const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
-                    const bf16_t* g = (m < M) ? src + (int64_t)m * ld + kk + c * 8 : zero;
-                    if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + NW * i) * 8 * BK);
-                }
-            } else {
-                // K order of a conv is channel-chunk major / tap minor: the 9 taps of one 64-channel chunk
-                // re-read (shifted) the same input pixels back to back, so they hit in L1/L2 instead of
-                // sweeping the whole input patch once per tap.
-                const int chunk = kt / 9, tap = kt - chunk * 9;
-                const int cch = chunk * BK;
-                const int kh = tap / 3, kw = tap - kh * 3;
-                const bf16_t* src;
-                int64_t ld;
-                int cc;
-                if (cch < k_split) { src = a0; ld = p.lda0; cc = cch; }
-                else { src = a1; ld = p.lda1; cc = cch - k_split; }
-                // branch-free gather parameters of the four conv modes:
-                //   u = o * sy + k - 1 must lie in [0, h_in << dv) (and be even for the transposed
-                //   stride-2 gather); source pixel = u >> dv.
-                const int sy = (p.a_mode == LECO_A_CONV3_S2) ? 2 : 1;
-                const int dv = (p.a_mode == LECO_A_CONV3_UP2 || p.a_mode == LECO_A_CONV3_TR2) ? 1 : 0;
-                const int odd_mask = (p.a_mode == LECO_A_CONV3_TR2) ? 1 : 0;
-                const int lim_y = p.h_in << dv, lim_x = p.w_in << dv;
-#pragma unroll
-                for (int i = 0; i < GA; ++i) {
-                    const int r = (wave + NW * i) * 8 + st_row, m = m0 + r;
-                    const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
-                    const int uy = py[i] * sy + kh - 1, ux = px[i] * sy + kw - 1;
-                    const bool ok = (m < M) & (uy >= 0) & (uy < lim_y) & (ux >= 0) & (ux < lim_x) &
-                                    (((uy | ux) & odd_mask) == 0);
-                    const int iy = uy >> dv, ix = ux >> dv;
-                    const int64_t off = ((int64_t)(pb[i] * p.h_in + iy) * p.w_in + ix) * ld + cc + c * 8;
-                    const bf16_t* g = ok ? src + off : zero;
-                    if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + NW * i) * 8 * BK);
-                }
-            }
-            int wcol = k0;
-            if (CONV) { const int chunk = kt / 9, tap = kt - chunk * 9; wcol = tap * cin + chunk * BK; }
-#pragma unroll
-            for (int i = 0; i < GW; ++i) {
-                if (RAGGED && i == GW - 1 && !w_last) break;
-                const int r = (wave + NW * i) * 8 + st_row, n = n0 + r;
-                const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
-                const bf16_t* g = (n < N) ? wp + (int64_t)n * p.ldw + wcol + c * 8 : zero;
-                if (LECO_GEMM_ABLATE != 4) glds16(g, sB + (wave + NW * i) * 8 * BK);
-            }
-        } else {  // LoRA K-extension tile
+        const int k0 = kt * BK;
+        const bf16_t* src;
+        unsigned ld;
+        int kk, wcol = k0;
+        if (!CONV) {
+            if (k0 < k_split) { src = a0; ld = (unsigned)p.lda0; kk = k0; }
+            else { src = a1; ld = (unsigned)p.lda1; kk = k0 - k_split; }
 #pragma unroll
             for (int i = 0; i < GA; ++i) {
-                const int r = (wave + NW * i) * 8 + st_row, m = m0 + r;
-                const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
-                const bf16_t* g = (c * 8 < p.ext_k && m < M) ? aext + (int64_t)m * p.ld_aext + c * 8 : zero;
-                if (LECO_GEMM_ABLATE != 5) glds16(g, sA + (wave + NW * i) * 8 * BK);
+                const unsigned off = mul24(arow[i], ld) + (unsigned)(kk + cpos8);
+                ad.a[i] = pick(src, off, vmask[i] & 1u);
             }
+        } else {
+            // K order of a conv is channel-chunk major / tap minor: the 9 taps of one 64-channel chunk
+            // re-read (shifted) the same input pixels back to back, so they hit in L1/L2 instead of
+            // sweeping the whole input patch once per tap.
+            const int chunk = kt / 9, tap = kt - chunk * 9;
+            const int cch = chunk * BK;
+            const int kh = tap / 3, kw = tap - kh * 3;
+            if (cch < k_split) { src = a0; ld = (unsigned)p.lda0; kk = cch; }
+            else { src = a1; ld = (unsigned)p.lda1; kk = cch - k_split; }
+            wcol = tap * cin + cch;
 #pragma unroll
-            for (int i = 0; i < GW; ++i) {
-                if (RAGGED && i == GW - 1 && !w_last) break;
-                const int r = (wave + NW * i) * 8 + st_row, n = n0 + r;
-                const int c = (LECO_GEMM_ABLATE == 3) ? st_pos : (st_pos ^ (r & 7));
-                const bf16_t* g = (c * 8 < p.ext_k && n < N) ? wext + (int64_t)n * p.ld_wext + c * 8 : zero;
-                if (LECO_GEMM_ABLATE != 4) glds16(g, sB + (wave + NW * i) * 8 * BK);
+            for (int i = 0; i < GA; ++i) {
+                const int iy = (qy[i] + kh) >> dv, ix = (qx[i] + kw) >> dv;
+                const unsigned pix = mul24((unsigned)(pbh[i] + iy), (unsigned)p.w_in) + (unsigned)ix;
+                const unsigned ok = (vmask[i] >> kh) & (vmask[i] >> (3 + kw)) & 1u;
+                const unsigned off = mul24(pix, ld) + (unsigned)(kk + cpos8);
+                ad.a[i] = pick(src, off, ok);
             }
         }
+#pragma unroll
+        for (int i = 0; i < GW; ++i) ad.w[i] = wrow[i] + ((unsigned)wcol & wmask[i]);
+    };
+    auto addr_ext = [&](Addr& ad) {   // LoRA K-extension tile
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            ad.a[i] = (cpos8 < p.ext_k && vmask[i]) ? aext + (int64_t)arow[i] * p.ld_aext + cpos8 : zero;
+#pragma unroll
+        for (int i = 0; i < GW; ++i) ad.w[i] = wxrow[i];
+    };
+    auto issue = [&](const Addr& ad, int buf, bool wl) {
+        bf16_t* sA = smem + buf * TILE;
+        bf16_t* sB = sA + BM * BK;
+#pragma unroll
+        for (int i = 0; i < GA; ++i)
+            if (!(LECO_GEMM_ABLATE & 8)) glds16(ad.a[i], sA + (wave + NW * i) * 8 * BK);
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            if (RAGGED && i == GW - 1 && !wl) break;
+            if (!(LECO_GEMM_ABLATE & 4)) glds16(ad.w[i], sB + (wave + NW * i) * 8 * BK);
+        }
+    };
+    auto stage = [&](int it, int buf) {
+        Addr ad;
+        if (it < n_main) addr_main(it, ad);
+        else addr_ext(ad);
+        issue(ad, buf, w_last);
     };
 
     f32x4 acc[FM][FN];
@@ -212,11 +244,14 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     // NS-deep DMA ring + software-pipelined fragment reads.  A K tile is consumed in two 32-wide half
     // steps; the ds_read_b128 of half step h+1 are issued BEFORE the MFMAs of half step h (two fragment
     // register sets), so LDS latency overlaps MFMA issue inside a wave.  Per iteration `it`:
-    //     read frags(it, ks1)           | MFMA frags(it, ks0)
+    //     read frags(it, ks1) ; addresses of tile it+NS  | MFMA frags(it, ks0)
     //     wait "tile it+1 landed" (counted vmcnt: this wave's pieces) ; barrier
     //         -> every wave has now finished reading tile `it` (both halves are in registers), so its ring
     //            slot can be re-filled; the barrier does not drain the younger DMAs
     //     issue DMA(tile it+NS) into that slot ; read frags(it+1, ks0) | MFMA frags(it, ks1)
+    // The steady-state body (tile it+NS is a main tile) is one straight-line basic block -- no branches,
+    // waitcnt immediates fixed per instantiation -- so the address arithmetic and the DMA issue interleave
+    // with the MFMAs instead of forming a separate phase after the barrier.
 #pragma unroll
     for (int s0 = 0; s0 < NS; ++s0)
         if (s0 < nk) stage(s0, s0);
@@ -227,16 +262,24 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         const bf16_t* sA = smem + (it % NS) * TILE;
         const bf16_t* sB = sA + BM * BK;
 #pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(sA + lds_off(wave_m * WM + i * 16 + fr, ks * 4 + fg));
+        for (int i = 0; i < FM; ++i) af[i] = lds_read16_async(sA + lds_off(wave_m * WM + i * 16 + fr, ks * 4 + fg));
 #pragma unroll
-        for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(sB + lds_off(wave_n * WN + j * 16 + fr, ks * 4 + fg));
+        for (int j = 0; j < FN; ++j) wf[j] = lds_read16_async(sB + lds_off(wave_n * WN + j * 16 + fr, ks * 4 + fg));
+    };
+    // fragment reads are explicit asynchronous ds_reads: `landed` hands a set back to the compiler once a
+    // wait has covered it
+    auto landed = [&](bf16x8 (&af)[FM], bf16x8 (&wf)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) lds_tie(af[i]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) lds_tie(wf[j]);
     };
     auto mma = [&](const bf16x8 (&af)[FM], const bf16x8 (&wf)[FN]) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                if (LECO_GEMM_ABLATE != 1) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+                if (!(LECO_GEMM_ABLATE & 1)) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
                 else acc[i][j][0] += __uint_as_float((unsigned)(wf[j][0] ^ af[i][0]));  // keep the LDS reads live
             }
     };
@@ -254,15 +297,48 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         barrier_keep_dma();
         read_frags(0, 0, afA, wfA);
     }
-    for (int it = 0; it < nk; ++it) {
+    int it = 0;
+    // steady state: iterations whose refill (tile it+NS) is a main tile.  Outstanding LDS reads when set A is
+    // needed: the FM+FN reads of set B issued after it -> lgkmcnt(FM+FN) completes A without waiting for B.
+    auto steady = [&](auto wl_c) {
+        constexpr bool WL = decltype(wl_c)::value;
+        constexpr int PIECES = GA + (WL ? GW : GW - 1);
+        for (; it + NS < n_main; ++it) {
+            Addr ad;
+            if (!(LECO_GEMM_ABLATE & 16) || it == 0) read_frags(it, 1, afB, wfB);
+            if (!(LECO_GEMM_ABLATE & 2)) addr_main(it + NS, ad);
+            lds_wait<FM + FN>();
+            landed(afA, wfA);
+            mma(afA, wfA);
+            sched_fence();
+            if (!(LECO_GEMM_ABLATE & 64)) {
+                wait_vmcnt<(NS - 2) * PIECES>();      // tile it+1 landed; NS-2 younger tiles stay in flight
+                barrier_keep_dma();                   // (also completes set B)
+            } else lds_wait<0>();
+            landed(afB, wfB);
+            if (!(LECO_GEMM_ABLATE & 2)) issue(ad, it % NS, WL);
+            if (!(LECO_GEMM_ABLATE & 16)) read_frags(it + 1, 0, afA, wfA);
+            mma(afB, wfB);
+            sched_fence();
+        }
+    };
+    if (RAGGED && !w_last) steady(std::false_type{});
+    else steady(std::true_type{});
+    for (; it < nk; ++it) {   // drain: last NS tiles (and the LoRA extension tile)
         read_frags(it, 1, afB, wfB);
+        lds_wait<FM + FN>();
+        landed(afA, wfA);
         mma(afA, wfA);
+        sched_fence();
         if (it + 1 < nk) wait_tile(it + 1, nk < it + NS ? nk : it + NS);
         barrier_keep_dma();
-        if (it + NS < nk && LECO_GEMM_ABLATE != 2) stage(it + NS, it % NS);
+        landed(afB, wfB);
+        if (it + NS < nk && !(LECO_GEMM_ABLATE & 2)) stage(it + NS, it % NS);
         if (it + 1 < nk) read_frags(it + 1, 0, afA, wfA);
         mma(afB, wfB);
+        sched_fence();
     }
+    lds_wait<0>();
 
     // ---- epilogue through LDS: the accumulators (lane = one row x 4 consecutive n) are staged as fp32,
     // 64 tile rows at a time, so that the global side of the epilogue (residual / bias reads, bf16 or
@@ -439,6 +515,13 @@ int validate(const leco_gemm_args& a) {
         if (a.a1 && (a.k_split % BK)) return fail(-EINVAL, "leco_gemm: conv k_split %% 64 != 0");
     } else if (a.a1 && (a.k_split % BK)) {
         return fail(-EINVAL, "leco_gemm: k_split %% 64 != 0");
+    }
+    {   // the A loader forms 32-bit element offsets with 24-bit multiplies (row or pixel index x row stride)
+        const int64_t rows = a.a_mode == LECO_A_PLAIN ? (int64_t)a.m : (int64_t)a.batch * a.h_in * a.w_in;
+        const int64_t ld = a.lda0 > (a.a1 ? a.lda1 : 0) ? a.lda0 : a.lda1;
+        if (rows >= (1 << 24) || ld >= (1 << 24) || rows * ld + a.k >= ((int64_t)1 << 32))
+            return fail(-EINVAL, "leco_gemm: activation operand too large for 32-bit element offsets (rows=%lld ld=%lld)",
+                        (long long)rows, (long long)ld);
     }
     return 0;
 }

@@ -52,6 +52,24 @@ __device__ __forceinline__ void barrier_keep_dma() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 }
+// 16-byte LDS read the compiler's s_waitcnt insertion does not track (ds_read_b128 through inline asm).  With
+// LDS-DMA in flight the compiler waits lgkmcnt(0) before the first use of ANY ds_read result, which would
+// serialise software-pipelined fragment reads; these reads are completed explicitly with lds_wait<N>() and
+// handed back to the compiler with lds_tie() (an empty asm that makes later uses depend on the wait).
+__device__ __forceinline__ bf16x8 lds_read16_async(const void* lds_ptr) {
+    bf16x8 v;
+    const unsigned a = (unsigned)(unsigned long long)lds_ptr;   // generic LDS pointer: low 32 bits = LDS byte address
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+// wait until at most N LDS (lgkm) operations of this wave are outstanding
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void lds_tie(bf16x8& v) { asm volatile("" : "+v"(v)); }
+// scheduling fence: the compiler moves no instruction across it
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // launch-time sized LDS (up to 160 KB per workgroup on gfx950)
 extern __shared__ __attribute__((aligned(16))) unsigned char leco_dyn_lds_[];
 __device__ __forceinline__ unsigned char* dyn_lds() { return leco_dyn_lds_; }
@@ -59,6 +77,8 @@ __device__ __forceinline__ unsigned char* dyn_lds() { return leco_dyn_lds_; }
 // tells the compiler a value is wave-uniform (v_readfirstlane): needed for values derived from
 // threadIdx (e.g. the wave index) that feed scalar operands such as the LDS-DMA base (M0)
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// 24-bit x 24-bit -> low 32 bits (v_mul_u32_u24 / v_mad_u32_u24: full-rate, unlike the 32-bit multiply)
+__device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) { return __umul24(a, b); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }

@@ -55,12 +55,18 @@ static inline void glds16(const void* gsrc, void* lds_wave_base) {
 }
 template <int N>
 static inline void wait_vmcnt() {}          // the emulated DMA completes immediately
+static inline bf16x8 lds_read16_async(const void* lds_ptr) { return *(const bf16x8*)lds_ptr; }
+template <int N>
+static inline void lds_wait() {}
+static inline void lds_tie(bf16x8&) {}
+static inline void sched_fence() {}
 static inline void barrier_keep_dma() { emu::sync_block(); }
 static inline unsigned char* dyn_lds() {
     static thread_local __attribute__((aligned(16))) unsigned char buf[160 * 1024];
     return buf;
 }
 static inline int uniform(int v) { return v; }
+static inline unsigned mul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int lane_id() { return emu::lane(); }
 static inline float shfl_xor(float v, int mask) {
     const unsigned char* all = emu::wave_gather(&v, 4);

@@ -15,7 +15,11 @@ dev = torch.device("cuda:0")
 
 
 def build_variant(v):
-    out = f"/tmp/libleco_ablate{v}.so"
+    d = os.path.join(ROOT, "tools", "_ablate")   # prebuilt variants travel to the GPU box with the snapshot
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, f"libleco_ablate{v}.so")
+    if os.path.exists(out) and os.path.getmtime(out) > os.path.getmtime(os.path.join(B.CSRC, "gemm.hip")):
+        return out
     srcs = [os.path.join(B.CSRC, f) for f in sorted(os.listdir(B.CSRC)) if f.endswith((".hip", ".cpp"))]
     cmd = [B.HIPCC, *B.FLAGS, f"-DLECO_GEMM_ABLATE={v}", "-shared", "-x", "hip", *srcs, "-o", out]
     subprocess.run(cmd, check=True)
@@ -40,10 +44,18 @@ CASES = [("conv L0 320", 16384, 320, 2880, (4, 64, 64, 64, 64), 0), ("conv L1 64
          ("conv L2 1280", 1024, 1280, 11520, (4, 16, 16, 16, 16), 0), ("conv L2 1280 t4", 1024, 1280, 11520, (4, 16, 16, 16, 16), 4),
          ("conv L3 1280", 256, 1280, 11520, (4, 8, 8, 8, 8), 0), ("conv L3 1280 t4", 256, 1280, 11520, (4, 8, 8, 8, 8), 4),
          ("conv up L2 2560", 1024, 1280, 23040, (4, 16, 16, 16, 16), 0), ("conv up L2 2560 t4", 1024, 1280, 23040, (4, 16, 16, 16, 16), 4),
-         ("ff1 L0", 16384, 2560, 320, None, 0), ("ff1 L0 t4", 16384, 2560, 320, None, 4), ("big t4", 8192, 8192, 1024, None, 4),
+         ("ff1 L0", 16384, 2560, 320, None, 0), ("ff1 L0 t4", 16384, 2560, 320, None, 4), ("big", 8192, 8192, 1024, None, 1), ("big t4", 8192, 8192, 1024, None, 4),
          ("lin L2 1280", 1024, 1280, 1280, None, 0)]
+VARIANTS = [int(a) for a in sys.argv[1:] if a.lstrip("-").isdigit()] or [0, 1, 2, 4, 8]
+ONLY = os.environ.get("ABLATE_CASES")
+if ONLY:
+    CASES = [c for c in CASES if c[0] in ONLY.split(",")]
+if "--build-only" in sys.argv:
+    for v in VARIANTS:
+        if v:
+            print(build_variant(v))
+    sys.exit(0)
 ws = torch.empty(32 * 1024 * 1024, device=dev)
-VARIANTS = [int(a) for a in sys.argv[1:]] or [0, 1, 2, 4, 5]
 
 for v in VARIANTS:
     hip._use_library(build_variant(v) if v else hip.LIB_PATH)
