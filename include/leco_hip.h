@@ -72,6 +72,17 @@ typedef struct leco_gemm_args {
     int64_t ldc;
     float* c_f32;             /* optional fp32 copy of the pre-rounding result, row stride ldc32 */
     int64_t ldc32;
+    /* Fused LoRA down-projection (plain A only; exclusive with a_ext): t_w = stacked lora_down rows, bf16
+     * [32][K] (rows >= groups*r zero), row stride ld_tw; t_rows = 16 or 32 = how many of them are non-zero
+     * (rounded up to 16).  The kernel forms T = A t_w^T during its own K sweep, rounds it to bf16 and uses it
+     * as the A side of the K-extension against w_ext (ext_k must be 32).  t_out (optional, bf16 [M][32], row
+     * stride ld_tout) receives T for the backward (lora_up wgrad); it is REQUIRED scratch when the launch
+     * heuristic may split K (then T is computed by a separate skinny GEMM into t_out). */
+    const void* t_w;
+    int64_t ld_tw;
+    int32_t t_rows;
+    void* t_out;
+    int64_t ld_tout;
 } leco_gemm_args;
 
 int leco_gemm(const leco_gemm_args* args, leco_stream_t stream);

@@ -362,7 +362,7 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const leco_lora_site* si
 }
 
 // ---- LoRA weight gradients: G[j][c] += scale * sum_m P[m][j] Q[m][c] -----------------------------------
-// block = 256 threads; thread owns column c of a 256-wide column tile; blockIdx.y walks WG_ROWS-row slabs
+// block = 256 threads over a 256-column tile (32 column vectors x 8 row lanes); blockIdx.y walks WG_ROWS-row slabs
 // of M (P slab staged in LDS as fp32); 8 independent Q loads in flight per thread.  r <= 16.
 constexpr int WG_ROWS = 128;
 struct WgradConv {   // a_mode == LECO_A_PLAIN: Q row = m.  Otherwise Q row = source pixel of output row m for tap (kh, kw)
@@ -372,10 +372,16 @@ template <int R>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_t ldp, const bf16_t* Q, int64_t ldq,
                                                           float* G, int64_t g_sj, int64_t g_sc, int M, int r,
                                                           int cols, float scale, WgradConv cv) {
+    // thread (vec = tid & 31, rl = tid >> 5): 8 adjacent columns (one 16-byte load per row) x every 8th row of
+    // the slab; the 8 row lanes are then combined through LDS in a fixed order and one atomic per (j, column)
+    // leaves the block.
     __shared__ float sp[WG_ROWS * R];
     __shared__ int srow[WG_ROWS];
+    __shared__ f32x4 red[8 * 256];
     const int tid = (int)threadIdx.x;
-    const int c = (int)blockIdx.x * 256 + tid;
+    const int vec = tid & 31, rl = tid >> 5;
+    const int c0 = (int)blockIdx.x * 256;
+    const int c = c0 + vec * 8;
     const int m0 = (int)blockIdx.y * WG_ROWS;
     const int rows = min(WG_ROWS, M - m0);
     for (int e = tid; e < WG_ROWS * R; e += 256) {
@@ -401,25 +407,56 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_
         srow[tid] = src;
     }
     __syncthreads();
-    if (c >= cols) return;
-    float acc[R];
+    float acc[8][R];
 #pragma unroll
-    for (int j = 0; j < R; ++j) acc[j] = 0.f;
-    for (int mm = 0; mm < WG_ROWS; mm += 8) {   // rows beyond `rows` contribute 0 through sp
-        float q[8];
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int sr = srow[mm + u];
-            q[u] = sr >= 0 ? bf2f(Q[(int64_t)sr * ldq + c]) : 0.f;
+        for (int j = 0; j < R; ++j) acc[i][j] = 0.f;
+    if (c < cols) {
+        for (int mm = rl; mm < WG_ROWS; mm += 32) {   // rows beyond `rows` contribute 0 through sp / srow
+            u32x4 qv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int sr = srow[mm + 8 * u];
+                qv[u] = sr >= 0 ? *(const u32x4*)(Q + (int64_t)sr * ldq + c) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float q[8];
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    q[2 * h] = bf2f((bf16_t)(qv[u][h] & 0xffffu));
+                    q[2 * h + 1] = bf2f((bf16_t)(qv[u][h] >> 16));
+                }
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const float pj = sp[(mm + 8 * u) * R + j];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) acc[i][j] += q[i] * pj;
+                }
+            }
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-            for (int j = 0; j < R; ++j) acc[j] += sp[(mm + u) * R + j] * q[u];
     }
 #pragma unroll
-    for (int j = 0; j < R; ++j)
-        if (j < r) atomicAdd(&G[j * g_sj + c * g_sc], acc[j] * scale);
+    for (int jb = 0; jb < R; jb += 4) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            red[rl * 256 + vec * 8 + i] = f32x4{acc[i][jb], acc[i][jb + 1], acc[i][jb + 2], acc[i][jb + 3]};
+        __syncthreads();
+        f32x4 t = red[tid];
+#pragma unroll
+        for (int l = 1; l < 8; ++l) {
+            const f32x4 o = red[l * 256 + tid];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) t[jj] += o[jj];
+        }
+        if (c0 + tid < cols) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                if (jb + jj < r) atomicAdd(&G[(jb + jj) * g_sj + (int64_t)(c0 + tid) * g_sc], t[jj] * scale);
+        }
+    }
 }
 
 // ---- per-sample column sums: out[b][c] = sum over the rows of sample b of x[row][c] (fp32 out; d time-embedding bias)

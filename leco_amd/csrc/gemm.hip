@@ -60,15 +60,27 @@ struct GemmRt {      // launch-time extras (not part of the C ABI struct)
 // NS in {2, 4}: LDS ring depth.  NWM in {2, 4}: waves along M (block = NWM x 2 waves).  With NWM = 4 a
 // 128-row tile runs on 8 waves = 2 per SIMD, so one wave's LDS-read latency hides behind the other's MFMAs
 // even when only one workgroup fits on a CU.
-template <int BM, int BN, bool CONV, int NS, int NWM>
+//
+// TF in {0, 1, 2}: fused LoRA down-projection.  The W operand tile carries 16*TF extra rows (the stacked
+// lora_down matrix t_w [16*TF][K]); T = A * t_w^T is accumulated next to the main accumulators during the
+// same K sweep (the activation tile is already in LDS), rounded to bf16 and written into LDS as the A side
+// of the K-extension tile -- the separate skinny T GEMM (one launch and one full re-read of A per LoRA
+// site) disappears.  TF = 1: every wave computes the 16 T columns for half of its row fragments;
+// TF = 2: wave column wave_n computes T columns [16 wave_n, 16 wave_n + 16).
+template <int BM, int BN, bool CONV, int NS, int NWM, int TF = 0>
 __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p, const GemmRt rt) {
     constexpr int NW = NWM * 2, NT = NW * 64;
     constexpr int WM = BM / NWM, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int BNT = BN + 16 * TF;                     // W tile rows including the fused lora_down rows
+    constexpr int TFM = TF == 0 ? 0 : (TF == 1 ? FM / 2 : FM);   // T accumulator fragments per wave
+    constexpr int FNT = FN + (TF ? 1 : 0);                // W-side fragments read per half step
+    static_assert(!(TF && CONV), "the fused down-projection is for plain (Linear / 1x1) sites");
+    static_assert(TF != 1 || FM % 2 == 0, "TF = 1 splits the row fragments of a wave in two");
     constexpr int GA = BM / 8 / NW;                       // 8-row groups staged per wave (A), exact
-    constexpr int GWT = BN / 8, GW = (GWT + NW - 1) / NW; // W groups: total / per wave (last may be absent)
+    constexpr int GWT = BNT / 8, GW = (GWT + NW - 1) / NW; // W groups: total / per wave (last may be absent)
     constexpr bool RAGGED = (GWT % NW) != 0;
     static_assert((BM / 8) % NW == 0, "A row groups must divide evenly over the waves");
-    constexpr int TILE = (BM + BN) * BK;       // elements per LDS buffer
+    constexpr int TILE = (BM + BNT) * BK;      // elements per LDS buffer
     bf16_t* smem = (bf16_t*)dyn_lds();
 
     // XCD-aware bijective remap.  The hardware places linear workgroup id b on XCD b % 8 (each XCD has a
@@ -103,7 +115,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     const bf16_t* zero = (const bf16_t*)g_zero_page;
     const int M = p.m, N = p.n;
     const int nk_main = p.k / BK;
-    const bool has_ext = aext != nullptr && p.ext_k > 0;
+    const bool has_ext = TF == 0 && aext != nullptr && p.ext_k > 0;
     // K range of this split (the LoRA extension tile belongs to the last split)
     const int kt_begin = (int)(((int64_t)nk_main * split) / rt.split_k);
     const int kt_end = (int)(((int64_t)nk_main * (split + 1)) / rt.split_k);
@@ -158,10 +170,16 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     unsigned wmask[GW];
 #pragma unroll
     for (int i = 0; i < GW; ++i) {
-        const int n = n0 + (wave + NW * i) * 8 + st_row;
-        wrow[i] = (n < N) ? wp + (int64_t)n * p.ldw + cpos8 : zero;
-        wmask[i] = (n < N) ? 0xffffffffu : 0u;
-        wxrow[i] = (n < N && cpos8 < p.ext_k && wext) ? wext + (int64_t)n * p.ld_wext + cpos8 : zero;
+        const int rl = (wave + NW * i) * 8 + st_row;      // row inside the W tile
+        const int n = n0 + rl;
+        const bool main_row = rl < BN && n < N;
+        wrow[i] = main_row ? wp + (int64_t)n * p.ldw + cpos8 : zero;
+        wmask[i] = main_row ? 0xffffffffu : 0u;
+        if (TF && rl >= BN && rl < BNT) {                 // fused lora_down rows
+            wrow[i] = (const bf16_t*)p.t_w + (int64_t)(rl - BN) * p.ld_tw + cpos8;
+            wmask[i] = 0xffffffffu;
+        }
+        wxrow[i] = (main_row && cpos8 < p.ext_k && wext) ? wext + (int64_t)n * p.ld_wext + cpos8 : zero;
     }
     // select "src + off" or the zero page without a branch: zero + ((src - zero) + 2*off) & mask
     auto pick = [&](const bf16_t* src, unsigned off, unsigned ok) -> const bf16_t* {
@@ -236,10 +254,15 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     };
 
     f32x4 acc[FM][FN];
+    f32x4 acct[TFM ? TFM : 1];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < (TFM ? TFM : 1); ++i) acct[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int t_i0 = TF == 1 ? wave_n * (FM / 2) : 0;          // first row fragment this wave projects
+    const int t_row = BN + (TF == 2 ? wave_n * 16 : 0);        // W-tile row of its lora_down fragment
 
     // NS-deep DMA ring + software-pipelined fragment reads.  A K tile is consumed in two 32-wide half
     // steps; the ds_read_b128 of half step h+1 are issued BEFORE the MFMAs of half step h (two fragment
@@ -257,24 +280,25 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         if (s0 < nk) stage(s0, s0);
 
     const int fr = lane & 15, fg = lane >> 4;
-    bf16x8 afA[FM], wfA[FN], afB[FM], wfB[FN];
-    auto read_frags = [&](int it, int ks, bf16x8 (&af)[FM], bf16x8 (&wf)[FN]) {
+    bf16x8 afA[FM], wfA[FNT], afB[FM], wfB[FNT];
+    auto read_frags = [&](int it, int ks, bf16x8 (&af)[FM], bf16x8 (&wf)[FNT]) {
         const bf16_t* sA = smem + (it % NS) * TILE;
         const bf16_t* sB = sA + BM * BK;
 #pragma unroll
         for (int i = 0; i < FM; ++i) af[i] = lds_read16_async(sA + lds_off(wave_m * WM + i * 16 + fr, ks * 4 + fg));
 #pragma unroll
         for (int j = 0; j < FN; ++j) wf[j] = lds_read16_async(sB + lds_off(wave_n * WN + j * 16 + fr, ks * 4 + fg));
+        if (TF) wf[FN] = lds_read16_async(sB + lds_off(t_row + fr, ks * 4 + fg));
     };
     // fragment reads are explicit asynchronous ds_reads: `landed` hands a set back to the compiler once a
     // wait has covered it
-    auto landed = [&](bf16x8 (&af)[FM], bf16x8 (&wf)[FN]) {
+    auto landed = [&](bf16x8 (&af)[FM], bf16x8 (&wf)[FNT]) {
 #pragma unroll
         for (int i = 0; i < FM; ++i) lds_tie(af[i]);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) lds_tie(wf[j]);
+        for (int j = 0; j < FNT; ++j) lds_tie(wf[j]);
     };
-    auto mma = [&](const bf16x8 (&af)[FM], const bf16x8 (&wf)[FN]) {
+    auto mma = [&](const bf16x8 (&af)[FM], const bf16x8 (&wf)[FNT]) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -282,6 +306,13 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
                 if (!(LECO_GEMM_ABLATE & 1)) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
                 else acc[i][j][0] += __uint_as_float((unsigned)(wf[j][0] ^ af[i][0]));  // keep the LDS reads live
             }
+#pragma unroll
+        for (int i = 0; i < TFM; ++i) {
+            // TF = 1: wave column 1 projects the upper half of the row fragments (uniform select, not a
+            // dynamically indexed register array)
+            const bf16x8 a = (TF == 1 && wave_n) ? af[(TF == 1 ? FM / 2 : 0) + i] : af[i];
+            acct[i] = mfma16(wf[FN], a, acct[i]);
+        }
     };
     // wait until this wave's DMA pieces of tile `t` have landed, given that tiles [0, staged) were issued:
     // the `staged - 1 - t` younger tiles may stay in flight
@@ -307,7 +338,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             Addr ad;
             if (!(LECO_GEMM_ABLATE & 16) || it == 0) read_frags(it, 1, afB, wfB);
             if (!(LECO_GEMM_ABLATE & 2)) addr_main(it + NS, ad);
-            lds_wait<FM + FN>();
+            lds_wait<FM + FNT>();
             landed(afA, wfA);
             mma(afA, wfA);
             sched_fence();
@@ -326,7 +357,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     else steady(std::true_type{});
     for (; it < nk; ++it) {   // drain: last NS tiles (and the LoRA extension tile)
         read_frags(it, 1, afB, wfB);
-        lds_wait<FM + FN>();
+        lds_wait<FM + FNT>();
         landed(afA, wfA);
         mma(afA, wfA);
         sched_fence();
@@ -339,6 +370,52 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         sched_fence();
     }
     lds_wait<0>();
+
+    if (TF) {
+        // ---- fused K-extension: T (this wave's fragments, fp32) -> bf16 into ring slot 0 as the A side,
+        // scale*up rows DMA'd next to it, one 32-wide MFMA step on the main accumulators.  Lane l holds
+        // T[row 16 i + (l & 15)][column 4 (l >> 4) + r] of its fragment (the swapped-operand D layout).
+        barrier_keep_dma();                       // every wave is done with the ring
+        bf16_t* sA = smem;
+        bf16_t* sB = sA + BM * BK;
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            if (RAGGED && i == GW - 1 && !w_last) break;
+            glds16(wxrow[i], sB + (wave + NW * i) * 8 * BK);
+        }
+        bf16_t* tout = (bf16_t*)p.t_out;
+        const int tcol = (TF == 2 ? wave_n * 16 : 0) + 4 * fg;
+#pragma unroll
+        for (int i = 0; i < TFM; ++i) {
+            const int row = wave_m * WM + (t_i0 + i) * 16 + fr;
+            const unsigned lo = pack_bf2(acct[i][0], acct[i][1]), hi = pack_bf2(acct[i][2], acct[i][3]);
+            unsigned* d = (unsigned*)(sA + lds_off(row, tcol >> 3) + (tcol & 7));
+            d[0] = lo;
+            d[1] = hi;
+            if (TF == 1) {   // columns 16..31 of the 32-wide step: explicit zeros (up_p is zero there too)
+                unsigned* z = (unsigned*)(sA + lds_off(row, (tcol + 16) >> 3) + (tcol & 7));
+                z[0] = 0u;
+                z[1] = 0u;
+            }
+            if (tout && tile_n == 0 && m0 + row < M) {
+                unsigned* g = (unsigned*)(tout + (int64_t)(m0 + row) * p.ld_tout + tcol);
+                g[0] = lo;
+                g[1] = hi;
+                if (TF == 1) { g[8] = 0u; g[9] = 0u; }   // columns 16..31 of the [M][32] image
+            }
+        }
+        wait_vmcnt<0>();
+        __syncthreads();
+        bf16x8 af[FM], wf[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(sA + lds_off(wave_m * WM + i * 16 + fr, fg));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(sB + lds_off(wave_n * WN + j * 16 + fr, fg));
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+    }
 
     // ---- epilogue through LDS: the accumulators (lane = one row x 4 consecutive n) are staged as fp32,
     // 64 tile rows at a time, so that the global side of the epilogue (residual / bias reads, bf16 or
@@ -452,16 +529,28 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const leco_gemm_args
     }
 }
 
-template <int BM, int BN, bool CONV, int NS, int NWM>
-void launch_ns(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
-    constexpr int lds_bytes = NS * (BM + BN) * BK * (int)sizeof(bf16_t);
+template <int BM, int BN, bool CONV, int NS, int NWM, int TF>
+void launch_k(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
+    constexpr int lds_bytes = NS * (BM + BN + 16 * TF) * BK * (int)sizeof(bf16_t);
+    static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
     static bool attr_set = false;
     if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, NS, NWM>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, NS, NWM, TF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, NS, NWM>), grid, dim3(NWM * 128), lds_bytes, s, a, rt);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, NS, NWM, TF>), grid, dim3(NWM * 128), lds_bytes, s, a, rt);
+}
+// fused LoRA down-projection variants exist for plain operands only; the ring loses one slot where the
+// extra lora_down rows would not fit in 160 KB
+template <int BM, int BN, bool CONV, int NS, int NWM>
+void launch_ns(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
+    if constexpr (!CONV) {
+        constexpr int NS2 = (NS * (BM + BN + 32) * BK * 2 <= 156 * 1024) ? NS : NS - 1;
+        if (a.t_w && a.t_rows == 16) return launch_k<BM, BN, CONV, NS, NWM, 1>(a, rt, grid, s);
+        if (a.t_w) return launch_k<BM, BN, CONV, NS2, NWM, 2>(a, rt, grid, s);
+    }
+    launch_k<BM, BN, CONV, NS, NWM, 0>(a, rt, grid, s);
 }
 
 // Pipeline shape by grid size.  Grids that put <= ~1.5 workgroups on a CU get the 4-deep DMA ring
@@ -470,9 +559,12 @@ void launch_ns(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t
 template <int BM, int BN, bool CONV>
 void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
     const long blocks = (long)grid.x * grid.y;
-    if (BM == 64) launch_ns<BM, BN, CONV, 4, 2>(a, rt, grid, s);
-    else if (blocks <= 384) launch_ns<BM, BN, CONV, 4, (BM >= 128 ? 4 : 2)>(a, rt, grid, s);
-    else launch_ns<BM, BN, CONV, 2, (BM >= 128 ? 4 : 2)>(a, rt, grid, s);
+    if constexpr (BM == 64) {
+        launch_ns<BM, BN, CONV, 4, 2>(a, rt, grid, s);
+    } else {
+        if (blocks <= 384) launch_ns<BM, BN, CONV, 4, 4>(a, rt, grid, s);
+        else launch_ns<BM, BN, CONV, 2, 4>(a, rt, grid, s);
+    }
 }
 
 template <int BM, int BN>
@@ -505,6 +597,13 @@ int validate(const leco_gemm_args& a) {
     if (!a.c && !a.c_f32) return fail(-EINVAL, "leco_gemm: no output");
     if (a.a_ext && a.ext_k != 32 && a.ext_k != 64) return fail(-EINVAL, "leco_gemm: ext_k=%d must be 32 or 64", a.ext_k);
     if (a.a_ext && !a.w_ext) return fail(-EINVAL, "leco_gemm: a_ext without w_ext");
+    if (a.t_w) {
+        if (a.a_ext) return fail(-EINVAL, "leco_gemm: t_w (fused down-projection) and a_ext are exclusive");
+        if (a.a_mode != LECO_A_PLAIN) return fail(-EINVAL, "leco_gemm: t_w needs a plain A operand");
+        if (!a.w_ext || a.ext_k != 32 || (a.t_rows != 16 && a.t_rows != 32) || a.ld_tw % 8 || a.ld_wext % 8 ||
+            (a.t_out && a.ld_tout % 8))
+            return fail(-EINVAL, "leco_gemm: t_w needs w_ext, ext_k == 32, t_rows in {16, 32}, 16-byte aligned strides");
+    }
     if (a.rowbias && a.rows_per_group <= 0) return fail(-EINVAL, "leco_gemm: rowbias needs rows_per_group");
     if (a.a_mode < LECO_A_PLAIN || a.a_mode > LECO_A_CONV3_TR2) return fail(-EINVAL, "leco_gemm: bad a_mode %d", a.a_mode);
     if ((a.lda0 | a.ldw | (a.a1 ? a.lda1 : 0) | (a.a_ext ? (a.ld_aext | a.ld_wext) : 0)) % 8)
@@ -570,6 +669,26 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         if (split_k > nk) split_k = nk;
     }
     if (split_k < 1) split_k = 1;
+    if (args->t_w && split_k > 1) {
+        // the fused down-projection cannot span K slices: keep the split (these are the latency-bound deep
+        // levels) and run the projection as its own skinny GEMM into t_out first
+        if (!args->t_out) split_k = 1;
+        else {
+            leco_gemm_args t{};
+            t.a0 = args->a0; t.a1 = args->a1; t.lda0 = args->lda0; t.lda1 = args->lda1; t.k_split = args->k_split;
+            t.a_mode = LECO_A_PLAIN;
+            t.w = args->t_w; t.ldw = args->ld_tw;
+            t.m = m; t.n = 32; t.k = args->k;
+            t.c = args->t_out; t.ldc = args->ld_tout;
+            rc = leco_gemm_ex(&t, 0, 1, nullptr, 0, stream);
+            if (rc) return rc;
+            leco_gemm_args main_args = *args;
+            main_args.t_w = nullptr;
+            main_args.a_ext = args->t_out;
+            main_args.ld_aext = args->ld_tout;
+            return leco_gemm_ex(&main_args, tile, split_k, workspace, workspace_bytes, stream);
+        }
+    }
     switch (tile) {
         case 1: return launch<128, 128>(*args, split_k, (float*)workspace, s);
         case 2: return launch<128, 160>(*args, split_k, (float*)workspace, s);

@@ -34,6 +34,7 @@ class GemmArgs(C.Structure):
         ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("act", C.c_int32),
         ("c", C.c_void_p), ("ldc", C.c_int64), ("c_f32", C.c_void_p), ("ldc32", C.c_int64),
+        ("t_w", C.c_void_p), ("ld_tw", C.c_int64), ("t_rows", C.c_int32), ("t_out", C.c_void_p), ("ld_tout", C.c_int64),
     ]
 
 
@@ -142,8 +143,10 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, 
               bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
               rows_per_group: int = 0, ld_rowbias: int = 0, residual: Optional[torch.Tensor] = None, ldr: int = 0,
               act: int = ACT_NONE, ldc: Optional[int] = None, out_f32: Optional[torch.Tensor] = None,
-              ldc32: int = 0) -> GemmArgs:
-    """Build the argument block for leco_gemm.  ``conv`` = (batch, h_out, w_out, h_in, w_in)."""
+              ldc32: int = 0, t_w: Optional[torch.Tensor] = None, t_rows: int = 0,
+              t_out: Optional[torch.Tensor] = None, ld_tout: int = 0) -> GemmArgs:
+    """Build the argument block for leco_gemm.  ``conv`` = (batch, h_out, w_out, h_in, w_in).
+    ``t_w`` ([32][k] stacked lora_down rows) selects the fused down-projection (see include/leco_hip.h)."""
     g = GemmArgs()
     g.a0 = ptr(a)
     g.a1 = ptr(a1)
@@ -164,6 +167,8 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, 
     g.act = act
     g.c, g.ldc = ptr(out), (n if ldc is None else ldc)
     g.c_f32, g.ldc32 = ptr(out_f32), ldc32 or n
+    g.t_w, g.ld_tw, g.t_rows = ptr(t_w), k, t_rows
+    g.t_out, g.ld_tout = ptr(t_out), ld_tout or 32
     return g
 
 

@@ -558,14 +558,20 @@ class PlanBuilder:
         self._last_T = None
         if lora is not None:
             T = self._last_T = self.act(name + ".loraT", rows, lora.Rp)
-            kw = dict(m=rows, n=lora.Rp, k=site.k, a_mode=amode, conv=conv)
-            if len(xs) == 2:
-                kw.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
-            g_t = gemm_args(a0, lora.dn_s, T.ptr, lda=lda0, ldc=T.ld, **kw)
-            self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T), ws=self.eng.workspace))
-            g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, a_ext=T.ptr, w_ext=lora.up_p, ext_k=lora.Rp,
-                             ld_aext=T.ld, ld_wext=lora.Rp, **common)
-            self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y), ws=self.eng.workspace))
+            if amode == A_PLAIN and lora.Rp == 32:
+                # down-projection fused into the main GEMM's K sweep (T is still written: lora_up wgrad)
+                g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, w_ext=lora.up_p, ext_k=32, ld_wext=32,
+                                 t_w=lora.dn_s, t_rows=lora.R16, t_out=T.ptr, ld_tout=T.ld, **common)
+                self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y, T), ws=self.eng.workspace))
+            else:
+                kw = dict(m=rows, n=lora.Rp, k=site.k, a_mode=amode, conv=conv)
+                if len(xs) == 2:
+                    kw.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
+                g_t = gemm_args(a0, lora.dn_s, T.ptr, lda=lda0, ldc=T.ld, **kw)
+                self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T), ws=self.eng.workspace))
+                g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, a_ext=T.ptr, w_ext=lora.up_p, ext_k=lora.Rp,
+                                 ld_aext=T.ld, ld_wext=lora.Rp, **common)
+                self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y), ws=self.eng.workspace))
         else:
             self.f_on.append(ops.gemm(g_off, ws=self.eng.workspace))
         if y is not None:

@@ -56,6 +56,45 @@ def test_gemm_split_k_with_epilogue_and_lora_tile(dev, tile, split):
     assert rel_err(o32, ref) < TOL32 and rel_err(out, ref) < TOLBF
 
 
+@pytest.mark.parametrize("tile,t_rows,split,M,N,K", [
+    (1, 16, 1, 300, 256, 320), (1, 32, 1, 300, 256, 320), (2, 16, 1, 200, 320, 192), (2, 32, 1, 200, 320, 192),
+    (3, 16, 1, 77, 64, 128), (3, 32, 1, 150, 72, 128), (4, 16, 1, 520, 256, 256), (4, 32, 1, 300, 128, 256),
+    (1, 16, 1, 2600, 640, 128),      # > 384 workgroups: the 2-buffer variant
+    (0, 16, 0, 256, 256, 2048),      # heuristic wants split-K: falls back to the separate projection
+    (0, 32, 0, 130, 200, 64)])
+def test_gemm_fused_lora_down_projection(dev, tile, t_rows, split, M, N, K):
+    """t_w: T = A t_w^T is formed inside the main GEMM's K sweep (bf16-rounded like the separate T GEMM),
+    used as the A side of the K-extension against scale*up, and optionally written out for the backward."""
+    torch.manual_seed(13)
+    R = 12 if t_rows == 16 else 24
+    a0 = torch.randn(M, 64).to(bf).to(dev); a1 = torch.randn(M, K - 64).to(bf).to(dev)
+    w = (torch.randn(N, K) / K ** 0.5).to(bf).to(dev)
+    tw = torch.zeros(32, K); tw[:R] = torch.randn(R, K) / K ** 0.5
+    tw = tw.to(bf).to(dev)
+    up = torch.zeros(N, 32); up[:, :R] = torch.randn(N, R) * 0.3
+    up = up.to(bf).to(dev)
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(bf).to(dev)
+    out = torch.zeros(M, N, dtype=bf, device=dev); o32 = torch.zeros(M, N, device=dev)
+    tout = torch.full((M, 32), 7.0, dtype=bf, device=dev)
+    ws = torch.empty(8 * M * N, device=dev)
+    g = hip.gemm_args(a0, w, out, m=M, n=N, k=K, lda=64, a1=a1, lda1=K - 64, k_split=64, w_ext=up, ext_k=32,
+                      bias=bias, residual=res, out_f32=o32, t_w=tw, t_rows=t_rows, t_out=tout)
+    hip.gemm(g, ops.default_stream(), tile, split, ws)
+    _sync(dev)
+    a = torch.cat([a0, a1], 1).float()
+    T = (a @ tw.float().T).to(bf)
+    ref = a @ w.float().T + T.float() @ up.float().T + bias + res.float()
+    assert rel_err(o32, ref) < TOL32 and rel_err(out, ref) < TOLBF
+    assert rel_err(tout[:, :R], T[:, :R]) < 1e-2 and float(tout[:, R:].float().abs().max()) == 0.0
+    # without t_out (LoRA-on passes that are never differentiated)
+    o32.zero_()
+    g2 = hip.gemm_args(a0, w, None, m=M, n=N, k=K, lda=64, a1=a1, lda1=K - 64, k_split=64, w_ext=up, ext_k=32,
+                       bias=bias, residual=res, out_f32=o32, t_w=tw, t_rows=t_rows)
+    hip.gemm(g2, ops.default_stream(), tile, 1, None)
+    _sync(dev)
+    assert rel_err(o32, ref) < TOL32
+
+
 def test_gemm_large_grid_two_buffer_variant(dev):
     """> 384 workgroups selects the 4-wave / 2-buffer pipeline (the small cases use the 8-wave / 4-deep ring)."""
     torch.manual_seed(12)
