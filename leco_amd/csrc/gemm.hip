@@ -26,6 +26,7 @@
 // remapped so each XCD (private L2) owns a contiguous run of tiles.  Deep-K / small-M problems
 // (the 8x8 and 16x16 levels) are split over K into fp32 partial slabs + a finishing kernel.
 #include <errno.h>
+#include <stdlib.h>
 #include <type_traits>
 #include <hip/hip_runtime.h>
 #include <leco_prims.h>
@@ -559,10 +560,16 @@ void launch_ns(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t
 template <int BM, int BN, bool CONV>
 void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
     const long blocks = (long)grid.x * grid.y;
+    static const long ns2_min_blocks = [] {   // tuning override: LECO_GEMM_NS2_MIN_BLOCKS.  Default: never -- since the
+        // K loop interleaves DMA issue with the MFMAs, one 8-wave workgroup per CU with the deep ring beats two
+        // resident workgroups with 2 buffers each (measured +1% on the whole step)
+        const char* e = getenv("LECO_GEMM_NS2_MIN_BLOCKS");
+        return e ? atol(e) : 1000000000L;
+    }();
     if constexpr (BM == 64) {
         launch_ns<BM, BN, CONV, 4, 2>(a, rt, grid, s);
     } else {
-        if (blocks <= 384) launch_ns<BM, BN, CONV, 4, 4>(a, rt, grid, s);
+        if (blocks <= ns2_min_blocks) launch_ns<BM, BN, CONV, 4, 4>(a, rt, grid, s);
         else launch_ns<BM, BN, CONV, 2, 4>(a, rt, grid, s);
     }
 }

@@ -2,14 +2,13 @@
 // HBM-bound: every kernel moves 16-byte (8 x bf16) vectors per lane; statistics are fp32.
 //
 // GroupNorm on [B][HW][C] with G groups of cg = C/G adjacent channels:
-//   gn_stats : per (sample, pixel-range) block; each thread owns 8 adjacent channels, sums
-//              x and x^2 over its pixels, folds them into per-group LDS bins, then one fp32
-//              atomicAdd pair per (block, group) into stats[b][g] = {sum, sumsq}.
-//   gn_apply : y = act((x - mean) * rstd * gamma + beta), act = SiLU or identity.
+//   one kernel (gn_block_kernel): a block owns all pixels of a few adjacent groups of one sample, so the
+//   statistics {sum, sumsq} and y = act((x - mean) * rstd * gamma + beta) (act = SiLU or identity) need no
+//   cross-block reduction; the second sweep over the same pixels hits in L2.
 // The input may be the channel-concat of two tensors (UNet skip connections): channels
 // [0,c0) come from x0, [c0,C) from x1 -- the concat is never materialised.
-// Backward (frozen gamma/beta => dgrad only): gn_bwd_stats accumulates {sum dxhat, sum dxhat*xhat}
-// per (b,g), gn_bwd_apply forms dx = rstd*(dxhat - s1/n - xhat*s2/n).
+// Backward (frozen gamma/beta => dgrad only): the same kernel in MODE 1 accumulates {sum dxhat, sum dxhat*xhat}
+// per (b,g) and forms dx = rstd*(dxhat - s1/n - xhat*s2/n).
 //
 // LayerNorm over the last dim (C <= 2048): one wave64 per row, two-pass statistics held in
 // registers, wave-shuffle reductions.
@@ -52,12 +51,183 @@ __device__ __forceinline__ u32x4 gn_load(const GnSrc& s, int64_t row, int c) {
 }
 
 constexpr int GN_MAX_GROUPS = 32;
+constexpr int GN_SEG = 16;           // row segments of the in-block reduction tree
+
+// One block = (sample b, a run of `gpb` adjacent groups whose channel span is a multiple of 8): the block owns
+// every pixel of those channels, so the statistics need no cross-block step -- no atomics, no partial
+// buffers, no finishing kernel, bitwise reproducible.  Thread t = (pixel lane t / nv, 16-byte channel
+// vector t % nv): consecutive threads read consecutive 16-byte pieces of a pixel's channel run.
+//   pass 1: per-thread sums over its pixels -> LDS [pixel lane][channel][2] -> fixed-order tree
+//           (row segments, then segments, then the cg channels of a group) -> group statistics
+//   pass 2: the same pixels again (L2-resident by now) -> normalise (+SiLU) / dgrad -> store.
+// MODE 0: forward, statistics {sum x, sum x^2} (also written to stats[b][g][2] for the backward).
+// MODE 1: backward, statistics {sum dxhat, sum dxhat*xhat}, dx = rstd*(dxhat - s1/n - xhat*s2/n).
+template <int MODE>
+__global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t* dy, int64_t lddy,
+                                                         const float* fstats, float* stats_out,
+                                                         const float* gamma, const float* beta, int act,
+                                                         float eps, int hw, int C, int G, int gpb,
+                                                         bf16_t* out, int64_t ldo) {
+    float* lds = (float*)dyn_lds();
+    const int tid = (int)threadIdx.x, NT = (int)blockDim.x;
+    const int b = (int)blockIdx.y, g0 = (int)blockIdx.x * gpb;
+    const int cg = C / G, chunkC = gpb * cg, nv = chunkC / 8, cbase = g0 * cg;
+    const int PL = NT / nv;                       // pixel lanes
+    const int pl = tid / nv, v = tid - pl * nv;
+    const bool active = pl < PL;
+    const int c = cbase + v * 8;
+    const float inv_n = 1.f / ((float)hw * (float)cg);
+    float* stage = lds;                            // [PL][chunkC][2]
+    float* part = stage + PL * chunkC * 2;         // [GN_SEG][chunkC][2]
+    float* chan = part + GN_SEG * chunkC * 2;      // [chunkC][2]
+    float* gs = chan + chunkC * 2;                 // [gpb][2]
+
+    float ga[8], be[8], mu[8], rs[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { ga[i] = 1.f; be[i] = 0.f; mu[i] = 0.f; rs[i] = 1.f; }
+    if (active) {
+        const f32x4 a0 = *(const f32x4*)(gamma + c), a1 = *(const f32x4*)(gamma + c + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ga[i] = a0[i]; ga[4 + i] = a1[i]; be[i] = b0[i]; be[4 + i] = b1[i]; }
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int g = (c + i) / cg;
+                const float m = fstats[(b * G + g) * 2] * inv_n;
+                const float var = fstats[(b * G + g) * 2 + 1] * inv_n - m * m;
+                mu[i] = m;
+                rs[i] = rsqrtf(fmaxf(var, 0.f) + eps);
+            }
+        }
+    }
+    // ---- pass 1
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    if (active) {
+        for (int p0 = pl; p0 < hw; p0 += 4 * PL) {
+            u32x4 xv[4], dv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = p0 + u * PL;
+                const int64_t row = (int64_t)b * hw + (p < hw ? p : p0);
+                xv[u] = gn_load(src, row, c);
+                if (MODE == 1) dv[u] = *(const u32x4*)(dy + row * lddy + c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p0 + u * PL >= hw) break;
+                float x[8];
+                unpack8(xv[u], x);
+                if (MODE == 0) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { s1[i] += x[i]; s2[i] += x[i] * x[i]; }
+                } else {
+                    float d[8];
+                    unpack8(dv[u], d);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float xh = (x[i] - mu[i]) * rs[i];
+                        float dz = d[i];
+                        if (act) dz *= dsilu(xh * ga[i] + be[i]);
+                        const float dxh = dz * ga[i];
+                        s1[i] += dxh;
+                        s2[i] += dxh * xh;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            stage[(pl * chunkC + v * 8 + i) * 2] = s1[i];
+            stage[(pl * chunkC + v * 8 + i) * 2 + 1] = s2[i];
+        }
+    }
+    __syncthreads();
+    const int pairs = chunkC * 2;
+    for (int t = tid; t < pairs * GN_SEG; t += NT) {          // rows seg, seg + GN_SEG, ...
+        const int seg = t / pairs, pr = t - seg * pairs;
+        float acc = 0.f;
+        for (int r = seg; r < PL; r += GN_SEG) acc += stage[r * pairs + pr];
+        part[t] = acc;
+    }
+    __syncthreads();
+    for (int t = tid; t < pairs; t += NT) {
+        float acc = 0.f;
+#pragma unroll
+        for (int sgi = 0; sgi < GN_SEG; ++sgi) acc += part[sgi * pairs + t];
+        chan[t] = acc;
+    }
+    __syncthreads();
+    if (tid < gpb * 2) {
+        const int g = tid >> 1, comp = tid & 1;
+        float acc = 0.f;
+        for (int k = 0; k < cg; ++k) acc += chan[(g * cg + k) * 2 + comp];
+        gs[tid] = acc;
+        stats_out[((int64_t)b * G + g0 + g) * 2 + comp] = acc;
+    }
+    __syncthreads();
+    if (!active) return;
+    // ---- pass 2
+    float t1[8], t2[8];   // MODE 0: mean, rstd.  MODE 1: s1/n, s2/n
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int g = (v * 8 + i) / cg;
+        const float q1 = gs[g * 2] * inv_n, q2 = gs[g * 2 + 1] * inv_n;
+        if (MODE == 0) {
+            t1[i] = q1;
+            t2[i] = rsqrtf(fmaxf(q2 - q1 * q1, 0.f) + eps);
+        } else {
+            t1[i] = q1;
+            t2[i] = q2;
+        }
+    }
+    for (int p0 = pl; p0 < hw; p0 += 4 * PL) {
+        u32x4 xv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * PL;
+            const int64_t row = (int64_t)b * hw + (p < hw ? p : p0);
+            xv[u] = gn_load(src, row, c);
+            if (MODE == 1) dv[u] = *(const u32x4*)(dy + row * lddy + c);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + u * PL;
+            if (p >= hw) break;
+            float x[8], o[8];
+            unpack8(xv[u], x);
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float z = (x[i] - t1[i]) * t2[i] * ga[i] + be[i];
+                    o[i] = act ? silu(z) : z;
+                }
+            } else {
+                float d[8];
+                unpack8(dv[u], d);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float xh = (x[i] - mu[i]) * rs[i];
+                    float dz = d[i];
+                    if (act) dz *= dsilu(xh * ga[i] + be[i]);
+                    const float dxh = dz * ga[i];
+                    o[i] = rs[i] * (dxh - t1[i] - xh * t2[i]);
+                }
+            }
+            *(u32x4*)(out + ((int64_t)b * hw + p) * ldo + c) = pack8(o);
+        }
+    }
+}
+
 constexpr int GN_MAX_PARTS = 256;  // pixel-range blocks per sample
 constexpr int GN_LDS_FLOATS = 2 * 2560 * 2;  // [rows_par][C][2] staging, rows_par * C <= 5120
 
-// Deterministic two-stage statistics (no atomics: results are bitwise reproducible run to run).
-// stage 1 (gn_stats): block (part, b) reduces its pixel range to part[b][part][g][2];
-// stage 2 (prologue of gn_apply): every apply block re-reduces the <= 64 partials of its sample.
+// ---- multi-block path for LARGE samples (few (sample, group-run) blocks, > ~200 KB each): three launches.
+// Deterministic statistics (no atomics: results are bitwise reproducible run to run):
+// gn_stats: block (part, b) reduces its pixel range to part[b][part][g][2]; gn_finish sums the parts in a
+// fixed order; gn_apply normalises.
 // MODE 0: forward stats {sum x, sum x^2}.  MODE 1: backward stats {sum dxhat, sum dxhat*xhat}.
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc src, const bf16_t* dy, int64_t lddy,
@@ -319,6 +489,42 @@ int pix_per_block(int batch, int hw, int c) {
     int ppb = cdiv(hw, nblk);
     return ppb < 12 ? 12 : ppb;
 }
+// launch geometry of gn_block_kernel: groups per block (channel span % 8 == 0), threads, LDS bytes
+struct GnGeom { int gpb, threads, lds; };
+GnGeom gn_geom(int hw, int C, int G) {
+    const int cg = C / G;
+    int gpb = 1;
+    while ((gpb * cg) % 8) gpb *= 2;                 // cg even (C % 8 == 0, G = 2^k): gpb in {1, 2, 4}
+    const int nv = gpb * cg / 8;
+    int64_t want = (int64_t)hw * nv;                 // one thread per (pixel, vector) if the block allows it
+    int threads = want >= 1024 ? 1024 : (int)((want + 63) / 64 * 64);
+    if (threads < 256) threads = 256;
+    if (threads < nv) threads = (nv + 63) / 64 * 64;
+    const int PL = threads / nv, chunkC = gpb * cg;
+    const int lds = (PL * chunkC * 2 + GN_SEG * chunkC * 2 + chunkC * 2 + gpb * 2) * (int)sizeof(float);
+    return GnGeom{gpb, threads, lds};
+}
+// One block per (sample, group run) is the fastest shape while a block's slice stays small or there are
+// enough of them to fill the chip; large slices on few blocks (the 64x64 / 32x32 levels at batch 4) are
+// bandwidth-starved (measured 41 vs 22 us for 4 x 4096 x 320) and take the pixel-parallel three-launch path.
+bool gn_use_block_kernel(const GnGeom& ge, int batch, int hw, int C, int G) {
+    const int64_t slice_bytes = (int64_t)hw * (C / G) * ge.gpb * 2;
+    const int blocks = batch * (G / ge.gpb);
+    return !(slice_bytes > 200 * 1024 && blocks < 96);
+}
+template <int MODE>
+void gn_launch(const GnGeom& ge, dim3 grid, hipStream_t s, GnSrc src, const bf16_t* dy, int64_t lddy,
+               const float* fstats, float* stats_out, const float* gamma, const float* beta, int act, float eps,
+               int hw, int C, int G, bf16_t* out, int64_t ldo) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_block_kernel<MODE>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gn_block_kernel<MODE>), grid, dim3(ge.threads), ge.lds, s, src, dy, lddy, fstats, stats_out,
+                       gamma, beta, act, eps, hw, C, G, ge.gpb, out, ldo);
+}
 }  // namespace
 }  // namespace leco
 
@@ -330,8 +536,14 @@ extern "C" int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, i
                                   void* y, int64_t ldy, leco_stream_t stream) {
     int rc = gn_check(c, groups, c0, x1);
     if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
     GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
+    const GnGeom ge = gn_geom(hw, c, groups);
+    hipStream_t s = (hipStream_t)stream;
+    if (gn_use_block_kernel(ge, batch, hw, c, groups)) {
+        gn_launch<0>(ge, dim3(groups / ge.gpb, batch), s, src, (const bf16_t*)nullptr, (int64_t)0,
+                     (const float*)nullptr, stats, gamma, beta, act, eps, hw, c, groups, (bf16_t*)y, ldy);
+        return check_launch("leco_groupnorm_fwd");
+    }
     const int ppb = pix_per_block(batch, hw, c);
     const int nparts = cdiv(hw, ppb);
     float* part = stats + (int64_t)batch * groups * 2;   // scratch tail of the stats buffer
@@ -354,8 +566,14 @@ extern "C" int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, i
                                   leco_stream_t stream) {
     int rc = gn_check(c, groups, c0, x1);
     if (rc) return rc;
-    hipStream_t s = (hipStream_t)stream;
     GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
+    const GnGeom ge = gn_geom(hw, c, groups);
+    hipStream_t s = (hipStream_t)stream;
+    if (gn_use_block_kernel(ge, batch, hw, c, groups)) {
+        gn_launch<1>(ge, dim3(groups / ge.gpb, batch), s, src, (const bf16_t*)dy, lddy, stats, bstats,
+                     gamma, beta, act, eps, hw, c, groups, (bf16_t*)dx, lddx);
+        return check_launch("leco_groupnorm_bwd");
+    }
     const int ppb = pix_per_block(batch, hw, c);
     const int nparts = cdiv(hw, ppb);
     float* part = bstats + (int64_t)batch * groups * 2;

@@ -176,16 +176,24 @@ def test_conv3x3_modes(dev, mode):
     assert rel_err(got, ref) < TOL32
 
 
-@pytest.mark.parametrize("act", [0, 1])
-def test_groupnorm_fwd_bwd(dev, act):
+@pytest.mark.parametrize("act,B,HW,C0,C1,G", [
+    (0, 2, 37, 64, 128, 32),      # cg = 6 -> 4 groups per block, two-source
+    (1, 2, 37, 64, 128, 32),
+    (1, 3, 300, 320, 0, 32),      # cg = 10 (SD1.5 level 0): 40-channel blocks, more pixels than pixel lanes
+    (1, 1, 70, 640, 320, 32),     # cg = 30, concat split inside a block's channel run
+    (0, 2, 16, 64, 0, 32),        # cg = 2 (tiny config): 4 groups inside one 8-channel vector
+    (1, 2, 9, 1280, 1280, 32),    # cg = 80: one group per block
+    (1, 1, 2600, 320, 0, 32)])    # > 200 KB per (sample, group run) on few blocks: pixel-parallel three-launch path
+def test_groupnorm_fwd_bwd(dev, act, B, HW, C0, C1, G):
     torch.manual_seed(3)
-    B, HW, C0, C1, G = 2, 37, 64, 128, 32
     C = C0 + C1
-    x0 = torch.randn(B * HW, C0).to(bf).to(dev); x1 = (torch.randn(B * HW, C1) * 2 + 0.5).to(bf).to(dev)
+    x0 = torch.randn(B * HW, C0).to(bf).to(dev)
+    x1 = (torch.randn(B * HW, C1) * 2 + 0.5).to(bf).to(dev) if C1 else None
     gamma = torch.randn(C).to(dev); beta = torch.randn(C).to(dev)
     stats = torch.zeros(B * G * 2 * 257, device=dev); y = torch.zeros(B * HW, C, dtype=bf, device=dev)
     ops.groupnorm_fwd(x0, C0, x1, C1, C0, gamma, beta, B, HW, C, G, 1e-5, act, stats, y, C).run()
-    xc = torch.cat([x0, x1], 1).float().cpu().reshape(B, HW, C).permute(0, 2, 1).requires_grad_(True)
+    xcat = torch.cat([x0, x1], 1) if C1 else x0
+    xc = xcat.float().cpu().reshape(B, HW, C).permute(0, 2, 1).requires_grad_(True)
     ref = F.group_norm(xc, G, gamma.cpu(), beta.cpu(), 1e-5)
     ref = F.silu(ref) if act else ref
     dy = torch.randn(B * HW, C).to(bf).to(dev); bstats = torch.zeros(B * G * 2 * 257, device=dev)
@@ -195,6 +203,10 @@ def test_groupnorm_fwd_bwd(dev, act):
     ref.backward(dy.float().cpu().reshape(B, HW, C).permute(0, 2, 1))
     assert rel_err(y.cpu().reshape(B, HW, C).permute(0, 2, 1), ref) < TOLBF
     assert rel_err(dx.cpu().reshape(B, HW, C).permute(0, 2, 1), xc.grad) < TOLBF
+    # statistics are published for the backward: {sum x, sum x^2} per (sample, group)
+    xs = xcat.float().cpu().reshape(B, HW, G, C // G)
+    s_ref = torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], -1).reshape(-1)
+    assert rel_err(stats[:B * G * 2].cpu(), s_ref) < 1e-4
 
 
 @pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64)])
