@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <leco_prims.h>
 #include <math.h>
+#include <type_traits>
 
 #include "common.h"
 
@@ -39,9 +40,15 @@ constexpr int KT = 64;  // keys per tile
 #ifndef LECO_ATTN_ABLATE
 #define LECO_ATTN_ABLATE 0
 #endif
+// forward-softmax variants (bit mask): 1 = full tiles skip the key-bound masking, 2 = ... and fold the scale into
+// an fma in front of exp2.  0 in the product build: on gfx950 both variants measured SLOWER (246 / 258 vs 228 us for 4x8x4096^2x40)
+// although they remove a third of the VALU instructions -- kept for tools/ablate_attn.py.
+#ifndef LECO_ATTN_OPT
+#define LECO_ATTN_OPT 0
+#endif
 
 template <int D, int QF>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void attn_fwd_kernel(AttnArgs p) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int NKS = DK / 32, NFD = DV / 16, NDC = D / 8;
     constexpr int KROW = DK + 8;   // padded K row (elements)
@@ -132,6 +139,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
         __syncthreads();
         if (kv0 + KT < p.skv && LECO_ATTN_ABLATE != 2) fetch(kv0 + KT);
 
+        auto compute = [&](auto mask_c) {
+        constexpr bool MASK = decltype(mask_c)::value;
         // S^T = K Q^T : lane holds S[q = fr][key = kv0 + 16 f + 4 fg + r]
         f32x4 acc_s[QF][4];
 #pragma unroll
@@ -152,25 +161,32 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
             }
         }
 
-        // online softmax per owned query row; P^T operand built in registers
-        // (measured on gfx950: this plain form -- scale, mask, max, exp2 -- is ~7 % faster than folding the
-        //  scale into an fma inside exp2 and masking only the partial tile)
+        // online softmax per owned query row; P^T operand built in registers.  Full tiles (MASK = false) skip
+        // the key-bound compares / selects and fold the scale into one fma in front of exp2; the ragged last
+        // tile keeps the plain scale -> mask -> max -> exp2 form.
         u32x4 pw[QF][2];
         float alpha[QF];
 #pragma unroll
         for (int u = 0; u < QF; ++u) {
+            constexpr bool FOLD = !MASK && (LECO_ATTN_OPT & 2);
             float mx = -INFINITY;
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = kv0 + 16 * f + 4 * fg + r;
-                    float sv = key < p.skv ? acc_s[u][f][r] * p.scale_log2 : -INFINITY;
-                    acc_s[u][f][r] = sv;
-                    mx = fmaxf(mx, sv);
+                    if (FOLD) {
+                        mx = fmaxf(mx, acc_s[u][f][r]);          // raw scores; scale applied once to the max
+                    } else {
+                        const int key = kv0 + 16 * f + 4 * fg + r;
+                        float sv = acc_s[u][f][r] * p.scale_log2;
+                        if (MASK) sv = key < p.skv ? sv : -INFINITY;
+                        acc_s[u][f][r] = sv;
+                        mx = fmaxf(mx, sv);
+                    }
                 }
             mx = fmaxf(mx, shfl_xor(mx, 16));
             mx = fmaxf(mx, shfl_xor(mx, 32));
+            if (FOLD) mx *= p.scale_log2;
             const float m_new = fmaxf(m_run[u], mx);
             alpha[u] = fast_exp2(m_run[u] - m_new);
             m_run[u] = m_new;
@@ -178,7 +194,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 float e0, e1, e2, e3;
-                if (LECO_ATTN_ABLATE != 1) {
+                if (FOLD) {
+                    e0 = fast_exp2(fmaf(acc_s[u][f][0], p.scale_log2, -m_new));
+                    e1 = fast_exp2(fmaf(acc_s[u][f][1], p.scale_log2, -m_new));
+                    e2 = fast_exp2(fmaf(acc_s[u][f][2], p.scale_log2, -m_new));
+                    e3 = fast_exp2(fmaf(acc_s[u][f][3], p.scale_log2, -m_new));
+                } else if (LECO_ATTN_ABLATE != 1) {
                     e0 = fast_exp2(acc_s[u][f][0] - m_new); e1 = fast_exp2(acc_s[u][f][1] - m_new);
                     e2 = fast_exp2(acc_s[u][f][2] - m_new); e3 = fast_exp2(acc_s[u][f][3] - m_new);
                 } else {
@@ -215,6 +236,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs p) {
                 }
             }
         }
+        };
+        if ((LECO_ATTN_OPT & 1) && kv0 + KT <= p.skv) compute(std::false_type{});
+        else compute(std::true_type{});
     }
 
     bf16_t* ob = p.o + (int64_t)b * p.bso + (int64_t)h * D;
@@ -288,7 +312,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(AttnBwdArgs p, int batc
 }
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(2) void attn_bwd_dq_kernel(AttnBwdArgs p) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int NKS = DK / 32, NFD = DV / 16, NDC = D / 8;
     constexpr int KROW = DK + 8, VROW = KT + 8;
@@ -395,7 +419,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnBwdArgs p) {
 constexpr int QT = 32;  // query rows per tile in the dK/dV kernel
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
+__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(2) void attn_bwd_dkv_kernel(AttnBwdArgs p) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int NKS = DK / 32, NFD = DV / 16, NDC = D / 8;
     constexpr int KROW = DK + 8, TROW = QT + 8;

@@ -70,6 +70,10 @@ __device__ __forceinline__ void lds_wait() {
 __device__ __forceinline__ void lds_tie(bf16x8& v) { asm volatile("" : "+v"(v)); }
 // scheduling fence: the compiler moves no instruction across it
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// Occupancy floor for a kernel (waves per SIMD).  Besides capping the register budget it makes the compiler
+// keep MFMA accumulators in VGPRs: with a budget above 256 registers it places them in AGPRs and every VALU
+// touch of an accumulator (softmax rescale of O) costs a v_accvgpr_read / v_accvgpr_write pair.
+#define LECO_MIN_WAVES_PER_SIMD(n) __attribute__((amdgpu_waves_per_eu(n)))
 // launch-time sized LDS (up to 160 KB per workgroup on gfx950)
 extern __shared__ __attribute__((aligned(16))) unsigned char leco_dyn_lds_[];
 __device__ __forceinline__ unsigned char* dyn_lds() { return leco_dyn_lds_; }

@@ -55,6 +55,7 @@ static inline void glds16(const void* gsrc, void* lds_wave_base) {
 }
 template <int N>
 static inline void wait_vmcnt() {}          // the emulated DMA completes immediately
+#define LECO_MIN_WAVES_PER_SIMD(n)
 static inline bf16x8 lds_read16_async(const void* lds_ptr) { return *(const bf16x8*)lds_ptr; }
 template <int N>
 static inline void lds_wait() {}

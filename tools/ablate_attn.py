@@ -1,4 +1,6 @@
-"""Attention-forward ablation on the GPU box (variants built with -DLECO_ATTN_ABLATE=n)."""
+"""Attention-forward ablation on the GPU box.  argv: integers n build -DLECO_ATTN_ABLATE=n, `optN` builds
+-DLECO_ATTN_OPT=N (softmax variants), a path names a prebuilt library.  Variants are cached under tools/_ablate
+so they can be built in the (GPU-less) dev container and travel with the snapshot (`--build-only`)."""
 import os
 import subprocess
 import sys
@@ -14,9 +16,16 @@ dev = torch.device("cuda:0")
 
 
 def build_variant(v):
-    out = f"/tmp/libleco_attn{v}.so"
+    if os.path.exists(str(v)):
+        return str(v)
+    d = os.path.join(ROOT, "tools", "_ablate")
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, f"libleco_attn_{v}.so")
+    if os.path.exists(out) and os.path.getmtime(out) > os.path.getmtime(os.path.join(B.CSRC, "attention.hip")):
+        return out
+    define = f"-DLECO_ATTN_OPT={str(v)[3:]}" if str(v).startswith("opt") else f"-DLECO_ATTN_ABLATE={v}"
     srcs = [os.path.join(B.CSRC, f) for f in sorted(os.listdir(B.CSRC)) if f.endswith((".hip", ".cpp"))]
-    subprocess.run([B.HIPCC, *B.FLAGS, f"-DLECO_ATTN_ABLATE={v}", "-shared", "-x", "hip", *srcs, "-o", out], check=True)
+    subprocess.run([B.HIPCC, *B.FLAGS, define, "-shared", "-x", "hip", *srcs, "-o", out], check=True)
     return out
 
 
@@ -33,13 +42,20 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-for v in [int(a) for a in sys.argv[1:]] or [0, 1, 2, 3, 4]:
-    hip._use_library(build_variant(v) if v else hip.LIB_PATH)
-    for (Bq, H, Sq, Skv, D) in [(4, 8, 4096, 4096, 40), (4, 8, 1024, 1024, 80), (4, 5, 9216, 9216, 64)]:
+VARIANTS = [a for a in sys.argv[1:] if a != "--build-only"] or ["0", "1", "2", "3", "4"]
+if "--build-only" in sys.argv:
+    for v in VARIANTS:
+        if v != "0":
+            print(build_variant(v))
+    sys.exit(0)
+for v in VARIANTS:
+    hip._use_library(build_variant(v) if v != "0" else hip.LIB_PATH)
+    for (Bq, H, Sq, Skv, D) in [(4, 8, 4096, 4096, 40), (12, 8, 4096, 4096, 40), (4, 8, 4096, 77, 40), (4, 8, 1024, 1024, 80),
+                                (4, 8, 256, 256, 160), (4, 5, 9216, 9216, 64)]:
         C = H * D
         q = torch.randn(Bq, Sq, C, device=dev).to(bf); k = torch.randn(Bq, Skv, C, device=dev).to(bf)
         vv = torch.randn(Bq, Skv, C, device=dev).to(bf); o = torch.empty_like(q); lse = torch.empty(Bq, H, Sq, device=dev)
         op = ops.attention_fwd(q.data_ptr(), C, Sq * C, k.data_ptr(), C, Skv * C, vv.data_ptr(), C, Skv * C, o.data_ptr(), C,
                                Sq * C, lse, Bq, H, Sq, Skv, D, D ** -0.5)
         t = timeit(lambda: op.run(None))
-        print(f"ablate={v} S={Sq} D={D}: {t:8.1f} us ({4.0*Bq*H*Sq*Skv*D/t/1e6:7.1f} TF/s nominal)", flush=True)
+        print(f"variant={os.path.basename(str(v)):22s} B={Bq} S={Sq}x{Skv} D={D}: {t:8.1f} us ({4.0*Bq*H*Sq*Skv*D/t/1e6:7.1f} TF/s nominal)", flush=True)
