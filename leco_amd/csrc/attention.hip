@@ -52,10 +52,14 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr int NKS = DK / 32, NFD = DV / 16, NDC = D / 8;
     constexpr int KROW = DK + 8;   // padded K row (elements)
-    constexpr int VROW = KT + 8;   // padded V^T row (elements)
-    __shared__ __attribute__((aligned(16))) bf16_t smem[KT * KROW + DV * VROW];
-    bf16_t* sK = smem;
-    bf16_t* sV = smem + KT * KROW;
+    // V stays ROW-major in LDS ([key][d], staged with the same 16-byte stores as K); the PV operand
+    // (8 consecutive keys of one channel per lane) is gathered by the hardware transpose read
+    // ds_read_b64_tr_b16.  Row stride = an odd multiple of 32 bytes, so the eight 32-byte row segments a
+    // 32-lane half reads land on disjoint banks.
+    constexpr int VRB0 = (DV * 2 + 31) / 32 * 32, VRB = ((VRB0 / 32) % 2) ? VRB0 : VRB0 + 32;
+    constexpr int VROW = VRB / 2;  // V row stride (elements)
+    constexpr int BUF = KT * KROW + KT * VROW;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * BUF];   // two K|V tile buffers: one barrier per tile
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -65,9 +69,6 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
     const bf16_t* qb = p.q + (int64_t)b * p.bsq + (int64_t)h * D;
     const bf16_t* kb = p.k + (int64_t)b * p.bsk + (int64_t)h * D;
     const bf16_t* vb = p.v + (int64_t)b * p.bsv + (int64_t)h * D;
-
-    // zero the V^T rows [D, DV) once (never written by the tile loads)
-    for (int e = tid; e < DV * VROW; e += 256) sV[e] = 0;
 
     // Q fragments (MFMA B operand: col = query row, k = head-dim)
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
@@ -94,11 +95,9 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
     }
 
     // K/V tiles are register-staged one tile ahead: the global loads of tile t+1 are issued before the
-    // MFMAs of tile t and written to LDS after the next barrier (latency hidden behind compute).
-    // K chunks: thread e -> (key = e / NDC, ch = e % NDC) (coalesced rows, 16-byte LDS stores).
-    // V chunks: thread e -> (ch = e / KT, key = e % KT): a wave's 64 lanes hold 64 consecutive keys of one
-    // channel chunk, so each of the 8 transposing 2-byte LDS stores writes 128 contiguous bytes of one
-    // V^T row (conflict-free); the price is a strided (L2-served) global read.
+    // MFMAs of tile t and written into the OTHER LDS buffer after them (latency hidden behind compute, one
+    // barrier per tile).  K and V chunks: thread e -> (key = e / NDC, ch = e % NDC): coalesced rows, one
+    // 16-byte LDS store each.
     constexpr int NLD = (KT * NDC + 255) / 256;   // 16-byte chunks per thread per operand
     u32x4 kreg[NLD], vreg[NLD];
     auto fetch = [&](int kv0) {
@@ -108,36 +107,42 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
             const int key = e / NDC, ch = e - key * NDC;
             const bool ok = e < KT * NDC && kv0 + key < p.skv;
             kreg[i] = ok ? *(const u32x4*)(kb + (int64_t)(kv0 + key) * p.ldk + ch * 8) : zero4;
-            const int vch = e / KT, vkey = e - vch * KT;
-            const bool vok = e < KT * NDC && kv0 + vkey < p.skv;
-            vreg[i] = vok ? *(const u32x4*)(vb + (int64_t)(kv0 + vkey) * p.ldv + vch * 8) : zero4;
+            vreg[i] = ok ? *(const u32x4*)(vb + (int64_t)(kv0 + key) * p.ldv + ch * 8) : zero4;
         }
     };
-    // zero the K columns [D, DK) once (the staged chunks only cover [0, D))
-    for (int e = tid; e < KT * (DK / 8 - NDC); e += 256) {
-        const int key = e / (DK / 8 - NDC), ch = NDC + e % (DK / 8 - NDC);
-        *(u32x4*)(sK + key * KROW + ch * 8) = zero4;
-    }
-    fetch(0);
-    for (int kv0 = 0; kv0 < p.skv; kv0 += KT) {
-        __syncthreads();
+    auto stash = [&](int buf) {   // staged registers -> LDS buffer `buf`
+        bf16_t* dK = smem + buf * BUF;
+        bf16_t* dV = dK + KT * KROW;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int e = tid + 256 * i;
             if (e < KT * NDC && LECO_ATTN_ABLATE != 2) {
                 const int key = e / NDC, ch = e - key * NDC;
-                *(u32x4*)(sK + key * KROW + ch * 8) = kreg[i];
-                const int vch = e / KT, vkey = e - vch * KT;
-                const u32x4 t = vreg[i];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    sV[(vch * 8 + 2 * j) * VROW + vkey] = (bf16_t)(t[j] & 0xffffu);
-                    sV[(vch * 8 + 2 * j + 1) * VROW + vkey] = (bf16_t)(t[j] >> 16);
-                }
+                *(u32x4*)(dK + key * KROW + ch * 8) = kreg[i];
+                *(u32x4*)(dV + key * VROW + ch * 8) = vreg[i];
             }
         }
-        __syncthreads();
-        if (kv0 + KT < p.skv && LECO_ATTN_ABLATE != 2) fetch(kv0 + KT);
+    };
+    // zero the K columns [D, DK) and V columns [D, DV) of both buffers once (the staged chunks cover [0, D))
+    for (int e = tid; e < 2 * KT * (DK / 8 - NDC); e += 256) {
+        const int buf = e / (KT * (DK / 8 - NDC)), r = e - buf * (KT * (DK / 8 - NDC));
+        const int key = r / (DK / 8 - NDC), ch = NDC + r % (DK / 8 - NDC);
+        *(u32x4*)(smem + buf * BUF + key * KROW + ch * 8) = zero4;
+    }
+    if (DV > D) {
+        for (int e = tid; e < 2 * KT; e += 256) {
+            const int buf = e / KT, key = e - buf * KT;
+            *(u32x4*)(smem + buf * BUF + KT * KROW + key * VROW + NDC * 8) = zero4;
+        }
+    }
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int kv0 = 0, tile = 0; kv0 < p.skv; kv0 += KT, ++tile) {
+        const bf16_t* sK = smem + (tile & 1) * BUF;
+        const bf16_t* sV = sK + KT * KROW;
+        const bool more = kv0 + KT < p.skv;
+        if (more && LECO_ATTN_ABLATE != 2) fetch(kv0 + KT);
 
         auto compute = [&](auto mask_c) {
         constexpr bool MASK = decltype(mask_c)::value;
@@ -224,9 +229,11 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
             }
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bf16_t* row = sV + (16 * fd + fr) * VROW + 4 * fg;
-                u32x2 lo = *(const u32x2*)(row + 16 * (2 * s));
-                u32x2 hi = *(const u32x2*)(row + 16 * (2 * s + 1));
+                // 16-lane group fg gathers the [4 keys][16 d] blocks of keys 16 (2s + h) + 4 fg .. + 3: lane i
+                // of the group addresses row i / 4, columns 4 (i % 4) .. + 3 and receives column i (4 keys)
+                const bf16_t* blk = sV + (16 * (2 * s) + 4 * fg + (fr >> 2)) * VROW + 16 * fd + 4 * (fr & 3);
+                const u32x2 lo = lds_read_tr16(blk);
+                const u32x2 hi = lds_read_tr16(blk + 16 * VROW);
                 u32x4 t = {lo[0], lo[1], hi[0], hi[1]};
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, t);
 #pragma unroll
@@ -239,6 +246,8 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
         };
         if ((LECO_ATTN_OPT & 1) && kv0 + KT <= p.skv) compute(std::false_type{});
         else compute(std::true_type{});
+        if (more) stash((tile + 1) & 1);
+        __syncthreads();
     }
 
     bf16_t* ob = p.o + (int64_t)b * p.bso + (int64_t)h * D;

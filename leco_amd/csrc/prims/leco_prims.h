@@ -62,6 +62,15 @@ __device__ __forceinline__ bf16x8 lds_read16_async(const void* lds_ptr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
     return v;
 }
+// Hardware transpose read (ds_read_b64_tr_b16): every lane passes the address of 4 consecutive bf16; inside each
+// group of 16 lanes the 16 x 4 elements are exchanged so that lane c receives element (c & 3) of lanes
+// c/4, 4 + c/4, 8 + c/4, 12 + c/4 -- i.e. with lane i addressing row i/4, columns 4(i%4).. of a [4][16] block,
+// lane c gets column c (4 rows): an MFMA operand gathered from a row-major tile without a transposing store.
+__device__ __forceinline__ u32x2 lds_read_tr16(const void* lds_ptr) {
+    typedef __attribute__((ext_vector_type(4))) short s4;
+    const s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)lds_ptr);
+    return __builtin_bit_cast(u32x2, v);
+}
 // wait until at most N LDS (lgkm) operations of this wave are outstanding
 template <int N>
 __device__ __forceinline__ void lds_wait() {

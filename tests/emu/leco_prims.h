@@ -57,6 +57,18 @@ template <int N>
 static inline void wait_vmcnt() {}          // the emulated DMA completes immediately
 #define LECO_MIN_WAVES_PER_SIMD(n)
 static inline bf16x8 lds_read16_async(const void* lds_ptr) { return *(const bf16x8*)lds_ptr; }
+static inline u32x2 lds_read_tr16(const void* lds_ptr) {
+    unsigned long long mine;
+    memcpy(&mine, lds_ptr, 8);
+    const unsigned char* all = emu::wave_gather(&mine, 8);
+    const int l = emu::lane(), g = l >> 4, c = l & 15;
+    unsigned short out[4];
+    for (int j = 0; j < 4; ++j) memcpy(&out[j], all + (size_t)(16 * g + 4 * j + (c >> 2)) * emu::kSlot + 2 * (c & 3), 2);
+    u32x2 r;
+    r[0] = (unsigned)out[0] | ((unsigned)out[1] << 16);
+    r[1] = (unsigned)out[2] | ((unsigned)out[3] << 16);
+    return r;
+}
 template <int N>
 static inline void lds_wait() {}
 static inline void lds_tie(bf16x8&) {}
