@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <leco_prims.h>
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -561,7 +562,14 @@ int launch_bwd(const AttnBwdArgs& a, int batch, hipStream_t s) {
 
 template <int D>
 int launch_fwd(const AttnArgs& a, int batch, hipStream_t s) {
-    if (a.sq >= 1024) {
+    static const int force_qf = [] {   // tuning override: LECO_ATTN_QF = 1 | 2 (query fragments per wave)
+        const char* e = getenv("LECO_ATTN_QF");
+        return e ? atoi(e) : 0;
+    }();
+    // two query fragments per wave halve the K/V traffic per query but also the workgroup count: worth it once
+    // there are still >= 4 workgroups per CU (measured: 4x8x4096^2x40 218 vs 238 us, 4x8x1024^2x80 35.8 vs 31.8 us)
+    const long wgs2 = (long)cdiv(a.sq, 128) * a.heads * batch;
+    if (force_qf ? force_qf == 2 : wgs2 >= 1024) {
         hipLaunchKernelGGL((attn_fwd_kernel<D, 2>), dim3(cdiv(a.sq, 128), a.heads, batch), dim3(256), 0, s, a);
     } else {
         hipLaunchKernelGGL((attn_fwd_kernel<D, 1>), dim3(cdiv(a.sq, 64), a.heads, batch), dim3(256), 0, s, a);
