@@ -44,7 +44,12 @@ enum {
     LECO_A_CONV3_UP2 = 3,  /* 3x3 pad 1 on the nearest-2x upsampled input (Upsample2D) */
     LECO_A_CONV3_TR2 = 4   /* transposed stride-2 gather: dgrad of LECO_A_CONV3_S2 */
 };
-enum { LECO_ACT_NONE = 0, LECO_ACT_SILU = 1 };
+/* LECO_ACT_GEGLU (leco_gemm only): the GEMM is the GEGLU input projection (diffusers GEGLU.proj, N = 2F) with its
+ * weight / bias / w_ext ROWS interleaved in blocks of 64 -- row 128 j + r holds value row 64 j + r (r < 64) or gate
+ * row F + 64 j + (r - 64) (r >= 64) -- so one 128-column tile owns a value block and its gate block: the epilogue
+ * writes value * gelu(gate) (erf form) as bf16 [M][F] (row stride ldc) and the [M][2F] intermediate never
+ * exists.  Needs n % 128 == 0, c != NULL, no residual / rowbias / c_f32, no split-K. */
+enum { LECO_ACT_NONE = 0, LECO_ACT_SILU = 1, LECO_ACT_GEGLU = 2 };
 
 typedef struct leco_gemm_args {
     const void* a0;       /* bf16 */
@@ -107,6 +112,7 @@ typedef struct leco_lora_site {
     void* up_p;
     void* up_t;
     void* dn_p;
+    void* up_pg;         /* optional: a second copy of up_p with the LECO_ACT_GEGLU row interleave (or NULL) */
 } leco_lora_site;
 
 int leco_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_stream_t stream);

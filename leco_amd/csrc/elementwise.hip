@@ -340,6 +340,11 @@ __global__ __launch_bounds__(256) void lora_pack_kernel(const leco_lora_site* si
             if (j >= g * s.r && j < (g + 1) * s.r)
                 val = s.scale * bf2f(((const bf16_t*)s.up[g])[(int64_t)(n - g * gn) * s.r + (j - g * s.r)]);
             up_p[t] = f2bf(val);
+            if (s.up_pg) {   // LECO_ACT_GEGLU row interleave: value row f -> 128 (f/64) + f%64, gate row F + f -> ... + 64
+                const int F = s.n / 2, f = n < F ? n : n - F;
+                const int64_t row = (int64_t)(f / 64) * 128 + (f % 64) + (n < F ? 0 : 64);
+                ((bf16_t*)s.up_pg)[row * Rp + j] = f2bf(val);
+            }
         } else if (e < n0 + n1 + n2) {  // up_t[j][n] = up[g][n - g*gn][jj] if group(n) == j / r
             const int64_t t = e - n0 - n1;
             const int j = (int)(t / s.n), n = (int)(t - (int64_t)j * s.n), g = n / gn;

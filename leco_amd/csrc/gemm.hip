@@ -447,6 +447,24 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             const f32x4 v0 = *(const f32x4*)(stg + rl * SROW + cc * 8);
             const f32x4 v1 = *(const f32x4*)(stg + rl * SROW + cc * 8 + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (BN == 128 && p.act == LECO_ACT_GEGLU) {
+                // columns [0, 64) of the tile: value block, [64, 128): its gate block (interleaved weight rows)
+                if (cc >= 8) continue;
+                const f32x4 g0 = *(const f32x4*)(stg + rl * SROW + 64 + cc * 8);
+                const f32x4 g1 = *(const f32x4*)(stg + rl * SROW + 64 + cc * 8 + 4);
+                float gt[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
+                if (p.bias) {
+                    const f32x4 a0 = *(const f32x4*)(p.bias + n), a1 = *(const f32x4*)(p.bias + n + 4);
+                    const f32x4 b0 = *(const f32x4*)(p.bias + n + 64), b1 = *(const f32x4*)(p.bias + n + 68);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] += a0[r]; v[4 + r] += a1[r]; gt[r] += b0[r]; gt[4 + r] += b1[r]; }
+                }
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] *= 0.5f * gt[r] * (1.f + erff(gt[r] * 0.7071067811865476f));
+                const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                *(u32x4*)(cp + (int64_t)m * p.ldc + (n0 >> 1) + cc * 8) = o;
+                continue;
+            }
             if (wsp) {   // split-K: raw partial sums, the epilogue runs in splitk_finish_kernel
                 *(f32x4*)(wsp + (int64_t)m * N + n) = v0;
                 *(f32x4*)(wsp + (int64_t)m * N + n + 4) = v1;
@@ -612,6 +630,8 @@ int validate(const leco_gemm_args& a) {
             return fail(-EINVAL, "leco_gemm: t_w needs w_ext, ext_k == 32, t_rows in {16, 32}, 16-byte aligned strides");
     }
     if (a.rowbias && a.rows_per_group <= 0) return fail(-EINVAL, "leco_gemm: rowbias needs rows_per_group");
+    if (a.act == LECO_ACT_GEGLU && (a.n % 128 || !a.c || a.residual || a.rowbias || a.c_f32 || a.ldc % 8))
+        return fail(-EINVAL, "leco_gemm: LECO_ACT_GEGLU needs n %% 128 == 0, a bf16 output and no residual / rowbias / fp32 copy");
     if (a.a_mode < LECO_A_PLAIN || a.a_mode > LECO_A_CONV3_TR2) return fail(-EINVAL, "leco_gemm: bad a_mode %d", a.a_mode);
     if ((a.lda0 | a.ldw | (a.a1 ? a.lda1 : 0) | (a.a_ext ? (a.ld_aext | a.ld_wext) : 0)) % 8)
         return fail(-EINVAL, "leco_gemm: operand strides must be multiples of 8 elements (16-byte DMA)");
@@ -644,6 +664,11 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int m = args->m, n = args->n, nk = args->k / BK;
+    if (args->act == LECO_ACT_GEGLU) {   // value / gate pairing lives inside one 128-column tile
+        if (tile != 0 && tile != 1 && tile != 4) return fail(-EINVAL, "leco_gemm: LECO_ACT_GEGLU needs a 128-column tile");
+        if (tile == 0) tile = 1;
+        split_k = 1;
+    }
     if (tile == 0) {
         if (n <= 64 || m <= 64) tile = 3;
         else {

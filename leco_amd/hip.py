@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libleco_hip.so")
 
 A_PLAIN, A_CONV3_S1, A_CONV3_S2, A_CONV3_UP2, A_CONV3_TR2 = range(5)
-ACT_NONE, ACT_SILU = 0, 1
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
 
 
 class GemmArgs(C.Structure):
@@ -44,6 +44,7 @@ class LoraSite(C.Structure):
         ("groups", C.c_int32), ("r", C.c_int32), ("k", C.c_int32), ("n", C.c_int32),
         ("scale", C.c_float), ("taps", C.c_int32),
         ("dn_s", C.c_void_p), ("up_p", C.c_void_p), ("up_t", C.c_void_p), ("dn_p", C.c_void_p),
+        ("up_pg", C.c_void_p),
     ]
 
 

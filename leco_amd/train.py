@@ -86,22 +86,26 @@ class FusedStep:
         st = self._state.get(key)
         if st is None:
             plan = self.unet.prepare((2 * bs, 4, h, w), lora_on=True)
+            eng = self.unet.engine()
+            # the k partial-denoising passes never see a backward: they run on their own forward-only plan
+            # (GEGLU fused into the ff projection's epilogue, no gradient buffers)
+            dplan = eng.plan(2 * bs, h, w, need_bwd=False)
             # the three LoRA-off predictions (positive / neutral / unconditional) run as ONE forward-only pass of
             # batch 3 x 2bs: same arithmetic per sample (GroupNorm / attention are per sample), three times
             # the rows per GEMM, a third of the launches
-            fplan = self.unet.engine().plan(6 * bs, h, w, need_bwd=False)
-            st = dict(plan=plan, fplan=fplan,
+            fplan = eng.plan(6 * bs, h, w, need_bwd=False)
+            st = dict(plan=plan, dplan=dplan, fplan=fplan,
                       x=torch.zeros(bs, 4, h, w, dtype=torch.float32, device=self.dev),
                       preds={n: fplan.pred[2 * bs * i:2 * bs * (i + 1)]
                              for i, n in enumerate(("positive", "neutral", "unconditional"))},
                       half_n=bs * 4 * h * w)
-            tail = [ops.cfg_ddim_step(plan.pred, st["x"], plan.x_in, self.coef, plan.t_idx, DENOISE_GUIDANCE,
+            tail = [ops.cfg_ddim_step(dplan.pred, st["x"], dplan.x_in, self.coef, dplan.t_idx, DENOISE_GUIDANCE,
                                       st["half_n"]),
-                    ops.advance(plan.t_idx)]
+                    ops.advance(dplan.t_idx)]
             # cross-attention K/V (+ their LoRA down projections) depend only on the prompt embeddings: the k
             # denoising passes of a step share one evaluation ("ctx_on"), the per-pass list skips those ops
-            plan.lists["ctx_on"] = [op for op in plan.lists["fwd_on"] if op.tag == "ctx"]
-            plan.lists["denoise"] = [op for op in plan.lists["fwd_on"] if op.tag != "ctx"] + tail
+            dplan.lists["ctx_on"] = [op for op in dplan.lists["fwd_on"] if op.tag == "ctx"]
+            dplan.lists["denoise"] = [op for op in dplan.lists["fwd_on"] if op.tag != "ctx"] + tail
             self._state[key] = st
         return st
 
@@ -156,18 +160,21 @@ class FusedStep:
         unet.prepare((2 * bs, 4, h, w), lora_on=True)   # re-packs LoRA operands if the slab changed
         x = st["x"]
         x.copy_(latents.to(self.dev, torch.float32))
-        plan.x_in.copy_(torch.cat([x, x]).to(torch.bfloat16))
-        plan.ctx.copy_(self._ctx(pair, "target", bs))
+        dplan = st["dplan"]
+        dplan.x_in.copy_(torch.cat([x, x]).to(torch.bfloat16))
+        dplan.ctx.copy_(self._ctx(pair, "target", bs))
         xl = self.unet.cfg.addition_embed_type == "text_time"
         if xl:
             ids = add_time_ids.reshape(1, 6).to(self.dev, torch.float32)
-            plan.time_ids.copy_(ids.repeat(2 * bs, 1).reshape(-1))
-            plan.text_embeds.copy_(self._pooled(pair, "target", bs))
-        plan.t_table[:n].copy_(self.ts_f)
-        plan.t_idx.zero_()
-        self._run(plan, "ctx_on")
+            for pl in (dplan, plan):
+                pl.time_ids.copy_(ids.repeat(2 * bs, 1).reshape(-1))
+                pl.text_embeds.copy_(self._pooled(pair, "target", bs))
+        dplan.t_table[:n].copy_(self.ts_f)
+        dplan.t_idx.zero_()
+        self._run(dplan, "ctx_on")
         for _ in range(k):
-            self._run(plan, "denoise")
+            self._run(dplan, "denoise")
+        plan.x_in.copy_(dplan.x_in)
         # 2. frozen predictions at the "current" timestep (train_lora.py:195-237)
         t_cur = int(self.sched.num_train_timesteps - 1 - int(k * self.sched.num_train_timesteps / n))
         plan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])

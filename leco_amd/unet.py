@@ -32,7 +32,7 @@ import torch
 import torch.nn as nn
 
 from . import hip, ops
-from .hip import (ACT_NONE, ACT_SILU, A_CONV3_S1, A_CONV3_S2, A_CONV3_TR2, A_CONV3_UP2, A_PLAIN, gemm_args)
+from .hip import (ACT_GEGLU, ACT_NONE, ACT_SILU, A_CONV3_S1, A_CONV3_S2, A_CONV3_TR2, A_CONV3_UP2, A_PLAIN, gemm_args)
 
 bf16 = torch.bfloat16
 
@@ -275,6 +275,8 @@ class LoraSiteState:
         self.up_p = torch.zeros(N, self.Rp, dtype=bf16, device=dev)
         self.up_t = torch.zeros(self.Rp, N, dtype=bf16, device=dev)
         self.dn_p = torch.zeros(K, self.Rp, dtype=bf16, device=dev)
+        # GEGLU input projections keep a second, row-interleaved copy of up_p for the fused-GEGLU epilogue
+        self.up_pg = torch.zeros(N, self.Rp, dtype=bf16, device=dev) if site.geglu_ok else None
 
 
 class GemmSite:
@@ -305,7 +307,25 @@ class GemmSite:
         else:
             self.bias = None
         self._wt = None
+        self._wg = None
         self.lora: Optional[LoraSiteState] = None
+        # GEGLU.proj sites (N = 2F, F % 64 == 0) can run with the GEGLU fused into the GEMM epilogue
+        self.geglu_ok = (not conv3) and name.endswith("ff.net.0.proj") and self.n % 128 == 0
+
+    @staticmethod
+    def geglu_perm(n: int, device) -> torch.Tensor:
+        """source row of interleaved row i: blocks of 128 = 64 value rows then their 64 gate rows (LECO_ACT_GEGLU)."""
+        i = torch.arange(n, device=device)
+        j, r = i // 128, i % 128
+        return torch.where(r < 64, j * 64 + r, n // 2 + j * 64 + (r - 64))
+
+    @property
+    def w_geglu(self) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+        """(weights, bias) with the LECO_ACT_GEGLU row interleave."""
+        if self._wg is None:
+            perm = self.geglu_perm(self.n, self.w.device)
+            self._wg = (self.w[perm].contiguous(), None if self.bias is None else self.bias[perm].contiguous())
+        return self._wg
 
     @property
     def wt(self) -> torch.Tensor:
@@ -458,6 +478,7 @@ class Engine:
             d.scale = 0.0  # filled by refresh_lora
             d.taps = 9 if site.conv3 else 1
             d.dn_s, d.up_p, d.up_t, d.dn_p = st.dn_s.data_ptr(), st.up_p.data_ptr(), st.up_t.data_ptr(), st.dn_p.data_ptr()
+            d.up_pg = st.up_pg.data_ptr() if st.up_pg is not None else None
         self._pack_host = sites
         self._pack_dev = torch.zeros(C.sizeof(sites), dtype=torch.uint8, device=self.device)
         self._pack_scale = None
@@ -536,7 +557,9 @@ class PlanBuilder:
     def gemm_fwd(self, site: GemmSite, x: Union[TRef, Tuple[TRef, TRef]], name: str, *, conv=None, amode=A_PLAIN,
                  rows: int, residual: Optional[TRef] = None, rowbias=None, rows_per_group=0, ld_rowbias=0,
                  act=ACT_NONE, out: Optional[TRef] = None, out_f32: Optional[torch.Tensor] = None,
-                 bias="site", ldc32_override: int = 0) -> TRef:
+                 bias="site", ldc32_override: int = 0, geglu: bool = False) -> TRef:
+        if geglu:
+            return self._gemm_fwd_geglu(site, x, name, rows)
         xs = x if isinstance(x, tuple) else (x,)
         rg_in = any(t.rg for t in xs) or (residual is not None and residual.rg)
         lora = site.lora
@@ -578,6 +601,25 @@ class PlanBuilder:
             y.rg = rg_in or lora is not None
             if y.rg:
                 self.tape.append(lambda: self.gemm_bwd(site, xs, y, T, conv, amode, rows, residual))
+        return y
+
+    def _gemm_fwd_geglu(self, site: GemmSite, x: TRef, name: str, rows: int) -> TRef:
+        """GEGLU.proj with value * gelu(gate) fused into the epilogue (forward-only plans): output [rows][N/2]."""
+        assert site.geglu_ok and not self.need_bwd
+        wg, bg = site.w_geglu
+        y = self.act(name, rows, site.n // 2)
+        common = dict(m=rows, n=site.n, k=site.k, bias=bg, act=ACT_GEGLU, lda=x.ld, ldc=y.ld)
+        self.f_off.append(ops.gemm(gemm_args(x.ptr, wg, y.ptr, **common), keep=(site, x, y, wg, bg), ws=self.eng.workspace))
+        lora = site.lora
+        if lora is not None and lora.Rp == 32 and lora.up_pg is not None:
+            T = self.act(name + ".loraT", rows, 32)
+            g_on = gemm_args(x.ptr, wg, y.ptr, w_ext=lora.up_pg, ext_k=32, ld_wext=32, t_w=lora.dn_s, t_rows=lora.R16,
+                             t_out=T.ptr, ld_tout=T.ld, **common)
+            self.f_on.append(ops.gemm(g_on, keep=(site, lora, x, y, T, wg, bg), ws=self.eng.workspace))
+        elif lora is not None:
+            raise RuntimeError("fused GEGLU needs the rank-<=32 fused down-projection path")
+        else:
+            self.f_on.append(self.f_off[-1])
         return y
 
     def lora_bwd(self, site: GemmSite, xs, dy: TRef, T: TRef, conv, amode, rows, name: str) -> TRef:
@@ -823,7 +865,11 @@ class PlanBuilder:
         a2 = self.attention(q2, kv, heads, hw, ctx.rows // self.B, bname + ".a2")
         h2 = self.gemm_fwd(S[bname + ".attn2.to_out.0"], a2, bname + ".h2", rows=rows, residual=h1)
         l3 = self.layernorm(bname + ".norm3", h2, bname + ".l3")
-        u = self.gemm_fwd(S[bname + ".ff.net.0.proj"], l3, bname + ".u", rows=rows)
+        ff1 = S[bname + ".ff.net.0.proj"]
+        if not self.need_bwd and ff1.geglu_ok and (ff1.lora is None or (ff1.lora.Rp == 32 and ff1.lora.up_pg is not None)):
+            gg = self.gemm_fwd(ff1, l3, bname + ".geglu", rows=rows, geglu=True)
+            return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2)
+        u = self.gemm_fwd(ff1, l3, bname + ".u", rows=rows)
         gg = self.act(bname + ".geglu", rows, 4 * Cc, rg=u.rg)
         self.both(ops.Op("leco_geglu_fwd", (u.ptr, u.ld, gg.ptr, gg.ld, rows, 4 * Cc), keep=(u, gg)))
         if gg.rg:

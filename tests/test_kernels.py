@@ -95,6 +95,40 @@ def test_gemm_fused_lora_down_projection(dev, tile, t_rows, split, M, N, K):
     assert rel_err(o32, ref) < TOL32
 
 
+@pytest.mark.parametrize("tile,M,F,K,lora", [(0, 300, 128, 192, False), (1, 200, 256, 320, True), (4, 520, 128, 128, True)])
+def test_gemm_fused_geglu_epilogue(dev, tile, M, F, K, lora):
+    """LECO_ACT_GEGLU: interleaved value / gate weight rows, value * gelu(gate) written as [M][F] (diffusers GEGLU)."""
+    torch.manual_seed(14)
+    N = 2 * F
+    a = torch.randn(M, K).to(bf).to(dev); w = (torch.randn(N, K) / K ** 0.5).to(bf); bias = torch.randn(N)
+    i = torch.arange(N); j, r = i // 128, i % 128
+    perm = torch.where(r < 64, j * 64 + r, F + j * 64 + (r - 64))
+    wg = w[perm].contiguous().to(dev); bg = bias[perm].contiguous().to(dev)
+    out = torch.zeros(M, F, dtype=bf, device=dev)
+    kw = {}
+    ref_u = a.float().cpu() @ w.float().T + bias
+    if lora:
+        R = 12
+        tw = torch.zeros(32, K); tw[:R] = torch.randn(R, K) / K ** 0.5
+        up = torch.zeros(N, 32); up[:, :R] = torch.randn(N, R) * 0.3
+        tw, up = tw.to(bf), up.to(bf)
+        kw = dict(w_ext=up[perm].contiguous().to(dev), ext_k=32, t_w=tw.to(dev), t_rows=16,
+                  t_out=torch.zeros(M, 32, dtype=bf, device=dev))
+        T = (a.float().cpu() @ tw.float().T).to(bf)
+        ref_u = ref_u + T.float() @ up.float().T
+    g = hip.gemm_args(a, wg, out, m=M, n=N, k=K, bias=bg, act=hip.ACT_GEGLU, ldc=F, **kw)
+    hip.gemm(g, ops.default_stream(), tile)
+    _sync(dev)
+    ref = ref_u[:, :F] * F_gelu(ref_u[:, F:])
+    assert rel_err(out, ref) < TOLBF
+    with pytest.raises(hip.LecoError):   # needs a 128-column tile
+        hip.gemm(g, ops.default_stream(), 2)
+
+
+def F_gelu(x):
+    return F.gelu(x)
+
+
 def test_gemm_large_grid_two_buffer_variant(dev):
     """> 384 workgroups selects the 4-wave / 2-buffer pipeline (the small cases use the 8-wave / 4-deep ring)."""
     torch.manual_seed(12)
