@@ -106,7 +106,7 @@ def test_gemm_fused_geglu_epilogue(dev, tile, M, F, K, lora):
     wg = w[perm].contiguous().to(dev); bg = bias[perm].contiguous().to(dev)
     out = torch.zeros(M, F, dtype=bf, device=dev)
     kw = {}
-    ref_u = a.float().cpu() @ w.float().T + bias
+    ref_u = a.float().cpu() @ w.float().T + bias   # reference on the host (w, bias were never moved)
     if lora:
         R = 12
         tw = torch.zeros(32, K); tw[:R] = torch.randn(R, K) / K ** 0.5
@@ -120,7 +120,7 @@ def test_gemm_fused_geglu_epilogue(dev, tile, M, F, K, lora):
     hip.gemm(g, ops.default_stream(), tile)
     _sync(dev)
     ref = ref_u[:, :F] * F_gelu(ref_u[:, F:])
-    assert rel_err(out, ref) < TOLBF
+    assert rel_err(out.cpu(), ref) < TOLBF
     with pytest.raises(hip.LecoError):   # needs a 128-column tile
         hip.gemm(g, ops.default_stream(), 2)
 
