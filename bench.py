@@ -61,6 +61,35 @@ def cpu_baseline(seconds_budget: float = 30.0):
             "host_cpus": os.cpu_count()}
 
 
+def dominant_kernel_roofline(dev):
+    """The kernel with the largest share of the step (profiles/: the 3x3-conv implicit GEMM) timed live with HIP
+    events on one of its heaviest launches: ResnetBlock conv 640->640 at 32x32, UNet batch 4 (M=4096, N=640,
+    K=5760; algorithmic work 2*M*N*K)."""
+    from leco_amd import hip, ops
+    B, H, C = 4, 32, 640
+    M, N, K = B * H * H, C, 9 * C
+    x = torch.randn(M, C, device=dev).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    ws = torch.empty(32 * 1024 * 1024, device=dev)
+    g = hip.gemm_args(x, w, out, m=M, n=N, k=K, a_mode=hip.A_CONV3_S1, conv=(B, H, H, H, H), lda=C)
+    stream = ops.default_stream()
+    for _ in range(10):
+        hip.gemm(g, stream, 0, 0, ws)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    iters = 50
+    e0.record()
+    for _ in range(iters):
+        hip.gemm(g, stream, 0, 0, ws)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    tf = 2.0 * M * N * K / us / 1e6
+    return {"name": "gemm_kernel<256,128,conv3x3> (+ split-K finish)", "shape": f"M={M} N={N} K={K}",
+            "us_per_launch": us, "achieved": tf, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": tf / (PEAK_BF16 / 1e12)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -156,6 +185,10 @@ def main():
                      "note": "algorithmic FLOPs W_ref(k)=2*bs*F_fwd*(k+5+a) summed over the timed steps / HIP-event "
                              "time on the compute stream (rank 0); per-kernel breakdown in profiles/"},
     }
+    try:
+        out["roofline"]["dominant_kernel"] = dominant_kernel_roofline(dev)
+    except Exception as e:  # never hide the step number
+        out["roofline"]["dominant_kernel"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline()
