@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--bs", type=int, default=2)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--rank", type=int, default=4)
+    ap.add_argument("--k", type=int, default=0, help="profiling only: fixed number of denoising passes per step "
+                                                     "(0 = the seeded reference distribution; the headline number uses 0)")
     args = ap.parse_args()
 
     from leco_amd import model_util, prompt_util, train_util
@@ -137,6 +139,8 @@ def main():
 
     kgen = torch.Generator().manual_seed(0)
     ks = [torch.randint(1, 50, (1,), generator=kgen).item() for _ in range(args.warmup + args.steps)]
+    if args.k > 0:
+        ks = [args.k] * len(ks)
     noise_gen = torch.Generator().manual_seed(1000 + rank)
 
     def one(i):
@@ -178,7 +182,7 @@ def main():
         "config": {"workload": f"SDv1.5 UNet (random init) LECO erase step, LoRA rank {args.rank} lierla, "
                                f"{args.res}x{args.res}, prompt batch {args.bs} (UNet batch {2 * args.bs}), DDIM 50, "
                                f"reference-faithful pass structure (k+3+1 fwd, 1 bwd)",
-                   "global_batch": args.bs * world, "k_sequence_seed": 0, "k_mean": sum(timed_ks) / len(timed_ks),
+                   "global_batch": args.bs * world, "k_sequence_seed": 0 if args.k <= 0 else f"fixed k={args.k} (profiling run)", "k_mean": sum(timed_ks) / len(timed_ks),
                    "hip_graphs": bool(unet.use_graphs), "parallelism": f"dp{world}", "loss": float(loss.item())},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": achieved / (PEAK_BF16 / 1e12), "traffic": None,
