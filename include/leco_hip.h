@@ -224,6 +224,18 @@ int leco_advance(int32_t* counter, leco_stream_t stream);
  * the next UNet input cat([x]*2) as bf16 (train_util.py:151). */
 int leco_cfg_ddim_step(const float* pred, float* x, void* x2, const float* coef, const int32_t* step,
                        float guidance, int64_t half_n, leco_stream_t stream);
+
+/* Same role for the other schedulers the reference accepts (ddpm / lms / euler_a, model_util.py:247-274), all linear
+ * in (sample, model output, fresh noise, previous derivatives).  coef: fp32 [steps][LECO_SCHED_ROW] rows
+ * {c_x, c_e, c_n, c_h1, c_h2, c_h3, s_in, d_x, d_e, -, -, -}:
+ *   x' = c_x x + c_e out + c_n noise + sum_j c_hj h_j        (out = CFG-combined raw prediction, or 0 if pred == NULL)
+ *   d  = d_x x + d_e out, history h1 <- d, h2 <- h1, h3 <- h2  (hist: fp32 [n_hist][half_n], n_hist = 0..3)
+ *   x2 = bf16(s_in x') twice = next UNet input (scale_model_input of the NEXT step, train_util.py:153).
+ * noise (fp32 [half_n]) may be NULL for deterministic schedulers. */
+#define LECO_SCHED_ROW 12
+int leco_cfg_sched_step(const float* pred, float* x, void* x2, const float* coef, const int32_t* step,
+                        float guidance, int64_t half_n, const float* noise, float* hist, int32_t n_hist,
+                        leco_stream_t stream);
 /* PromptEmbedsPair.loss (prompt_util.py:107-148) with MSELoss(mean) on device in fp32, plus
  * d loss / d (raw target-pass UNet output) (train_lora.py:279 first autograd step). */
 int leco_esd_loss(const float* tgt, const float* pos, const float* neu, const float* unc, float g_pred,
@@ -233,6 +245,12 @@ int leco_esd_loss(const float* tgt, const float* pos, const float* neu, const fl
  * (train_lora.py:280).  hyper (device): {lr, 1-beta1^t, 1-beta2^t, grad_scale}. */
 int leco_adamw(float* p, const float* g, float* m, float* v, void* shadow, const float* hyper,
                float beta1, float beta2, float eps, float wd, int64_t n, leco_stream_t stream);
+
+/* Lion (`lion_pytorch.Lion`, selected by train.optimizer = "lion", train_util.py:362-365): p *= 1 - lr wd;
+ * p -= lr sign(beta1 m + (1-beta1) g); m = beta2 m + (1-beta2) g.  Same hyper block ({lr, -, -, grad_scale}) and
+ * bf16 shadow refresh as leco_adamw. */
+int leco_lion(float* p, const float* g, float* m, void* shadow, const float* hyper, float beta1, float beta2,
+              float wd, int64_t n, leco_stream_t stream);
 int leco_cast_f32_bf16(const float* x, void* y, int64_t n, leco_stream_t stream);
 int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream);
 

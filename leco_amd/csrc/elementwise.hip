@@ -256,6 +256,35 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const float* pred, float*
     }
 }
 
+// ---- CFG combine + generic linear scheduler update (DDPM / LMS / Euler-ancestral, model_util.py:247-274) --------
+// row = coef + LECO_SCHED_ROW * step: {c_x, c_e, c_n, c_h1, c_h2, c_h3, s_in, d_x, d_e, ...}
+//   x' = c_x x + c_e out + c_n noise + sum_j c_hj h_j ;  d = d_x x + d_e out, history shifted h1 <- d, h2 <- h1, h3 <- h2
+//   x2 = bf16(s_in x') duplicated = the next UNet input (scale_model_input of the next step folded in)
+__global__ __launch_bounds__(256) void cfg_sched_kernel(const float* pred, float* x, bf16_t* x2, const float* coef,
+                                                         const int* step, float guidance, int64_t half_n,
+                                                         const float* noise, float* hist, int n_hist) {
+    const int st = step ? *step : 0;
+    const float* r = coef + LECO_SCHED_ROW * st;
+    const float cx = r[0], ce = r[1], cn = r[2], sin_ = r[6], dx = r[7], de = r[8];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < half_n; e += (int64_t)gridDim.x * 256) {
+        const float out = pred ? pred[e] + guidance * (pred[half_n + e] - pred[e]) : 0.f;
+        const float xo = x[e];
+        float xn = cx * xo + ce * out;
+        if (noise) xn += cn * noise[e];
+        float hprev = dx * xo + de * out;
+        for (int j = 0; j < n_hist; ++j) {   // oldest-last; shift while accumulating
+            const float hj = hist[(int64_t)j * half_n + e];
+            xn += r[3 + j] * hj;
+            hist[(int64_t)j * half_n + e] = hprev;
+            hprev = hj;
+        }
+        x[e] = xn;
+        const bf16_t hb = f2bf(sin_ * xn);
+        x2[e] = hb;
+        x2[half_n + e] = hb;
+    }
+}
+
 // ---- ESD loss (prompt_util.py:107-135 with MSELoss, train_lora.py:96,265-270) and d loss / d target-pass output --
 // each *_pred is the raw fp32 [2*bs][n] UNet output; guided = u + g_pred*(c - u) (train_util.py:163-166).
 // target_goal = neutral + sign * g_loss * (positive - unconditional); loss = mean((target - goal)^2).
@@ -304,6 +333,22 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, fl
         p[e] = pv;
         m[e] = mm;
         v[e] = vv;
+        shadow[e] = f2bf(pv);
+    }
+}
+
+// Lion (Chen et al. 2023; `lion_pytorch.Lion`, train_util.py:362-365): decoupled weight decay, sign of the
+// interpolated momentum, then the momentum update with beta2.  hyper = {lr, -, -, grad_scale}.
+__global__ __launch_bounds__(256) void lion_kernel(float* p, const float* g, float* m, bf16_t* shadow,
+                                                    const float* hyper, float beta1, float beta2, float wd, int64_t n) {
+    const float lr = hyper[0], gs = hyper[3];
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+        const float gr = g[e] * gs, mo = m[e];
+        float pv = p[e] * (1.f - lr * wd);
+        const float u = beta1 * mo + (1.f - beta1) * gr;
+        pv -= lr * (u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f));
+        p[e] = pv;
+        m[e] = beta2 * mo + (1.f - beta2) * gr;
         shadow[e] = f2bf(pv);
     }
 }
@@ -553,6 +598,14 @@ extern "C" int leco_cfg_ddim_step(const float* pred, float* x, void* x2, const f
                        coef, (const int*)step, guidance, half_n);
     return check_launch("leco_cfg_ddim_step");
 }
+extern "C" int leco_cfg_sched_step(const float* pred, float* x, void* x2, const float* coef, const int32_t* step,
+                                   float guidance, int64_t half_n, const float* noise, float* hist, int32_t n_hist,
+                                   leco_stream_t stream) {
+    if (n_hist < 0 || n_hist > 3 || (n_hist && !hist)) return fail(-EINVAL, "cfg_sched_step: n_hist=%d needs 0..3 history slabs", n_hist);
+    hipLaunchKernelGGL(cfg_sched_kernel, dim3(grid_for(half_n)), dim3(256), 0, LECO_STREAM, pred, x, (bf16_t*)x2, coef,
+                       (const int*)step, guidance, half_n, noise, hist, n_hist);
+    return check_launch("leco_cfg_sched_step");
+}
 extern "C" int leco_esd_loss(const float* tgt, const float* pos, const float* neu, const float* unc, float g_pred,
                              float g_loss, float sign, int64_t half_n, float* loss, float* dpred,
                              leco_stream_t stream) {
@@ -566,6 +619,12 @@ extern "C" int leco_adamw(float* p, const float* g, float* m, float* v, void* sh
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n)), dim3(256), 0, LECO_STREAM, p, g, m, v, (bf16_t*)shadow,
                        hyper, beta1, beta2, eps, wd, n);
     return check_launch("leco_adamw");
+}
+extern "C" int leco_lion(float* p, const float* g, float* m, void* shadow, const float* hyper, float beta1,
+                         float beta2, float wd, int64_t n, leco_stream_t stream) {
+    hipLaunchKernelGGL(lion_kernel, dim3(grid_for(n)), dim3(256), 0, LECO_STREAM, p, g, m, (bf16_t*)shadow, hyper, beta1,
+                       beta2, wd, n);
+    return check_launch("leco_lion");
 }
 extern "C" int leco_cast_f32_bf16(const float* x, void* y, int64_t n, leco_stream_t stream) {
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, LECO_STREAM, x, (bf16_t*)y, n);

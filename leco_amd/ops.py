@@ -37,8 +37,10 @@ _SIGS = {
     "leco_timestep_embedding": [_vp, _vp, _i32, _i32, _i32, _vp, _vp],
     "leco_advance": [_vp, _vp],
     "leco_cfg_ddim_step": [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp],
+    "leco_cfg_sched_step": [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp, _vp, _i32, _vp],
     "leco_esd_loss": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp, _vp, _vp],
     "leco_adamw": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _vp],
+    "leco_lion": [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp],
     "leco_cast_f32_bf16": [_vp, _vp, _i64, _vp],
     "leco_memset": [_vp, _i32, _i64, _vp],
     "leco_lora_pack": [_vp, _i32, _vp],
@@ -181,6 +183,11 @@ def advance(counter) -> Op:
     return Op("leco_advance", (ptr(counter),))
 
 
+def cfg_sched_step(pred, x, x2, coef, step, guidance, half_n, noise=None, hist=None, n_hist=0) -> Op:
+    return Op("leco_cfg_sched_step", (ptr(pred), ptr(x), ptr(x2), ptr(coef), ptr(step), guidance, half_n, ptr(noise),
+                                      ptr(hist), n_hist))
+
+
 def cfg_ddim_step(pred, x, x2, coef, step, guidance, half_n) -> Op:
     return Op("leco_cfg_ddim_step", (ptr(pred), ptr(x), ptr(x2), ptr(coef), ptr(step), guidance, half_n))
 
@@ -192,6 +199,10 @@ def esd_loss(tgt, pos, neu, unc, g_pred, g_loss, sign, half_n, loss, dpred) -> O
 
 def adamw(p, g, m, v, shadow, hyper, beta1, beta2, eps, wd, n) -> Op:
     return Op("leco_adamw", (ptr(p), ptr(g), ptr(m), ptr(v), ptr(shadow), ptr(hyper), beta1, beta2, eps, wd, n))
+
+
+def lion(p, g, m, shadow, hyper, beta1, beta2, wd, n) -> Op:
+    return Op("leco_lion", (ptr(p), ptr(g), ptr(m), ptr(shadow), ptr(hyper), beta1, beta2, wd, n))
 
 
 def cast_f32_bf16(x, y, n) -> Op:

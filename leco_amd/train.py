@@ -61,8 +61,12 @@ class FusedStep:
 
     def __init__(self, unet, network: LoRANetwork, scheduler, max_denoising_steps: int = 50, lr: float = 1e-4,
                  betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2, world_size: int = 1,
-                 process_group=None):
+                 process_group=None, optimizer="adamw"):
+        """``optimizer``: "adamw" / "adam" (fused leco_adamw; adam = no decoupled decay), "lion" (fused leco_lion),
+        or a ``torch.optim.Optimizer`` built on ``network.prepare_optimizer_params()`` (its ``step()`` runs on the
+        fp32 slab views, then the bf16 shadow is refreshed)."""
         self.unet, self.net, self.sched = unet, network, scheduler
+        self.optimizer = optimizer
         self.n_steps = max_denoising_steps
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.world, self.pg = world_size, process_group
@@ -72,13 +76,35 @@ class FusedStep:
         # device-side schedule tables
         scheduler.set_timesteps(max_denoising_steps)
         self.ts_f = scheduler.timesteps.to(torch.float32).to(dev)          # [n] 980, 960, ...
-        self.coef = scheduler.coef_table().to(dev).contiguous()            # [n][2]
+        # DDIM: (c_x, c_e) table for leco_cfg_ddim_step.  ddpm / lms / euler_a: SCHED_ROW-wide rows for
+        # leco_cfg_sched_step (+ one extra row, rewritten every step, that re-scales the denoised latents for the
+        # "current timestep" of the frozen / target passes, train_util.py:153 via train_lora.py:195-199)
+        self.generic = not hasattr(scheduler, "coef_table")
+        if self.generic:
+            from .scheduler import SCHED_ROW
+            rows = scheduler.rows()
+            fin = torch.zeros(1, SCHED_ROW)
+            fin[0, 0] = fin[0, 6] = 1.0
+            self.coef = torch.cat([rows, fin]).to(dev).contiguous()
+            self.fin_idx = torch.tensor([max_denoising_steps], dtype=torch.int32, device=dev)
+            self.first_scale = float(scheduler.scale_model_input(torch.ones(1), scheduler.timesteps[0]))
+        else:
+            self.coef = scheduler.coef_table().to(dev).contiguous()        # [n][2]
         self.all_t = torch.arange(0, scheduler.num_train_timesteps, dtype=torch.float32, device=dev)
         self.single_slot = 512
         self.slot_idx = torch.tensor([self.single_slot], dtype=torch.int32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ctx_cache = {}
         self._state = {}
+
+    def _scale_at(self, t_train: int) -> float:
+        """scale_model_input factor at train timestep `t_train` of the 1000-step schedule (train_lora.py:195-199)."""
+        n_keep = self.sched.num_inference_steps
+        self.sched.set_timesteps(self.sched.num_train_timesteps)
+        try:
+            return float(self.sched.scale_model_input(torch.ones(1), torch.tensor(float(t_train))))
+        finally:
+            self.sched.set_timesteps(n_keep)
 
     # ---- per (batch, h, w) state: latents + per-pass prediction copies + the denoise plan -----------
     def _bucket(self, bs: int, h: int, w: int):
@@ -99,9 +125,18 @@ class FusedStep:
                       preds={n: fplan.pred[2 * bs * i:2 * bs * (i + 1)]
                              for i, n in enumerate(("positive", "neutral", "unconditional"))},
                       half_n=bs * 4 * h * w)
-            tail = [ops.cfg_ddim_step(dplan.pred, st["x"], dplan.x_in, self.coef, dplan.t_idx, DENOISE_GUIDANCE,
-                                      st["half_n"]),
-                    ops.advance(dplan.t_idx)]
+            if self.generic:
+                st["noise"] = (torch.zeros(st["half_n"], dtype=torch.float32, device=self.dev)
+                               if self.sched.needs_noise else None)
+                st["hist"] = (torch.zeros(self.sched.n_hist * st["half_n"], dtype=torch.float32, device=self.dev)
+                              if self.sched.n_hist else None)
+                tail = [ops.cfg_sched_step(dplan.pred, st["x"], dplan.x_in, self.coef, dplan.t_idx, DENOISE_GUIDANCE,
+                                           st["half_n"], st["noise"], st["hist"], self.sched.n_hist),
+                        ops.advance(dplan.t_idx)]
+            else:
+                tail = [ops.cfg_ddim_step(dplan.pred, st["x"], dplan.x_in, self.coef, dplan.t_idx, DENOISE_GUIDANCE,
+                                          st["half_n"]),
+                        ops.advance(dplan.t_idx)]
             # cross-attention K/V (+ their LoRA down projections) depend only on the prompt embeddings: the k
             # denoising passes of a step share one evaluation ("ctx_on"), the per-pass list skips those ops
             dplan.lists["ctx_on"] = [op for op in dplan.lists["fwd_on"] if op.tag == "ctx"]
@@ -161,7 +196,10 @@ class FusedStep:
         x = st["x"]
         x.copy_(latents.to(self.dev, torch.float32))
         dplan = st["dplan"]
-        dplan.x_in.copy_(torch.cat([x, x]).to(torch.bfloat16))
+        x_first = x * self.first_scale if self.generic else x        # scale_model_input of the first step
+        dplan.x_in.copy_(torch.cat([x_first, x_first]).to(torch.bfloat16))
+        if self.generic and st["hist"] is not None:
+            st["hist"].zero_()
         dplan.ctx.copy_(self._ctx(pair, "target", bs))
         xl = self.unet.cfg.addition_embed_type == "text_time"
         if xl:
@@ -173,10 +211,18 @@ class FusedStep:
         dplan.t_idx.zero_()
         self._run(dplan, "ctx_on")
         for _ in range(k):
+            if self.generic and st["noise"] is not None:
+                st["noise"].normal_()          # fresh ancestral noise (device RNG, like diffusers' randn_tensor)
             self._run(dplan, "denoise")
-        plan.x_in.copy_(dplan.x_in)
         # 2. frozen predictions at the "current" timestep (train_lora.py:195-237)
         t_cur = int(self.sched.num_train_timesteps - 1 - int(k * self.sched.num_train_timesteps / n))
+        if self.generic:
+            # sigma-space schedulers: the UNet input of the remaining passes is x / sqrt(sigma(t_cur)^2 + 1)
+            sc = self._scale_at(t_cur)
+            self.coef[n, 6:7].copy_(torch.tensor([sc], dtype=torch.float32), non_blocking=True)
+            ops.cfg_sched_step(None, x, plan.x_in, self.coef, self.fin_idx, 0.0, st["half_n"]).run()
+        else:
+            plan.x_in.copy_(dplan.x_in)
         plan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])
         plan.t_idx.copy_(self.slot_idx)
         net.multiplier = 0
@@ -210,8 +256,20 @@ class FusedStep:
         lr = self.lr if lr is None else lr
         net.hyper.copy_(torch.tensor([lr, 1 - b1 ** self.opt_step, 1 - b2 ** self.opt_step, 1.0 / self.world]),
                         non_blocking=True)
-        ops.adamw(net.slab.detach(), net.grad, net.exp_avg, net.exp_avg_sq, net.shadow, net.hyper, b1, b2, self.eps,
-                  self.wd, net.slab.numel()).run()
+        if isinstance(self.optimizer, str) and self.optimizer in ("adam", "adamw"):
+            ops.adamw(net.slab.detach(), net.grad, net.exp_avg, net.exp_avg_sq, net.shadow, net.hyper, b1, b2, self.eps,
+                      self.wd, net.slab.numel()).run()
+        elif self.optimizer == "lion":
+            ops.lion(net.slab.detach(), net.grad, net.exp_avg, net.shadow, net.hyper, b1, b2, self.wd,
+                     net.slab.numel()).run()
+        else:   # any torch optimizer over the slab views (prodigy, dadapt*, 8-bit ... when their packages exist)
+            if self.world > 1:
+                net.grad.mul_(1.0 / self.world)
+            net.attach_grads()
+            for group in self.optimizer.param_groups:
+                group["lr"] = lr
+            self.optimizer.step()
+            net.sync_shadow()
         net.mark_updated()
         return self.loss
 
@@ -285,13 +343,21 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
 
     opt_name = config.train.optimizer.lower()
     optimizer_kwargs = _parse_optimizer_args(config.train.optimizer_args)
-    if opt_name not in ("adam", "adamw"):
-        raise NotImplementedError(f"optimizer '{config.train.optimizer}': only adam / adamw run fused on the MI355X "
-                                  f"path (the other names need packages that are not installed here)")
+    if opt_name in ("adam", "adamw", "lion"):
+        # fused on the flat slab.  torch.optim.Adam's weight_decay is a coupled L2 term, which the fused kernel
+        # does not implement: fall through to the torch object in that (non-default) case
+        fused_opt = opt_name if not (opt_name == "adam" and optimizer_kwargs.get("weight_decay", 0.0)) else None
+    else:
+        fused_opt = None
+    if fused_opt is None:
+        optimizer_module = train_util.get_optimizer(opt_name)     # ImportError names the missing package
+        fused_opt = optimizer_module(network.prepare_optimizer_params(), lr=config.train.lr, **optimizer_kwargs)
     wd_default = 1e-2 if opt_name == "adamw" else 0.0
+    default_betas = (0.9, 0.99) if opt_name == "lion" else (0.9, 0.999)
     fused = FusedStep(unet, network, noise_scheduler, config.train.max_denoising_steps, lr=config.train.lr,
-                      betas=tuple(optimizer_kwargs.get("betas", (0.9, 0.999))), eps=optimizer_kwargs.get("eps", 1e-8),
-                      weight_decay=optimizer_kwargs.get("weight_decay", wd_default), world_size=world)
+                      betas=tuple(optimizer_kwargs.get("betas", default_betas)), eps=optimizer_kwargs.get("eps", 1e-8),
+                      weight_decay=optimizer_kwargs.get("weight_decay", wd_default), world_size=world,
+                      optimizer=fused_opt)
     # LR schedule: drive torch's own scheduler objects on a dummy parameter so the values are exact
     _dummy = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=config.train.lr)
     lr_scheduler = train_util.get_lr_scheduler(config.train.lr_scheduler, _dummy, max_iterations=config.train.iterations,

@@ -444,3 +444,53 @@ def test_lora_pack_forward_wgrad(dev):
     ops.lora_wgrad(T.data_ptr() + 2 * r, Rp, dy.data_ptr() + 2 * 64, N_, G.data_ptr(), 1, r, M, r, 64, 0.25).run()
     _sync(dev)
     assert rel_err(G.cpu(), 0.25 * dy[:, 64:128].float().cpu().T @ T[:, r:2 * r].float().cpu()) < 1e-5
+
+
+@pytest.mark.parametrize("name", ["euler_a", "lms", "ddpm"])
+def test_cfg_sched_step_matches_scheduler_objects(dev, name):
+    """leco_cfg_sched_step driven by `rows()` reproduces predict_noise's CFG combine (train_util.py:163-166) followed by
+    scheduler.step (train_util.py:190) and the next scale_model_input (train_util.py:153) for the non-DDIM schedulers."""
+    from leco_amd import scheduler as S
+    torch.manual_seed(21)
+    n, bs, numel, g = 6, 2, 4 * 8 * 8, 3.0
+    half = bs * numel
+    sch = S.create_noise_scheduler(name)
+    sch.set_timesteps(n)
+    ref = S.create_noise_scheduler(name)
+    ref.set_timesteps(n)
+    coef = sch.rows().to(dev)
+    x0 = torch.randn(half) * float(sch.init_noise_sigma)
+    x = x0.clone().to(dev); xr = x0.clone()
+    x2 = torch.zeros(2 * half, dtype=bf, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    hist = torch.zeros(3 * half, device=dev)
+    for i, t in enumerate(ref.timesteps):
+        pred = torch.randn(2 * half)
+        noise = torch.randn(half)
+        ops.cfg_sched_step(pred.to(dev), x, x2, coef, step, g, half, noise.to(dev) if sch.needs_noise else None,
+                           hist if sch.n_hist else None, sch.n_hist).run()
+        ops.advance(step).run()
+        out = pred[:half] + g * (pred[half:] - pred[:half])
+        xr = (ref.step(out, t, xr).prev_sample if name == "lms" else ref.step(out, t, xr, noise=noise).prev_sample)
+        _sync(dev)
+        assert rel_err(x.cpu(), xr) < 1e-5, (name, i)
+        nxt = ref.scale_model_input(xr, ref.timesteps[i + 1]) if i + 1 < n else xr
+        assert rel_err(x2.cpu()[:half].float(), nxt) < TOLBF and torch.equal(x2[:half], x2[half:])
+
+
+def test_lion_matches_the_published_update(dev):
+    """leco_lion vs the Lion update rule (Chen et al. 2023, as in lion_pytorch): decay, sign(interp), momentum."""
+    torch.manual_seed(22)
+    n, lr, b1, b2, wd, gs = 1000, 3e-4, 0.9, 0.99, 0.1, 0.5
+    p0 = torch.randn(n); g0 = torch.randn(n); m0 = torch.randn(n) * 0.1
+    g0[:10] = 0.0; m0[:10] = 0.0          # sign(0) = 0
+    p, g, m = p0.clone().to(dev), g0.clone().to(dev), m0.clone().to(dev)
+    shadow = torch.zeros(n, dtype=bf, device=dev)
+    hyper = torch.tensor([lr, 1.0, 1.0, gs], device=dev)
+    ops.lion(p, g, m, shadow, hyper, b1, b2, wd, n).run()
+    _sync(dev)
+    gr = g0 * gs
+    pr = p0 * (1 - lr * wd) - lr * torch.sign(b1 * m0 + (1 - b1) * gr)
+    mr = b2 * m0 + (1 - b2) * gr
+    assert torch.allclose(p.cpu(), pr, atol=1e-7) and torch.allclose(m.cpu(), mr, atol=1e-7)
+    assert torch.equal(shadow.cpu(), pr.to(bf))

@@ -10,6 +10,7 @@ import pytest
 import torch
 from safetensors.torch import load_file
 
+from conftest import rel_err
 from oracle import lora_ref, step_ref
 from oracle import unet_ref as R
 from oracle.ddim_ref import DDIMSchedulerRef
@@ -95,3 +96,47 @@ def test_oracle_unet_fp64_self_consistency():
         y64 = u.double()(x.double(), torch.tensor(500), encoder_hidden_states=ctx.double()).sample
     assert torch.equal(y32, GOLD["unet.y_t500"])
     assert ((y32.double() - y64).norm() / y64.norm()).item() < 1e-5
+
+
+@pytest.mark.parametrize("pred", ["epsilon", "v_prediction"])
+def test_non_ddim_schedulers_rows_match_the_stepwise_restatement(pred):
+    """leco_amd.scheduler's pre-multiplied coefficient rows (what the fused loop consumes) against the step-by-step
+    restatement in oracle/sched_ref.py, for every step of a 50-step schedule, plus the public sigma_max."""
+    from leco_amd import scheduler as S
+    from oracle import sched_ref as R
+    g = torch.Generator().manual_seed(5)
+    n = 50
+    sch = R.SigmaSchedule(n)
+    assert abs(sch.init_noise_sigma - 14.6146) < 1e-3
+    for name in ("euler_a", "lms", "ddpm"):
+        s = S.create_noise_scheduler(name, prediction_type=pred)
+        s.set_timesteps(n)
+        assert abs(float(s.init_noise_sigma) - (14.6146 if name != "ddpm" else 1.0)) < 1e-3
+        x = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64) * float(s.init_noise_sigma)
+        xr = x.clone()
+        hist, hist_r = [], []
+        rows = s.rows().double()
+        for i, t in enumerate(s.timesteps):
+            out = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+            noise = torch.randn(2, 4, 8, 8, generator=g, dtype=torch.float64)
+            # (a) the scheduler object's own step (drop-in path)
+            if name == "lms":
+                a = s.step(out, t, x).prev_sample
+            else:
+                a = s.step(out, t, x, noise=noise).prev_sample
+            # (b) the coefficient row (fused path), with the derivative history it implies
+            r = rows[i]
+            h = hist + [torch.zeros_like(x)] * 3
+            b = r[0] * x + r[1] * out + r[2] * noise + r[3] * h[0] + r[4] * h[1] + r[5] * h[2]
+            hist = [r[7] * x + r[8] * out] + hist[:2]
+            # (c) the step-by-step restatement
+            if name == "euler_a":
+                c = R.euler_a_step(sch, i, xr, out, noise, pred)
+            elif name == "lms":
+                c = R.lms_step(sch, i, xr, out, hist_r, pred)
+            else:
+                c = R.ddpm_step(int(t), n, xr, out, noise, pred)
+            assert rel_err(a, c) < 1e-5 and rel_err(b, c) < 1e-5, (name, i)
+            if name != "ddpm" and i + 1 < n:
+                assert abs(float(r[6]) - sch.scale(i + 1)) < 1e-6
+            x, xr = a, c

@@ -250,6 +250,82 @@ def test_fused_step_sdxl_matches_oracle(dev):
     assert rel_err(net.grad[:net.numel].cpu(), gref) < 8e-2
 
 
+@pytest.mark.parametrize("name", ["lms", "euler_a", "ddpm"])
+def test_fused_step_other_schedulers_match_oracle(dev, name):
+    """config `train.noise_scheduler` in {lms, euler_a, ddpm} (model_util.py:247-274): the fused step (table-driven
+    leco_cfg_sched_step, sigma-space input scaling, ancestral noise, multistep history) against the oracle loop
+    driven by the step-by-step scheduler restatements of oracle/sched_ref.py."""
+    from oracle import sched_ref
+    if dev.type == "cuda" and name != "lms":
+        pytest.skip("ancestral noise comes from the device RNG: only the CPU stream can be replayed for the oracle")
+    ref = oracle_unet()
+    m = hip_unet(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rnet = lora_ref.LoRANetworkRef(ref, rank=4)
+        net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
+    g = torch.Generator().manual_seed(31)
+    with torch.no_grad():
+        for rl, l in zip(rnet.unet_loras, net.unet_loras):
+            d = (torch.randn(rl.lora_down.weight.shape, generator=g) * 0.05).to(bf).float()
+            u = (torch.randn(rl.lora_up.weight.shape, generator=g) * 0.05).to(bf).float()
+            rl.lora_down.weight.copy_(d); rl.lora_up.weight.copy_(u)
+            l.lora_down.weight.copy_(d.reshape(l.lora_down.weight.shape)); l.lora_up.weight.copy_(u.reshape(l.lora_up.weight.shape))
+    net.mark_updated()
+    emb = _golden_emb()
+    k, n, bs = 3, 10, 1
+    sched = create_noise_scheduler(name)
+    lat = torch.randn(bs, 4, 16, 16, generator=g) * float(sched.init_noise_sigma)   # get_initial_latents (train_util.py:55)
+    half = bs * 4 * 16 * 16
+    torch.manual_seed(777)
+    noises = [torch.empty(half).normal_() for _ in range(k)]
+    rs = {"lms": sched_ref.LMSRef, "euler_a": sched_ref.EulerARef, "ddpm": sched_ref.DDPMRef}[name](noises=noises)
+    out = step_ref.leco_step(ref, rnet, rs, emb, lat.clone(), k, n, guidance_scale=2.0, batch_size=bs)
+    out["loss"].backward()
+    gref = torch.cat([p.grad.reshape(-1) for l in rnet.unet_loras for p in (l.lora_down.weight, l.lora_up.weight)])
+    settings = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=2.0,
+                                          batch_size=bs, resolution=128, action="erase")
+    pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["target"], emb["positive"], emb["unconditional"],
+                                        emb["neutral"], settings)
+    fs = FusedStep(m, net, sched, n, lr=1e-3)
+    torch.manual_seed(777)
+    loss = fs.step(pair, k, lat.clone())
+    st = fs._state[(bs, 16, 16)]
+    assert rel_err(st["x"].cpu(), out["denoised"]) < 1.5e-2
+    assert rel_err(st["plan"].pred.cpu()[bs:], out["preds"]["target"].detach()) < 2.5e-2
+    assert rel_err(st["preds"]["positive"].cpu()[bs:], out["preds"]["positive"]) < 2.5e-2
+    assert abs(loss.item() - out["loss"].item()) / out["loss"].item() < 5e-2
+    assert rel_err(net.grad[:net.numel].cpu(), gref) < 8e-2
+
+
+def test_fused_step_optimizer_choices(dev):
+    """train.optimizer: the fused AdamW, the fused Lion and an arbitrary torch optimizer object on the slab views all
+    start from the same gradients; each update equals its own rule applied to those gradients."""
+    m = hip_unet(dev)
+    emb = _golden_emb()
+    settings = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=2.0,
+                                          batch_size=BS, resolution=128, action="erase")
+    pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["target"], emb["positive"], emb["unconditional"],
+                                        emb["neutral"], settings)
+    results = {}
+    for kind in ("adamw", "lion", "torch_sgd"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
+        load_lora(net)
+        before = net.slab.detach()[:net.numel].cpu().clone()
+        opt = torch.optim.SGD(net.prepare_optimizer_params(), lr=1e-3) if kind == "torch_sgd" else kind
+        fs = FusedStep(m, net, create_noise_scheduler("ddim"), N_STEPS, lr=1e-3, weight_decay=0.0,
+                       betas=(0.9, 0.99) if kind == "lion" else (0.9, 0.999), optimizer=opt)
+        fs.step(pair, K, GOLD["latents"].clone())
+        results[kind] = (before, net.grad[:net.numel].cpu().clone(), net.slab.detach()[:net.numel].cpu().clone(),
+                         net.shadow[:net.numel].cpu().clone())
+    b, g, after, shadow = results["lion"]
+    assert torch.allclose(after, b - 1e-3 * torch.sign(g), atol=1e-7)            # first step: m = 0 -> sign(g)
+    assert torch.equal(shadow, after.to(bf))
+    b, g, after, shadow = results["torch_sgd"]
+    assert torch.allclose(after, b - 1e-3 * g, atol=1e-7) and torch.equal(shadow, after.to(bf))
+    assert rel_err(results["adamw"][1], results["lion"][1]) < 1e-4               # same gradients into every rule
+
+
 def test_dropin_autograd_path_equals_fused_gradients(dev):
     """Reference-style loop body (predict_noise + loss.backward() + torch AdamW) on the HIP UNet."""
     from leco_amd import train_util
