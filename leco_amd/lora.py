@@ -218,6 +218,31 @@ class LoRANetwork(nn.Module):
         else:
             torch.save(state_dict, file)
 
+    def load_weights(self, file, strict: bool = True) -> None:
+        """Inverse of `save_weights` (the reference has none): fills `lora_down` / `lora_up` from a file written by
+        this package or by the reference (same key names, Appendix E); `alpha` must agree with the construction."""
+        if os.path.splitext(str(file))[1] == ".safetensors":
+            from safetensors.torch import load_file
+            sd = load_file(str(file))
+        else:
+            sd = torch.load(file, map_location="cpu", weights_only=True)
+        own = self.state_dict()
+        missing = [k for k in own if k.startswith("lora") and k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        if strict and (missing or unexpected):
+            raise KeyError(f"{file}: LoRA keys differ (missing {missing[:3]}, unexpected {unexpected[:3]})")
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k not in own:
+                    continue
+                if k.endswith(".alpha"):
+                    if strict and abs(float(v) - float(own[k])) > 1e-6:
+                        raise ValueError(f"{file}: {k} = {float(v)} but the network was built with {float(own[k])}")
+                    continue
+                own[k].copy_(v.to(own[k].dtype).reshape(own[k].shape))
+        self.mark_updated()
+        self.sync_shadow()
+
     def __enter__(self):
         self.multiplier = 1.0
         for lora in self.unet_loras:

@@ -274,6 +274,42 @@ class FusedStep:
         return self.loss
 
 
+STATE_KEYS = ("slab", "exp_avg", "exp_avg_sq")
+
+
+def save_training_state(path, fused: "FusedStep", iteration: int, lr_scheduler=None) -> None:
+    """Everything a bit-exact continuation needs (the reference cannot resume): fp32 master slab, optimizer
+    moments and step count, the iteration, the CPU RNG state (prompt choice, k, initial latents are all drawn from
+    it, train_lora.py:148-176) and the LR-scheduler state."""
+    net = fused.net
+    blob = {k: getattr(net, k).detach().cpu().clone() for k in STATE_KEYS}
+    blob.update(opt_step=fused.opt_step, iteration=int(iteration), rng=torch.get_rng_state(),
+                lr_scheduler=None if lr_scheduler is None else lr_scheduler.state_dict(),
+                optimizer=None if isinstance(fused.optimizer, str) else fused.optimizer.state_dict())
+    torch.save(blob, path)
+
+
+def load_training_state(path, fused: "FusedStep", lr_scheduler=None) -> int:
+    """Restores `save_training_state`; returns the next iteration index."""
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    net = fused.net
+    with torch.no_grad():
+        for k in STATE_KEYS:
+            getattr(net, k).detach().copy_(blob[k].to(getattr(net, k).device))
+    fused.opt_step = int(blob["opt_step"])
+    if blob.get("optimizer") is not None and not isinstance(fused.optimizer, str):
+        fused.optimizer.load_state_dict(blob["optimizer"])
+    if lr_scheduler is not None and blob.get("lr_scheduler") is not None:
+        lr_scheduler.load_state_dict(blob["lr_scheduler"])
+        # recursive schedules (cosine) continue from the optimizer's current lr, which the scheduler state lacks
+        for group, lr in zip(lr_scheduler.optimizer.param_groups, lr_scheduler.get_last_lr()):
+            group["lr"] = lr
+    torch.set_rng_state(blob["rng"])
+    net.sync_shadow()
+    net.mark_updated()
+    return int(blob["iteration"]) + 1
+
+
 def flush():
     import gc
     if torch.cuda.is_available():
@@ -291,9 +327,12 @@ def _parse_optimizer_args(s: str) -> dict:
 
 
 def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[torch.device] = None,
-          use_graphs: bool = True, progress: bool = True, xl: bool = False):
+          use_graphs: bool = True, progress: bool = True, xl: bool = False, resume_from: Optional[str] = None,
+          save_state: bool = False, stop_after: Optional[int] = None):
     """Reference entry point ``train(config, prompts)`` (train_lora.py:34; ``xl=True``: train_lora_xl.py:40).
-    Extra keyword arguments only select the device and execution mode."""
+    Extra keyword arguments only select the device and execution mode, and the resume extension:
+    ``save_state`` writes ``{save.name}_state.pt`` next to every saved LoRA, ``resume_from`` continues from one
+    (same config), ``stop_after`` ends the run after that iteration index (used to test resumption)."""
     rank, world, local = init_distributed()
     if device is None:
         device = torch.device(f"cuda:{local}" if torch.cuda.is_available() else "cpu")
@@ -391,7 +430,15 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
     # all ranks run the same number of denoising passes.
     k_gen = torch.Generator().manual_seed(20230701) if world > 1 else None
     loss = None
+    start = 0
+    if resume_from is not None:
+        start = load_training_state(resume_from, fused, lr_scheduler)
+        if k_gen is not None:   # replay the shared k stream up to the resume point
+            for _ in range(start):
+                torch.randint(1, config.train.max_denoising_steps, (1,), generator=k_gen)
     for i in it:
+        if i < start:
+            continue
         pair = prompt_pairs[torch.randint(0, len(prompt_pairs), (1,)).item()]
         timesteps_to = torch.randint(1, config.train.max_denoising_steps, (1,), generator=k_gen).item()
         height, width = pair.resolution, pair.resolution
@@ -412,11 +459,21 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
         if i % config.save.per_steps == 0 and i != 0 and i != config.train.iterations - 1 and rank == 0:
             print("Saving...")
             save_path.mkdir(parents=True, exist_ok=True)
-            network.save_weights(save_path / f"{config.save.name}_{i}steps.safetensors", dtype=save_weight_dtype)
+            network.save_weights(save_path / f"{config.save.name}_{i}steps.safetensors", dtype=save_weight_dtype,
+                                 metadata=metadata)
+            if save_state:
+                save_training_state(save_path / f"{config.save.name}_state.pt", fused, i, lr_scheduler)
+        if stop_after is not None and i >= stop_after:
+            if save_state and rank == 0:
+                save_path.mkdir(parents=True, exist_ok=True)
+                save_training_state(save_path / f"{config.save.name}_state.pt", fused, i, lr_scheduler)
+            break
     if rank == 0:
         print("Saving...")
         save_path.mkdir(parents=True, exist_ok=True)
-        network.save_weights(save_path / f"{config.save.name}_last.safetensors", dtype=save_weight_dtype)
+        # the reference builds `metadata` (train_lora.py:38-41) and then drops it; it is written here
+        network.save_weights(save_path / f"{config.save.name}_last.safetensors", dtype=save_weight_dtype,
+                             metadata=metadata)
     flush()
     print("Done.")
     return network, (loss.item() if loss is not None else None)
@@ -425,4 +482,5 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
 def main(args, xl: bool = False):
     config = config_util.load_config_from_yaml(args.config_file)
     prompts = prompt_util.load_prompts_from_yaml(config.prompts_file)
-    train(config, prompts, xl=xl)
+    train(config, prompts, xl=xl, resume_from=getattr(args, "resume", None),
+          save_state=bool(getattr(args, "save_state", False)))

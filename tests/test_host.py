@@ -95,8 +95,10 @@ def test_ddim_scheduler_matches_oracle(pt):
     assert tab.shape == (50, 2)
     assert torch.allclose(tab[3, 0] * x + tab[3, 1] * e, b.step(e, a.timesteps[3], x).prev_sample, rtol=1e-5, atol=1e-6)
     assert a.init_noise_sigma == 1.0 and a.scale_model_input(x, 5) is x
-    with pytest.raises(NotImplementedError):
-        create_noise_scheduler("euler_a")
+    for name in ("ddpm", "lms", "euler_a"):      # model_util.py:247-274: every accepted name builds
+        assert create_noise_scheduler(name, prediction_type=pt).prediction_type == pt
+    with pytest.raises(ValueError):
+        create_noise_scheduler("dpm++")
 
 
 def test_lora_save_format_round_trip(tmp_path):

@@ -421,3 +421,45 @@ def test_sd15_full_size_forward_vs_oracle_on_gpu():
     y3 = m(x, torch.tensor(500), encoder_hidden_states=ctx).sample.float()
     # (not bitwise: GroupNorm statistics are accumulated with fp32 atomics, so a few bf16 roundings flip)
     assert rel_err(y2, y3) < 5e-3 and rel_err(y2, y) < 5e-3
+
+
+def _tiny_train_config(tmp_path, name, iterations, **train_kw):
+    from leco_amd import config_util
+    cfg = dict(prompts_file="unused", pretrained_model=dict(name_or_path="synthetic:tiny"),
+               network=dict(type="lierla", rank=4, alpha=1.0),
+               train=dict(precision="bfloat16", noise_scheduler="ddim", iterations=iterations, lr=1e-3, optimizer="AdamW",
+                          lr_scheduler="cosine", max_denoising_steps=3, **train_kw),
+               save=dict(name=name, path=str(tmp_path / name), per_steps=100), logging={}, other={})
+    return config_util.RootConfig(**cfg)
+
+
+def test_train_entry_point_resume_is_bit_exact_and_writes_metadata(dev, tmp_path):
+    """`train(config, prompts)` (train_lora.py:34) end to end on the synthetic tiny model: 3 iterations in one go vs
+    1 iteration + saved state + resume.  Also: load_weights round trip and the safetensors metadata."""
+    from safetensors import safe_open
+    from leco_amd import train as T
+    prompts = [prompt_util.PromptSettings(target="van gogh", positive="van gogh", unconditional="", neutral="",
+                                          action="erase", guidance_scale=1.0, resolution=128, batch_size=1)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        torch.manual_seed(11)
+        net_a, _ = T.train(_tiny_train_config(tmp_path, "a", 3), prompts, device=dev, use_graphs=False, progress=False)
+        torch.manual_seed(11)
+        T.train(_tiny_train_config(tmp_path, "b", 3), prompts, device=dev, use_graphs=False, progress=False,
+                save_state=True, stop_after=0)
+        torch.manual_seed(999)   # the resumed run restores the RNG stream itself
+        net_b, _ = T.train(_tiny_train_config(tmp_path, "b", 3), prompts, device=dev, use_graphs=False, progress=False,
+                           resume_from=str(tmp_path / "b" / "b_state.pt"))
+    a, b = net_a.slab.detach()[:net_a.numel].cpu(), net_b.slab.detach()[:net_b.numel].cpu()
+    if dev.type == "cpu":
+        assert torch.equal(a, b)
+    else:                       # fp32 atomics of the LoRA wgrad are order-dependent on the GPU
+        assert rel_err(b, a) < 1e-4
+    f = str(tmp_path / "a" / "a_last.safetensors")
+    with safe_open(f, "pt") as fh:
+        md = fh.metadata()
+    assert "van gogh" in md["prompts"] and "synthetic:tiny" in md["config"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        net_c = LoRANetwork(hip_unet(dev), rank=4, multiplier=1.0, alpha=1.0)
+    net_c.load_weights(f)
+    assert rel_err(net_c.slab.detach()[:net_c.numel].cpu(), a) < 4e-3      # the file holds bf16 (train.precision)
+    assert torch.equal(net_c.shadow[:net_c.numel].cpu(), net_c.slab.detach()[:net_c.numel].to(bf).cpu())

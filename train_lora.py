@@ -11,4 +11,6 @@ from leco_amd.train import main
 if __name__ == "__main__":
     parser = argparse.ArgumentParser()
     parser.add_argument("--config_file", required=True, help="Config file for training.")
+    parser.add_argument("--save_state", action="store_true", help="also write {save.name}_state.pt (resumable state)")
+    parser.add_argument("--resume", default=None, help="continue from a {save.name}_state.pt of the same config")
     main(parser.parse_args())
