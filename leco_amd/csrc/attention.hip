@@ -125,10 +125,13 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
         }
     };
     // zero the K columns [D, DK) and V columns [D, DV) of both buffers once (the staged chunks cover [0, D))
-    for (int e = tid; e < 2 * KT * (DK / 8 - NDC); e += 256) {
-        const int buf = e / (KT * (DK / 8 - NDC)), r = e - buf * (KT * (DK / 8 - NDC));
-        const int key = r / (DK / 8 - NDC), ch = NDC + r % (DK / 8 - NDC);
-        *(u32x4*)(smem + buf * BUF + key * KROW + ch * 8) = zero4;
+    if constexpr (DK / 8 > NDC) {
+        constexpr int PADC = DK / 8 - NDC;   // zero chunks per key
+        for (int e = tid; e < 2 * KT * PADC; e += 256) {
+            const int buf = e / (KT * PADC), r = e - buf * (KT * PADC);
+            const int key = r / PADC, ch = NDC + r % PADC;
+            *(u32x4*)(smem + buf * BUF + key * KROW + ch * 8) = zero4;
+        }
     }
     if (DV > D) {
         for (int e = tid; e < 2 * KT; e += 256) {

@@ -250,7 +250,13 @@ class FusedStep:
         if self.world > 1:
             import torch.distributed as dist
             dist.all_reduce(net.grad, group=self.pg)
-        # 7. fused AdamW on the fp32 master slab (+ bf16 shadow)
+        # 7. optimizer on the fp32 master slab (+ bf16 shadow)
+        self.apply_optimizer(lr)
+        return self.loss
+
+    def apply_optimizer(self, lr: Optional[float] = None) -> None:
+        """Step 7 of `step`: consume `network.grad` (already all-reduced) with the configured optimizer."""
+        net = self.net
         self.opt_step += 1
         b1, b2 = self.betas
         lr = self.lr if lr is None else lr
@@ -271,7 +277,7 @@ class FusedStep:
             self.optimizer.step()
             net.sync_shadow()
         net.mark_updated()
-        return self.loss
+
 
 
 STATE_KEYS = ("slab", "exp_avg", "exp_avg_sq")

@@ -50,11 +50,44 @@ static inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return out;
 }
 
+// LDS-DMA model.  Default: the copy completes at issue (earliest possible landing: exposes a DMA that overwrites
+// a ring slot other waves still read).  With LECO_EMU_DMA=late in the environment every copy is DEFERRED until
+// the issuing lane's counted wait (`wait_vmcnt<N>` completes all but its N youngest) or a full
+// `__syncthreads()` (which drains vmcnt on the hardware): the latest possible landing, so a fragment read that
+// is not covered by the right `vmcnt` + barrier sees stale LDS and the parity tests fail.  Kernels must pass in
+// both modes (tests/test_kernels.py::test_gemm_dma_protocol_under_late_completion).
+namespace emu_dma {
+struct Pending { const void* src; void* dst; };
+struct Queue { Pending q[64]; int head = 0, count = 0; };
+static inline bool late() {
+    static const bool v = [] { const char* e = getenv("LECO_EMU_DMA"); return e && !strcmp(e, "late"); }();
+    return v;
+}
+static inline Queue& mine() {
+    static thread_local Queue qs[1024];      // one workgroup at a time per OS thread; indexed by work-item
+    return qs[emu::t_idx.x + emu::b_dim.x * (emu::t_idx.y + emu::b_dim.y * emu::t_idx.z)];
+}
+static inline void complete_all_but(int keep) {
+    Queue& Q = mine();
+    while (Q.count > keep) {
+        memcpy(Q.q[Q.head].dst, Q.q[Q.head].src, 16);
+        Q.head = (Q.head + 1) & 63;
+        --Q.count;
+    }
+}
+}  // namespace emu_dma
 static inline void glds16(const void* gsrc, void* lds_wave_base) {
-    memcpy((unsigned char*)lds_wave_base + 16 * emu::lane(), gsrc, 16);
+    void* dst = (unsigned char*)lds_wave_base + 16 * emu::lane();
+    if (!emu_dma::late()) { memcpy(dst, gsrc, 16); return; }
+    emu_dma::Queue& Q = emu_dma::mine();
+    if (Q.count == 64) emu_dma::complete_all_but(63);       // vmcnt saturates: the oldest has landed by then
+    Q.q[(Q.head + Q.count) & 63] = emu_dma::Pending{gsrc, dst};
+    ++Q.count;
 }
 template <int N>
-static inline void wait_vmcnt() {}          // the emulated DMA completes immediately
+static inline void wait_vmcnt() { if (emu_dma::late()) emu_dma::complete_all_but(N); }
+#undef __syncthreads
+#define __syncthreads() (emu_dma::complete_all_but(0), emu::sync_block())
 #define LECO_MIN_WAVES_PER_SIMD(n)
 static inline bf16x8 lds_read16_async(const void* lds_ptr) { return *(const bf16x8*)lds_ptr; }
 static inline u32x2 lds_read_tr16(const void* lds_ptr) {

@@ -4,6 +4,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 import torch
@@ -197,3 +198,15 @@ def test_open_clip_text_tower_conversion():
     assert torch.equal(out[base + "self_attn.v_proj.bias"], sd[pre + "transformer.resblocks.0.attn.in_proj_bias"][2 * d:])
     assert base + "layer_norm1.weight" in out and base + "mlp.fc1.bias" in out and base + "self_attn.out_proj.weight" in out
     assert "text_model.embeddings.position_embedding.weight" in out and "text_model.final_layer_norm.bias" in out
+
+
+def test_gemm_dma_protocol_under_late_completion():
+    """The emulator normally lands an LDS-DMA at issue; with LECO_EMU_DMA=late it lands only at the issuing lane's
+    counted `s_waitcnt vmcnt(N)` (or a draining __syncthreads) -- the latest moment the hardware allows.  The GEMM /
+    conv kernels (counted waits across a raw barrier, 3-4 tiles in flight) must give the same results in both
+    models; a missing or mis-counted wait shows up as stale LDS data (rel. error ~1 instead of 1e-7)."""
+    env = dict(os.environ, LECO_EMU_DMA="late")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels.py"), "-q", "-x",
+                        "-m", "not gpu", "-k", "gemm or conv3x3 or attention", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
