@@ -140,8 +140,13 @@ def load_diffusers_model(path: str, v2: bool = False, clip_skip: Optional[int] =
                          weight_dtype: torch.dtype = torch.float32):
     from transformers import CLIPTextModel, CLIPTokenizer
     tokenizer = CLIPTokenizer.from_pretrained(path, subfolder="tokenizer")
-    full = 24 if v2 else 12
-    default_layers = 23 if v2 else 12  # v2: penultimate layer (model_util.py:43-49)
+    full = 24 if v2 else 12             # the released checkpoints (model_util.py:43-49, 58-61) ...
+    try:                                # ... or whatever the folder's own config says (reduced test models)
+        with open(os.path.join(path, "text_encoder", "config.json")) as f:
+            full = int(json.load(f).get("num_hidden_layers", full))
+    except OSError:
+        pass
+    default_layers = full - 1 if v2 else full   # v2: penultimate layer (model_util.py:43-49)
     nl = full - (clip_skip - 1) if clip_skip is not None else default_layers
     text_encoder = CLIPTextModel.from_pretrained(path, subfolder="text_encoder", num_hidden_layers=nl,
                                                  torch_dtype=weight_dtype)
@@ -187,19 +192,27 @@ def load_checkpoint_model(checkpoint_path: str, v2: bool = False, clip_skip: Opt
                        f"(missing {missing[:3]}, unexpected {unexpected[:3]})")
     if any(k.startswith("cond_stage_model.model.") for k in sd):        # SD2.x: OpenCLIP ViT-H text tower
         te_sd = cc.convert_open_clip(sd)
-        full, default_layers = 24, 23                                   # penultimate layer (model_util.py:43-49)
-        tcfg = dict(hidden_size=1024, intermediate_size=4096, num_attention_heads=16, projection_dim=1024,
-                    hidden_act="gelu", vocab_size=49408, max_position_embeddings=77)
+        act, drop_last = "gelu", 1                                      # penultimate layer (model_util.py:43-49)
     elif any(k.startswith("cond_stage_model.transformer.") for k in sd):  # SD1.x: HF CLIP-L names already
         te_sd = cc.convert_ldm_clip(sd)
-        full, default_layers = 12, 12
-        tcfg = dict(hidden_size=768, intermediate_size=3072, num_attention_heads=12, projection_dim=768,
-                    hidden_act="quick_gelu", vocab_size=49408, max_position_embeddings=77)
+        act, drop_last = "quick_gelu", 0
     else:
         raise KeyError(f"{checkpoint_path}: no text encoder (cond_stage_model.*) in the checkpoint")
-    nl = full - (clip_skip - 1) if clip_skip is not None else default_layers   # model_util.py:92-96
-    text_encoder = CLIPTextModel(CLIPTextConfig(num_hidden_layers=nl, **tcfg))
+    # geometry from the tensors themselves (CLIP-L: 768 / 12 layers, OpenCLIP-H: 1024 / 24 layers, heads = width / 64)
+    emb = te_sd["text_model.embeddings.token_embedding.weight"]
+    full = 1 + max(int(k.split(".")[3]) for k in te_sd if k.startswith("text_model.encoder.layers."))
+    hidden = int(emb.shape[1])
+    tcfg = dict(vocab_size=int(emb.shape[0]), hidden_size=hidden, projection_dim=hidden, hidden_act=act,
+                intermediate_size=int(te_sd["text_model.encoder.layers.0.mlp.fc1.weight"].shape[0]),
+                num_attention_heads=max(1, hidden // 64),
+                max_position_embeddings=int(te_sd["text_model.embeddings.position_embedding.weight"].shape[0]))
+    nl = full - (clip_skip - 1) if clip_skip is not None else full - drop_last   # model_util.py:92-96
+    # CLIP's BPE vocabulary ends with <|startoftext|>, <|endoftext|> (49406 / 49407); pooling looks for the latter
+    text_encoder = CLIPTextModel(CLIPTextConfig(num_hidden_layers=nl, bos_token_id=tcfg["vocab_size"] - 2,
+                                                eos_token_id=tcfg["vocab_size"] - 1, **tcfg))
     want = text_encoder.state_dict()
+    if not any(k.startswith("text_model.") for k in want):             # transformers >= 5 dropped the prefix
+        te_sd = {k[len("text_model."):] if k.startswith("text_model.") else k: v for k, v in te_sd.items()}
     te_sd = {k: v for k, v in te_sd.items() if k in want}               # layers beyond `nl` are dropped
     lacking = [k for k in want if k not in te_sd and not k.endswith("position_ids")]
     if lacking:

@@ -210,3 +210,67 @@ def test_gemm_dma_protocol_under_late_completion():
                         "-m", "not gpu", "-k", "gemm or conv3x3 or attention", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def _write_synthetic_clip(folder, hidden=64, layers=3):
+    """A tiny but real transformers CLIP text stack on disk: tokenizer files + text_encoder/ (HF format)."""
+    import json
+    from transformers import CLIPTextConfig, CLIPTextModel
+    chars = list("abcdefghijklmnopqrstuvwxyz")
+    vocab = {c: i for i, c in enumerate(chars)}
+    vocab.update({c + "</w>": len(chars) + i for i, c in enumerate(chars)})
+    vocab["<|startoftext|>"] = len(vocab)
+    vocab["<|endoftext|>"] = len(vocab)
+    os.makedirs(os.path.join(folder, "tokenizer"), exist_ok=True)
+    json.dump(vocab, open(os.path.join(folder, "tokenizer", "vocab.json"), "w"))
+    open(os.path.join(folder, "tokenizer", "merges.txt"), "w").write("#version: 0.2\n")
+    json.dump({"model_max_length": 77, "bos_token": "<|startoftext|>", "eos_token": "<|endoftext|>",
+               "unk_token": "<|endoftext|>", "pad_token": "<|endoftext|>", "tokenizer_class": "CLIPTokenizer"},
+              open(os.path.join(folder, "tokenizer", "tokenizer_config.json"), "w"))
+    torch.manual_seed(0)
+    te = CLIPTextModel(CLIPTextConfig(vocab_size=len(vocab), hidden_size=hidden, intermediate_size=2 * hidden,
+                                      num_hidden_layers=layers, num_attention_heads=max(1, hidden // 64),
+                                      max_position_embeddings=77, projection_dim=hidden,
+                                      bos_token_id=len(vocab) - 2, eos_token_id=len(vocab) - 1))
+    return te
+
+
+def test_real_clip_front_end_from_a_diffusers_folder_and_from_a_single_file(tmp_path):
+    """N1 + N2 with the installed transformers: `load_models` on (a) a diffusers-format folder (unet/, tokenizer/,
+    text_encoder/; model_util.py:30-72) and (b) a single-file LDM checkpoint with the tokenizer next to it
+    (model_util.py:75-101); both feed `train_util.encode_prompts` (train_lora.py:109-137) and agree."""
+    import json
+    from safetensors.torch import save_file
+    from leco_amd import ckpt_convert as cc, model_util, train_util
+    from leco_amd.unet import UNet2DConditionModel
+    cfg = model_util.tiny_config()
+    unet = model_util.init_synthetic_(UNet2DConditionModel(cfg), 3)
+    folder = str(tmp_path / "model")
+    te = _write_synthetic_clip(folder, hidden=cfg.cross_attention_dim)
+    te.save_pretrained(os.path.join(folder, "text_encoder"))
+    os.makedirs(os.path.join(folder, "unet"))
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.__dict__.items()},
+              open(os.path.join(folder, "unet", "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in unet.state_dict().items()},
+              os.path.join(folder, "unet", "diffusion_pytorch_model.safetensors"))
+    tok, enc, u2, sched = model_util.load_models(folder, "ddim")
+    a, b = unet.state_dict(), u2.state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    e_folder = train_util.encode_prompts(tok, enc, ["van gogh", ""])
+    assert e_folder.shape == (2, 77, cfg.cross_attention_dim) and torch.isfinite(e_folder).all()
+    assert not torch.equal(e_folder[0], e_folder[1])
+    # (b) the same weights as ONE file in the LDM layout: UNet under model.diffusion_model.*, CLIP under
+    # cond_stage_model.transformer.text_model.* (the names SD1.x checkpoints use)
+    ldm = cc.diffusers_unet_to_ldm(unet.state_dict(), cfg)
+    for k, v in te.state_dict().items():
+        k = k if k.startswith("text_model.") else "text_model." + k
+        ldm["cond_stage_model.transformer." + k] = v
+    ck = str(tmp_path / "model" / "tiny-sd.safetensors")
+    save_file({k: v.contiguous() for k, v in ldm.items()}, ck)
+    tok2, enc2, u3, _ = model_util.load_models(ck, "ddim")
+    assert all(torch.equal(a[k], u3.state_dict()[k]) for k in a)
+    e_file = train_util.encode_prompts(tok2, enc2, ["van gogh", ""])
+    assert torch.allclose(e_file, e_folder, atol=1e-6)
+    # clip_skip drops layers from the top (model_util.py:92-96)
+    _, enc3, _ = model_util.load_checkpoint_model(ck, clip_skip=2)
+    assert len([k for k in enc3.state_dict() if k.endswith("layer_norm1.weight")]) == 2
