@@ -150,7 +150,7 @@ def main():
     def barrier():
         if world > 1:
             import torch.distributed as dist
-            dist.barrier()
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for i in range(args.warmup):

@@ -52,6 +52,8 @@ def init_distributed(backend: Optional[str] = None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":   # bind this rank to its GPU before RCCL creates the communicator
+            torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
