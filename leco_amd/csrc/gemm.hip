@@ -584,9 +584,20 @@ void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_
         const char* e = getenv("LECO_GEMM_NS2_MIN_BLOCKS");
         return e ? atol(e) : 1000000000L;
     }();
+    // EXPERIMENTAL (unmeasured, off by default): LECO_GEMM_W4_MIN_BLOCKS = n runs plain 128x128 grids of >= n
+    // workgroups as 4-wave workgroups (64x64 wave tiles) with a 2-deep ring: ~70 KB of LDS and <= 256 VGPRs, so TWO
+    // workgroups share a CU and one's prologue / epilogue overlaps the other's K loop (the many-round short-K
+    // level-0 projections are prologue / epilogue bound).
+    static const long w4_min_blocks = [] {
+        const char* e = getenv("LECO_GEMM_W4_MIN_BLOCKS");
+        return e ? atol(e) : 1000000000L;
+    }();
     if constexpr (BM == 64) {
         launch_ns<BM, BN, CONV, 4, 2>(a, rt, grid, s);
     } else {
+        if constexpr (BM == 128 && BN == 128 && !CONV) {
+            if (blocks >= w4_min_blocks) return launch_ns<BM, BN, CONV, 2, 2>(a, rt, grid, s);
+        }
         if (blocks <= ns2_min_blocks) launch_ns<BM, BN, CONV, 4, 4>(a, rt, grid, s);
         else launch_ns<BM, BN, CONV, 2, 4>(a, rt, grid, s);
     }
