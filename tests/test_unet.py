@@ -429,7 +429,7 @@ def test_training_state_resume_is_bit_exact(dev, tmp_path):
     m = hip_unet(dev)
     emb = _golden_emb()
     settings = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=2.0,
-                                          batch_size=BS, resolution=128, action="erase")
+                                          batch_size=1, resolution=64, action="erase")
     pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["target"], emb["positive"], emb["unconditional"],
                                         emb["neutral"], settings)
     sched = create_noise_scheduler("ddim")
@@ -443,7 +443,7 @@ def test_training_state_resume_is_bit_exact(dev, tmp_path):
         return net, FusedStep(m, net, sched, N_STEPS, lr=1e-3), dummy, lrs
 
     def one(fs, dummy, lrs):
-        lat = train_util.get_initial_latents(sched, BS, 128, 128, 1)        # draws from the global CPU RNG
+        lat = train_util.get_initial_latents(sched, 1, 64, 64, 1)        # draws from the global CPU RNG
         fs.step(pair, 1, lat, lr=lrs.get_last_lr()[0])
         dummy.step()
         lrs.step()
