@@ -109,10 +109,21 @@ class FusedStep:
             self.sched.set_timesteps(n_keep)
 
     # ---- per (batch, h, w) state: latents + per-pass prediction copies + the denoise plan -----------
+    MAX_BUCKETS = int(os.environ.get("LECO_MAX_BUCKETS", "4"))   # resident (bs, h, w) plan sets (LRU)
+
     def _bucket(self, bs: int, h: int, w: int):
         key = (bs, h, w)
         st = self._state.get(key)
+        if st is not None:
+            self._state[key] = self._state.pop(key)      # most recently used last
         if st is None:
+            while len(self._state) >= self.MAX_BUCKETS:   # dynamic_resolution: do not pin every bucket's buffers
+                old = next(iter(self._state))
+                self._state.pop(old)
+                eng = self.unet.engine()
+                ob, oh, ow = old
+                for pk in ((2 * ob, oh, ow, True), (2 * ob, oh, ow, False), (6 * ob, oh, ow, False)):
+                    eng.drop_plan(pk)
             plan = self.unet.prepare((2 * bs, 4, h, w), lora_on=True)
             eng = self.unet.engine()
             # the k partial-denoising passes never see a backward: they run on their own forward-only plan

@@ -505,6 +505,22 @@ class Engine:
             self.plans[key] = PlanBuilder(self, B, h, w, need_bwd).build()
         return self.plans[key]
 
+    def drop_plan(self, key: tuple) -> None:
+        """Release one plan: its captured hipGraphs, then (by dropping the references) its activation buffers.
+        `dynamic_resolution` prompts (train_lora.py:160-170) visit up to 25 (h, w) buckets of several GB each."""
+        plan = self.plans.pop(key, None)
+        if plan is None:
+            return
+        if plan.graphs:
+            if self.device.type == "cuda":
+                torch.cuda.synchronize(self.device)
+            lib = _graph_api()
+            for g in plan.graphs.values():
+                lib.leco_graph_destroy(g)
+            plan.graphs.clear()
+        plan.lists.clear()
+        plan.bufs.clear()
+
 
 class PlanBuilder:
     def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True):

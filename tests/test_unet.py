@@ -500,3 +500,20 @@ def test_train_entry_point_writes_metadata_and_reloadable_weights(dev, tmp_path)
     net_c.load_weights(f)
     assert rel_err(net_c.slab.detach()[:net_c.numel].cpu(), a) < 4e-3      # the file holds bf16 (train.precision)
     assert torch.equal(net_c.shadow[:net_c.numel].cpu(), net_c.slab.detach()[:net_c.numel].to(bf).cpu())
+
+
+def test_plan_buckets_are_evicted_lru(dev):
+    """`dynamic_resolution` visits many (h, w) buckets; FusedStep keeps at most MAX_BUCKETS plan sets resident."""
+    m = hip_unet(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
+    fs = FusedStep(m, net, create_noise_scheduler("ddim"), N_STEPS, lr=1e-3)
+    fs.MAX_BUCKETS = 2
+    eng = m.engine()
+    for hw in ((8, 8), (8, 16), (16, 8)):
+        fs._bucket(1, *hw)
+    assert list(fs._state) == [(1, 8, 16), (1, 16, 8)]
+    assert (2, 8, 8, True) not in eng.plans and (6, 8, 8, False) not in eng.plans and (2, 16, 8, False) in eng.plans
+    fs._bucket(1, 8, 16)                       # touch: becomes most recent
+    fs._bucket(1, 8, 8)                        # evicts (1, 16, 8)
+    assert list(fs._state) == [(1, 8, 16), (1, 8, 8)] and (2, 16, 8, True) not in eng.plans
