@@ -277,10 +277,13 @@ def test_real_clip_front_end_from_a_diffusers_folder_and_from_a_single_file(tmp_
 
 
 @pytest.mark.parametrize("env", [{"LECO_GEMM_W4_MIN_BLOCKS": "1"}, {"LECO_GEMM_W4_MIN_BLOCKS": "1", "LECO_EMU_DMA": "late"},
+                                 {"LECO_GEMM_PERSISTENT_MIN_TILES": "1", "LECO_GEMM_PERSISTENT_GRID": "3"},
+                                 {"LECO_GEMM_PERSISTENT_MIN_TILES": "1", "LECO_GEMM_PERSISTENT_GRID": "2",
+                                  "LECO_EMU_DMA": "late"},
                                  {"LECO_GEMM_NS2_MIN_BLOCKS": "1", "LECO_EMU_DMA": "late"}, {"LECO_ATTN_QF": "1"}])
 def test_tuning_switch_variants_stay_correct(env):
-    """Launch-shape switches that exist for tuning (4-wave / two-workgroups-per-CU GEMM, 2-buffer GEMM, one query
-    fragment per wave) select different kernel instantiations: each must pass the same parity tests."""
+    """Launch-shape switches that exist for tuning (4-wave / two-workgroups-per-CU GEMM, 2-buffer GEMM, persistent
+    cross-tile GEMM, one query fragment per wave) select different kernel instantiations: each must pass the same parity tests."""
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels.py"), "-q", "-x",
                         "-m", "not gpu", "-k", "gemm or conv3x3 or attention", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)

@@ -20,6 +20,8 @@ run "W4 (2 WG/CU, 4 waves) blocks>=2048" LECO_GEMM_W4_MIN_BLOCKS=2048
 run "W4 blocks>=1024" LECO_GEMM_W4_MIN_BLOCKS=1024
 run "W4 blocks>=512" LECO_GEMM_W4_MIN_BLOCKS=512
 run "W4 blocks>=257" LECO_GEMM_W4_MIN_BLOCKS=257
+run "persistent GEMM tiles>=512" LECO_GEMM_PERSISTENT_MIN_TILES=512
+run "persistent GEMM tiles>=1024" LECO_GEMM_PERSISTENT_MIN_TILES=1024
 run "NS2 (2 WG/CU, 8 waves) blocks>384" LECO_GEMM_NS2_MIN_BLOCKS=384
 run "attention QF=1 everywhere" LECO_ATTN_QF=1
 run "attention QF=2 everywhere" LECO_ATTN_QF=2
