@@ -426,10 +426,11 @@ def test_training_state_resume_is_bit_exact(dev, tmp_path):
     """Two steps in one go vs one step, `save_training_state`, a fresh LoRANetwork / FusedStep, `load_training_state`,
     one more step (fp32 slab, AdamW moments, step count, LR-schedule and RNG state all restored)."""
     from leco_amd import train as T, train_util
+    res = 64 if dev.type == "cpu" else 128      # the emulator tier keeps the shapes small; the GPU tier the usual ones
     m = hip_unet(dev)
     emb = _golden_emb()
     settings = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=2.0,
-                                          batch_size=1, resolution=64, action="erase")
+                                          batch_size=1, resolution=res, action="erase")
     pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["target"], emb["positive"], emb["unconditional"],
                                         emb["neutral"], settings)
     sched = create_noise_scheduler("ddim")
@@ -443,7 +444,7 @@ def test_training_state_resume_is_bit_exact(dev, tmp_path):
         return net, FusedStep(m, net, sched, N_STEPS, lr=1e-3), dummy, lrs
 
     def one(fs, dummy, lrs):
-        lat = train_util.get_initial_latents(sched, 1, 64, 64, 1)        # draws from the global CPU RNG
+        lat = train_util.get_initial_latents(sched, 1, res, res, 1)        # draws from the global CPU RNG
         fs.step(pair, 1, lat, lr=lrs.get_last_lr()[0])
         dummy.step()
         lrs.step()
