@@ -465,8 +465,8 @@ def test_training_state_resume_is_bit_exact(dev, tmp_path):
     a, c = net_a.slab.detach()[:net_a.numel].cpu(), net_c.slab.detach()[:net_c.numel].cpu()
     if dev.type == "cpu":
         assert torch.equal(a, c)
-    else:                       # fp32 atomics of the LoRA wgrad are order-dependent on the GPU
-        assert rel_err(c, a) < 1e-4
+    else:   # fp32 atomics of the LoRA wgrad are order-dependent on the GPU, and AdamW's first steps move every
+        assert rel_err(c, a) < 5e-3   # parameter by ~lr * sign(g): a near-zero gradient may flip (exactness: CPU tier)
 
 
 def _tiny_train_config(tmp_path, name, iterations, **train_kw):
