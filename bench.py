@@ -15,6 +15,7 @@ whole-job rate: world_size * K / max-over-ranks wall time.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -177,8 +178,9 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
+    losses = []
     for i in range(args.warmup, args.warmup + args.steps):
-        loss = one(i)
+        losses.append(one(i).clone())       # device-side copy of the loss scalar: no host sync in the timed loop
     e1.record()
     barrier()
     dt = time.perf_counter() - t0
@@ -188,7 +190,11 @@ def main():
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+    losses = [float(l.item()) for l in losses]
+    finite = all(math.isfinite(l) for l in losses)
     if rank != 0:
+        if not finite:
+            sys.exit(f"rank {rank}: non-finite loss in the timed steps: {losses}")
         return
     timed_ks = ks[args.warmup:]
     flops = sum(step_flops(args.bs, k) for k in timed_ks)
@@ -201,7 +207,7 @@ def main():
                                f"{args.res}x{args.res}, prompt batch {args.bs} (UNet batch {2 * args.bs}), DDIM 50, "
                                f"reference-faithful pass structure (k+3+1 fwd, 1 bwd)",
                    "global_batch": args.bs * world, "k_sequence_seed": 0 if args.k <= 0 else f"fixed k={args.k} (profiling run)", "k_mean": sum(timed_ks) / len(timed_ks),
-                   "hip_graphs": bool(unet.use_graphs), "parallelism": f"dp{world}", "loss": float(loss.item())},
+                   "hip_graphs": bool(unet.use_graphs), "parallelism": f"dp{world}", "loss": losses[-1], "losses": losses},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                      "frac": achieved / (PEAK_BF16 / 1e12), "traffic": None,
                      "note": "algorithmic FLOPs W_ref(k)=2*bs*F_fwd*(k+5+a) summed over the timed steps / HIP-event "
@@ -217,6 +223,8 @@ def main():
         except Exception as e:  # the baseline leg must never hide the GPU number
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     print(json.dumps(out))
+    if not finite:   # a timing of a broken computation is not a result
+        sys.exit(f"non-finite loss in the timed steps: {losses}")
 
 
 if __name__ == "__main__":

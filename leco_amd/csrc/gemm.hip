@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         for (int i = 0; i < FM; ++i) af[i] = lds_read16_async(sA + lds_off(wave_m * WM + i * 16 + fr, ks * 4 + fg));
 #pragma unroll
         for (int j = 0; j < FN; ++j) wf[j] = lds_read16_async(sB + lds_off(wave_n * WN + j * 16 + fr, ks * 4 + fg));
-        if (TF) wf[FN] = lds_read16_async(sB + lds_off(t_row + fr, ks * 4 + fg));
+        if constexpr (TF != 0) wf[FN] = lds_read16_async(sB + lds_off(t_row + fr, ks * 4 + fg));
     };
     // fragment reads are explicit asynchronous ds_reads: `landed` hands a set back to the compiler once a
     // wait has covered it
@@ -307,12 +307,14 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
                 if (!(LECO_GEMM_ABLATE & 1)) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
                 else acc[i][j][0] += __uint_as_float((unsigned)(wf[j][0] ^ af[i][0]));  // keep the LDS reads live
             }
+        if constexpr (TF != 0) {
 #pragma unroll
-        for (int i = 0; i < TFM; ++i) {
-            // TF = 1: wave column 1 projects the upper half of the row fragments (uniform select, not a
-            // dynamically indexed register array)
-            const bf16x8 a = (TF == 1 && wave_n) ? af[(TF == 1 ? FM / 2 : 0) + i] : af[i];
-            acct[i] = mfma16(wf[FN], a, acct[i]);
+            for (int i = 0; i < TFM; ++i) {
+                // TF = 1: wave column 1 projects the upper half of the row fragments (uniform select, not a
+                // dynamically indexed register array)
+                const bf16x8 a = (TF == 1 && wave_n) ? af[(TF == 1 ? FM / 2 : 0) + i] : af[i];
+                acct[i] = mfma16(wf[FN], a, acct[i]);
+            }
         }
     };
     // wait until this wave's DMA pieces of tile `t` have landed, given that tiles [0, staged) were issued:
@@ -324,10 +326,18 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         else if (NS >= 2 && younger == 1) { if (w_last) wait_vmcnt<GA + GW>(); else wait_vmcnt<GA + GW - 1>(); }
         else wait_vmcnt<0>();
     };
+    // INVARIANT (tools/audit_async_lds.py proves it on the ISA): an asynchronous fragment read is in flight only
+    // inside ONE loop -- never across a loop entry or exit.  The compiler treats the asm ds_read's destination as
+    // written at the end of the statement, so where two loops keep a fragment set in different registers it copies
+    // the registers on the connecting edge, i.e. BEFORE the data has landed (round-1 full-size NaN: the w_last
+    // steady loop of the 64x64 TF=1 kernel vs its drain loop).  Completing the set on both sides of every loop
+    // costs one LDS latency per tile.
     if (nk > 0) {
         wait_tile(0, nk < NS ? nk : NS);
         barrier_keep_dma();
         read_frags(0, 0, afA, wfA);
+        lds_wait<0>();
+        landed(afA, wfA);
     }
     int it = 0;
     // steady state: iterations whose refill (tile it+NS) is a main tile.  Outstanding LDS reads when set A is
@@ -353,6 +363,8 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             mma(afB, wfB);
             sched_fence();
         }
+        lds_wait<0>();          // set A of tile `it` complete before the loop exit (see INVARIANT above)
+        landed(afA, wfA);
     };
     if (RAGGED && !w_last) steady(std::false_type{});
     else steady(std::true_type{});
@@ -506,330 +518,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     }
 }
 
-// =====================================================================================================
-// EXPERIMENTAL persistent variant (off by default: LECO_GEMM_PERSISTENT_MIN_TILES; unmeasured, emulator-verified).
-// Plain A, 128 x 128 tile, 8 waves, split_k == 1, fused LoRA down-projection TF in {0, 1, 2}.  gridDim.x workgroups
-// walk the tile list tile = blockIdx.x + j * gridDim.x as ONE continuous stream of K tiles: the DMA ring (3 slots)
-// keeps filling with the next tile's first K tiles while the current tile's K-extension step and epilogue run
-// in a SEPARATE LDS region, so the prologue latency and the epilogue of the short-K (K = 320) level-0 projections --
-// 90 % of their time in the one-tile-per-workgroup kernel -- overlap across tiles.
-// =====================================================================================================
-template <int TF>
-__global__ __launch_bounds__(512) void gemm_persistent_kernel(const leco_gemm_args p, const GemmRt rt) {
-    constexpr int BM = 128, BN = 128, NS = 3, NWM = 4;
-    constexpr int NW = NWM * 2, NT = NW * 64;
-    constexpr int WM = BM / NWM, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-    constexpr int BNT = BN + 16 * TF;
-    constexpr int TFM = TF == 0 ? 0 : (TF == 1 ? FM / 2 : FM);
-    constexpr int FNT = FN + (TF ? 1 : 0);
-    constexpr int GA = BM / 8 / NW;
-    constexpr int GWT = BNT / 8, GW = (GWT + NW - 1) / NW;
-    constexpr bool RAGGED = (GWT % NW) != 0;
-    constexpr int TILE = (BM + BNT) * BK;
-    constexpr int SROW = BN + 4, NC8 = BN / 8;
-    bf16_t* smem = (bf16_t*)dyn_lds();
-    float* stg = (float*)(smem + NS * TILE);           // epilogue staging region, never a DMA target
-
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
-    const bool w_last = !RAGGED || (wave + NW * (GW - 1) < GWT);
-    const int st_row = lane >> 3, st_pos = lane & 7;
-    const int fr = lane & 15, fg = lane >> 4;
-    const int cpos8 = (st_pos ^ st_row) * 8;
-    const bf16_t* a0 = (const bf16_t*)p.a0;
-    const bf16_t* a1 = (const bf16_t*)p.a1;
-    const bf16_t* wp = (const bf16_t*)p.w;
-    const bf16_t* wext = (const bf16_t*)p.w_ext;
-    const bf16_t* zero = (const bf16_t*)g_zero_page;
-    const int M = p.m, N = p.n, nk = p.k / BK;
-    const int k_split = a1 ? p.k_split : 0x7fffffff;
-    const int tiles_n = rt.tiles_n, tiles = tiles_n * ((M + BM - 1) / BM);
-    const int G = (int)gridDim.x, wg = (int)blockIdx.x;
-    const int n_items = (tiles - wg + G - 1) / G;      // tiles wg, wg + G, ... (>= 1: the grid never exceeds the tiles)
-    constexpr int EXT = TF ? 1 : 0;                    // the K-extension tile [T | scale*up] rides in the same stream
-    const int nkx = nk + EXT;
-    const int total = n_items * nkx;
-
-    // ---- addressing state of the item being STAGED (may run one item ahead of the item being computed)
-    unsigned arow[GA], vmask[GA], wmask[GW];
-    const bf16_t* wrow[GW];
-    const bf16_t* wxrow[GW];
-    auto set_stage_item = [&](int j) {
-        const int tile = wg + j * G;
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-#pragma unroll
-        for (int i = 0; i < GA; ++i) {
-            const int m = tm * BM + (wave + NW * i) * 8 + st_row;
-            arow[i] = (unsigned)(m < M ? m : 0);
-            vmask[i] = m < M ? 1u : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < GW; ++i) {
-            const int rl = (wave + NW * i) * 8 + st_row;
-            const int n = tn * BN + rl;
-            const bool main_row = rl < BN && n < N;
-            wrow[i] = main_row ? wp + (int64_t)n * p.ldw + cpos8 : zero;
-            wmask[i] = main_row ? 0xffffffffu : 0u;
-            if (TF && rl >= BN && rl < BNT) {
-                wrow[i] = (const bf16_t*)p.t_w + (int64_t)(rl - BN) * p.ld_tw + cpos8;
-                wmask[i] = 0xffffffffu;
-            }
-            wxrow[i] = (TF && main_row && cpos8 < p.ext_k) ? wext + (int64_t)n * p.ld_wext + cpos8 : zero;
-        }
-    };
-    auto pick = [&](const bf16_t* src, unsigned off, unsigned ok) -> const bf16_t* {
-        const long long delta = (const char*)src - (const char*)zero;
-        const long long d = (delta + ((long long)off << 1)) & -(long long)ok;
-        return (const bf16_t*)((const char*)zero + d);
-    };
-    int staged_item = -1;
-    auto stage = [&](int q) {                          // K tile q of this workgroup's stream -> ring slot q % NS
-        const int j = q / nkx, kt = q - j * nkx;
-        if (j != staged_item) { set_stage_item(j); staged_item = j; }
-        bf16_t* sA = smem + (q % NS) * TILE;
-        bf16_t* sB = sA + BM * BK;
-        if (EXT && kt == nk) {   // extension tile: W side = scale*up rows; A side (T) is written from registers later
-#pragma unroll
-            for (int i = 0; i < GA; ++i) glds16(zero, sA + (wave + NW * i) * 8 * BK);   // same piece count as a main tile
-#pragma unroll
-            for (int i = 0; i < GW; ++i) {
-                if (RAGGED && i == GW - 1 && !w_last) break;
-                glds16(wxrow[i], sB + (wave + NW * i) * 8 * BK);
-            }
-            return;
-        }
-        const int k0 = kt * BK;
-        const bf16_t* src;
-        unsigned ld;
-        int kk;
-        if (k0 < k_split) { src = a0; ld = (unsigned)p.lda0; kk = k0; }
-        else { src = a1; ld = (unsigned)p.lda1; kk = k0 - k_split; }
-#pragma unroll
-        for (int i = 0; i < GA; ++i) {
-            const unsigned off = mul24(arow[i], ld) + (unsigned)(kk + cpos8);
-            glds16(pick(src, off, vmask[i]), sA + (wave + NW * i) * 8 * BK);
-        }
-#pragma unroll
-        for (int i = 0; i < GW; ++i) {
-            if (RAGGED && i == GW - 1 && !w_last) break;
-            glds16(wrow[i] + ((unsigned)k0 & wmask[i]), sB + (wave + NW * i) * 8 * BK);
-        }
-    };
-
-    f32x4 acc[FM][FN];
-    f32x4 acct[TFM ? TFM : 1];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int i = 0; i < (TFM ? TFM : 1); ++i) acct[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    zero_acc();
-    const int t_row = BN + (TF == 2 ? wave_n * 16 : 0);
-    const int t_i0 = TF == 1 ? wave_n * (FM / 2) : 0;
-
-    bf16x8 afA[FM], wfA[FNT], afB[FM], wfB[FNT];
-    auto read_frags = [&](int q, int ks, bf16x8 (&af)[FM], bf16x8 (&wf)[FNT]) {
-        const bf16_t* sA = smem + (q % NS) * TILE;
-        const bf16_t* sB = sA + BM * BK;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = lds_read16_async(sA + lds_off(wave_m * WM + i * 16 + fr, ks * 4 + fg));
-#pragma unroll
-        for (int j = 0; j < FN; ++j) wf[j] = lds_read16_async(sB + lds_off(wave_n * WN + j * 16 + fr, ks * 4 + fg));
-        if (TF) wf[FN] = lds_read16_async(sB + lds_off(t_row + fr, ks * 4 + fg));
-    };
-    auto landed = [&](bf16x8 (&af)[FM], bf16x8 (&wf)[FNT]) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i) lds_tie(af[i]);
-#pragma unroll
-        for (int j = 0; j < FNT; ++j) lds_tie(wf[j]);
-    };
-    auto mma = [&](const bf16x8 (&af)[FM], const bf16x8 (&wf)[FNT]) {
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-#pragma unroll
-        for (int i = 0; i < TFM; ++i) {
-            const bf16x8 a = (TF == 1 && wave_n) ? af[(TF == 1 ? FM / 2 : 0) + i] : af[i];
-            acct[i] = mfma16(wf[FN], a, acct[i]);
-        }
-    };
-
-    // ---- the end of a tile: epilogue inside `stg`; the ring keeps receiving the next tile's DMAs meanwhile.  Ends
-    // with a full drain (vmcnt(0) + barrier): the epilogue's own
-    // global loads / stores share the vmcnt counter with the DMAs, so the counted waits restart from a clean slate.
-    bf16_t* cp = (bf16_t*)p.c;
-    const bf16_t* res = (const bf16_t*)p.residual;
-    auto finish_tile = [&](int item) {
-        const int tile = wg + item * G;
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-        const int m0 = tm * BM, n0 = tn * BN;
-#pragma unroll
-        for (int h = 0; h < BM / 64; ++h) {
-            __syncthreads();                         // `stg` no longer read (extension operands / previous half)
-            if ((wave_m * WM) / 64 == h) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int rl = (wave_m * WM) % 64 + i * 16 + fr;
-#pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        *(f32x4*)(stg + rl * SROW + wave_n * WN + j * 16 + 4 * fg) = acc[i][j];
-                }
-            }
-            __syncthreads();
-            for (int e = tid; e < 64 * NC8; e += NT) {
-                const int rl = e / NC8, cc = e - rl * NC8;
-                const int m = m0 + h * 64 + rl, n = n0 + cc * 8;
-                if (m >= M || n >= N) continue;
-                const f32x4 v0 = *(const f32x4*)(stg + rl * SROW + cc * 8);
-                const f32x4 v1 = *(const f32x4*)(stg + rl * SROW + cc * 8 + 4);
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                if (p.act == LECO_ACT_GEGLU) {
-                    if (cc >= 8) continue;
-                    const f32x4 g0 = *(const f32x4*)(stg + rl * SROW + 64 + cc * 8);
-                    const f32x4 g1 = *(const f32x4*)(stg + rl * SROW + 64 + cc * 8 + 4);
-                    float gt[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                    if (p.bias) {
-                        const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
-                        const f32x4 c0 = *(const f32x4*)(p.bias + n + 64), c1 = *(const f32x4*)(p.bias + n + 68);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; gt[r] += c0[r]; gt[4 + r] += c1[r]; }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] *= 0.5f * gt[r] * (1.f + erff(gt[r] * 0.7071067811865476f));
-                    const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-                    *(u32x4*)(cp + (int64_t)m * p.ldc + (n0 >> 1) + cc * 8) = o;
-                    continue;
-                }
-                if (p.bias) {
-                    const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
-                }
-                if (p.rowbias) {
-                    const float* rb = p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias + n;
-                    const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
-                }
-                if (res) {
-                    const u32x4 rr = *(const u32x4*)(res + (int64_t)m * p.ldr + n);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[2 * r] += bf2f((bf16_t)(rr[r] & 0xffffu));
-                        v[2 * r + 1] += bf2f((bf16_t)(rr[r] >> 16));
-                    }
-                }
-                if (p.act == LECO_ACT_SILU) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
-                }
-                if (cp) {
-                    const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
-                    *(u32x4*)(cp + (int64_t)m * p.ldc + n) = o;
-                }
-                if (p.c_f32) {
-                    const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
-                    *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n) = o0;
-                    *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n + 4) = o1;
-                }
-            }
-        }
-        zero_acc();
-        __syncthreads();                             // drains vmcnt: every DMA issued so far has landed
-    };
-
-    // ---- the stream
-#pragma unroll
-    for (int s0 = 0; s0 < NS; ++s0)
-        if (s0 < total) stage(s0);
-    int staged = total < NS ? total : NS;            // K tiles issued so far
-    bool clean = false;                              // true right after a full drain: no DMA outstanding
-    auto wait_tile = [&](int q) {                    // this wave's pieces of K tile q have landed
-        const int younger = clean ? 0 : staged - 1 - q;
-        if (younger >= 2) { if (w_last) wait_vmcnt<2 * (GA + GW)>(); else wait_vmcnt<2 * (GA + GW - 1)>(); }
-        else if (younger == 1) { if (w_last) wait_vmcnt<GA + GW>(); else wait_vmcnt<GA + GW - 1>(); }
-        else wait_vmcnt<0>();
-    };
-    wait_tile(0);
-    barrier_keep_dma();
-    read_frags(0, 0, afA, wfA);
-    for (int q = 0; q < total; ++q) {
-        const int item = q / nkx, kt = q - item * nkx;
-        if (EXT && kt == nk) {
-            // ---- K-extension tile.  Its W side landed by DMA (waited for in the previous iteration); the A side is T,
-            // rounded to bf16 from this wave's accumulators: lane l holds T[16 i + (l & 15)][4 (l >> 4) + r].
-            bf16_t* sA = smem + (q % NS) * TILE;
-            const bf16_t* sB = sA + BM * BK;
-            const int tile = wg + item * G;
-            const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-            bf16_t* tout = (bf16_t*)p.t_out;
-            const int tcol = (TF == 2 ? wave_n * 16 : 0) + 4 * fg;
-#pragma unroll
-            for (int i = 0; i < TFM; ++i) {
-                const int row = wave_m * WM + (t_i0 + i) * 16 + fr;
-                const unsigned lo = pack_bf2(acct[i][0], acct[i][1]), hi = pack_bf2(acct[i][2], acct[i][3]);
-                unsigned* d = (unsigned*)(sA + lds_off(row, tcol >> 3) + (tcol & 7));
-                d[0] = lo;
-                d[1] = hi;
-                if (TF == 1) {       // columns 16..31 of the 32-wide step: explicit zeros (the DMA'd zero page is
-                    unsigned* z = (unsigned*)(sA + lds_off(row, (tcol + 16) >> 3) + (tcol & 7));   // there already)
-                    z[0] = 0u;
-                    z[1] = 0u;
-                }
-                if (tout && tn == 0 && tm * BM + row < M) {
-                    unsigned* g = (unsigned*)(tout + (int64_t)(tm * BM + row) * p.ld_tout + tcol);
-                    g[0] = lo;
-                    g[1] = hi;
-                    if (TF == 1) { g[8] = 0u; g[9] = 0u; }
-                }
-            }
-            barrier_keep_dma();                      // T visible to every wave
-            {
-                bf16x8 af[FM], wf[FN];
-#pragma unroll
-                for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(sA + lds_off(wave_m * WM + i * 16 + fr, fg));
-#pragma unroll
-                for (int j = 0; j < FN; ++j) wf[j] = *(const bf16x8*)(sB + lds_off(wave_n * WN + j * 16 + fr, fg));
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
-            }
-            if (q + 1 < total) wait_tile(q + 1);
-            barrier_keep_dma();                      // slot q % NS fully consumed
-            if (q + NS < total) { stage(q + NS); staged = q + NS + 1; clean = false; }
-            finish_tile(item);
-            clean = true;
-            if (q + 1 < total) read_frags(q + 1, 0, afA, wfA);
-            continue;
-        }
-        read_frags(q, 1, afB, wfB);
-        lds_wait<FM + FNT>();
-        landed(afA, wfA);
-        mma(afA, wfA);
-        sched_fence();
-        if (q + 1 < total) wait_tile(q + 1);
-        barrier_keep_dma();                          // every wave is done with slot q % NS (both halves in registers)
-        landed(afB, wfB);
-        if (q + NS < total) { stage(q + NS); staged = q + NS + 1; clean = false; }
-        const bool next_main = kt + 1 < nk;
-        if (next_main) read_frags(q + 1, 0, afA, wfA);
-        mma(afB, wfB);
-        sched_fence();
-        if (!EXT && kt == nk - 1) {
-            lds_wait<0>();
-            finish_tile(item);
-            clean = true;                            // finish_tile ended with vmcnt(0) + barrier
-            if (q + 1 < total) read_frags(q + 1, 0, afA, wfA);
-        }
-    }
-    lds_wait<0>();
-}
-
 // sums the split-K partial slabs and applies the epilogue (4 consecutive n per thread)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const leco_gemm_args p, const float* ws, int splits) {
     const int M = p.m, N = p.n, nq = N / 4;
@@ -896,54 +584,27 @@ void launch_ns(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t
     launch_k<BM, BN, CONV, NS, NWM, 0>(a, rt, grid, s);
 }
 
-// Pipeline shape by grid size.  Grids that put <= ~1.5 workgroups on a CU get the 4-deep DMA ring
-// (4 x 36 KB for 128x160) and, for 128-row tiles, 8 waves (two per SIMD); larger grids keep two
-// 4-wave workgroups per CU with 2 buffers each, which overlap each other.
+// Pipeline shape by grid size.  One 8-wave workgroup per CU with the 4-deep DMA ring (4 x 36 KB for 128x160; two
+// waves per SIMD) is the default.  Plain 128x128 grids of >= 512 workgroups (the many-round short-K level-0
+// projections, prologue / epilogue bound) run as 4-wave workgroups with 64x64 wave tiles and a 2-deep ring: ~70 KB of
+// LDS and <= 256 VGPRs, so TWO workgroups share a CU and one's prologue / epilogue overlaps the other's K loop
+// (measured on the whole step, profiles/r02_switch_sweep.txt: +1.5 %; two 8-wave 2-buffer workgroups per CU: -0.2 %,
+// a persistent cross-tile-prefetching variant: -2..3.5 % -- both removed).  LECO_GEMM_W4_MIN_BLOCKS overrides the
+// threshold (tools/switch_sweep.sh).
 template <int BM, int BN, bool CONV>
 void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
-    const long blocks = (long)grid.x * grid.y;
-    static const long ns2_min_blocks = [] {   // tuning override: LECO_GEMM_NS2_MIN_BLOCKS.  Default: never -- since the
-        // K loop interleaves DMA issue with the MFMAs, one 8-wave workgroup per CU with the deep ring beats two
-        // resident workgroups with 2 buffers each (measured +1% on the whole step)
-        const char* e = getenv("LECO_GEMM_NS2_MIN_BLOCKS");
-        return e ? atol(e) : 1000000000L;
-    }();
-    // EXPERIMENTAL (unmeasured, off by default): LECO_GEMM_W4_MIN_BLOCKS = n runs plain 128x128 grids of >= n
-    // workgroups as 4-wave workgroups (64x64 wave tiles) with a 2-deep ring: ~70 KB of LDS and <= 256 VGPRs, so TWO
-    // workgroups share a CU and one's prologue / epilogue overlaps the other's K loop (the many-round short-K
-    // level-0 projections are prologue / epilogue bound).
-    static const long w4_min_blocks = [] {
-        const char* e = getenv("LECO_GEMM_W4_MIN_BLOCKS");
-        return e ? atol(e) : 1000000000L;
-    }();
     if constexpr (BM == 64) {
         launch_ns<BM, BN, CONV, 4, 2>(a, rt, grid, s);
     } else {
         if constexpr (BM == 128 && BN == 128 && !CONV) {
-            if (blocks >= w4_min_blocks) return launch_ns<BM, BN, CONV, 2, 2>(a, rt, grid, s);
+            static const long w4_min_blocks = [] {
+                const char* e = getenv("LECO_GEMM_W4_MIN_BLOCKS");
+                return e ? atol(e) : 512L;
+            }();
+            if ((long)grid.x * grid.y >= w4_min_blocks) return launch_ns<BM, BN, CONV, 2, 2>(a, rt, grid, s);
         }
-        if (blocks <= ns2_min_blocks) launch_ns<BM, BN, CONV, 4, 4>(a, rt, grid, s);
-        else launch_ns<BM, BN, CONV, 2, 4>(a, rt, grid, s);
+        launch_ns<BM, BN, CONV, 4, 4>(a, rt, grid, s);
     }
-}
-
-template <int TF>
-void launch_persistent(const leco_gemm_args& a, const GemmRt& rt, int tiles, hipStream_t s) {
-    constexpr int lds_bytes = 3 * (128 + 128 + 16 * TF) * BK * (int)sizeof(bf16_t) + 64 * (128 + 4) * (int)sizeof(float);
-    static_assert(lds_bytes <= 160 * 1024, "LDS ring + epilogue region do not fit");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_persistent_kernel<TF>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
-    }
-    static const int max_grid = [] {                 // LECO_GEMM_PERSISTENT_GRID: test hook (small grids walk many tiles)
-        const char* e = getenv("LECO_GEMM_PERSISTENT_GRID");
-        const int v = e ? atoi(e) : 256;
-        return v > 0 ? v : 256;
-    }();
-    const int grid = tiles < max_grid ? tiles : max_grid;   // one workgroup per CU walks tiles blockIdx.x, + grid, ...
-    hipLaunchKernelGGL((gemm_persistent_kernel<TF>), dim3(grid), dim3(512), lds_bytes, s, a, rt);
 }
 
 template <int BM, int BN>
@@ -951,20 +612,6 @@ int launch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s) {
     const int tm = cdiv(a.m, BM), tn = cdiv(a.n, BN);
     GemmRt rt{tn, split_k, ws};
     dim3 grid((unsigned)(tm * tn), (unsigned)split_k);
-    if constexpr (BM == 128 && BN == 128) {
-        // EXPERIMENTAL (off by default): LECO_GEMM_PERSISTENT_MIN_TILES = n routes plain, unsplit 128x128 problems of
-        // >= n tiles through the persistent cross-tile-prefetching kernel
-        static const long persistent_min_tiles = [] {
-            const char* e = getenv("LECO_GEMM_PERSISTENT_MIN_TILES");
-            return e ? atol(e) : 1000000000L;
-        }();
-        if (a.a_mode == LECO_A_PLAIN && split_k == 1 && !a.a_ext && (long)tm * tn >= persistent_min_tiles) {
-            if (a.t_w && a.t_rows == 16) launch_persistent<1>(a, rt, tm * tn, s);
-            else if (a.t_w) launch_persistent<2>(a, rt, tm * tn, s);
-            else launch_persistent<0>(a, rt, tm * tn, s);
-            return check_launch("leco_gemm");
-        }
-    }
     if constexpr (BM == 256) {   // 256x128 tile: 48 KB per ring slot -> 3-deep ring (144 KB), 8 waves (4 x 2)
         if (a.a_mode == LECO_A_PLAIN) launch_ns<BM, BN, false, 3, 4>(a, rt, grid, s);
         else launch_ns<BM, BN, true, 3, 4>(a, rt, grid, s);

@@ -37,6 +37,7 @@ from .lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV, LoRAN
 from .prompt_util import PromptEmbedsCache, PromptEmbedsPair, PromptSettings
 
 DENOISE_GUIDANCE = 3.0  # hard-coded in the reference loop (train_lora.py:192)
+DP_BASE_SEED = 1234     # data parallel: LoRA init seed (all ranks); rank r's data stream is seeded DP_BASE_SEED + 1 + r
 
 
 def dist_info():
@@ -296,13 +297,31 @@ class FusedStep:
 STATE_KEYS = ("slab", "exp_avg", "exp_avg_sq")
 
 
+def _rank_rng_states(dev) -> dict:
+    """This rank's generator states: the CPU stream (prompt pair, resolution bucket, crops, initial latents --
+    train_lora.py:148-176) and, on a GPU, the device stream (ancestral noise of ddpm / euler_a)."""
+    st = {"cpu": torch.get_rng_state()}
+    if dev.type == "cuda":
+        st["cuda"] = torch.cuda.get_rng_state(dev)
+    return st
+
+
 def save_training_state(path, fused: "FusedStep", iteration: int, lr_scheduler=None) -> None:
-    """Everything a bit-exact continuation needs (the reference cannot resume): fp32 master slab, optimizer
-    moments and step count, the iteration, the CPU RNG state (prompt choice, k, initial latents are all drawn from
-    it, train_lora.py:148-176) and the LR-scheduler state."""
+    """Everything a continuation needs (the reference cannot resume): fp32 master slab, optimizer moments and step
+    count, the iteration, EVERY rank's RNG state and the LR-scheduler state.  Collective when data parallel (all
+    ranks call it; rank 0 writes).  Tensors and primitives only, so the file loads with ``weights_only=True``."""
     net = fused.net
+    rngs = [_rank_rng_states(fused.dev)]
+    rank = 0
+    if fused.world > 1:
+        import torch.distributed as dist
+        rank = dist.get_rank(fused.pg)
+        rngs = [None] * fused.world
+        dist.all_gather_object(rngs, _rank_rng_states(fused.dev), group=fused.pg)
+    if rank != 0:
+        return
     blob = {k: getattr(net, k).detach().cpu().clone() for k in STATE_KEYS}
-    blob.update(opt_step=fused.opt_step, iteration=int(iteration), rng=torch.get_rng_state(),
+    blob.update(opt_step=fused.opt_step, iteration=int(iteration), rng=rngs,
                 lr_scheduler=None if lr_scheduler is None else lr_scheduler.state_dict(),
                 optimizer=None if isinstance(fused.optimizer, str) else fused.optimizer.state_dict())
     torch.save(blob, path)
@@ -310,7 +329,7 @@ def save_training_state(path, fused: "FusedStep", iteration: int, lr_scheduler=N
 
 def load_training_state(path, fused: "FusedStep", lr_scheduler=None) -> int:
     """Restores `save_training_state`; returns the next iteration index."""
-    blob = torch.load(path, map_location="cpu", weights_only=False)
+    blob = torch.load(path, map_location="cpu", weights_only=True)
     net = fused.net
     with torch.no_grad():
         for k in STATE_KEYS:
@@ -323,7 +342,16 @@ def load_training_state(path, fused: "FusedStep", lr_scheduler=None) -> int:
         # recursive schedules (cosine) continue from the optimizer's current lr, which the scheduler state lacks
         for group, lr in zip(lr_scheduler.optimizer.param_groups, lr_scheduler.get_last_lr()):
             group["lr"] = lr
-    torch.set_rng_state(blob["rng"])
+    rank = 0
+    if fused.world > 1:
+        import torch.distributed as dist
+        rank = dist.get_rank(fused.pg)
+    rngs = blob["rng"]
+    if rank >= len(rngs):
+        raise ValueError(f"state file holds RNG streams for {len(rngs)} ranks; this run has rank {rank}")
+    torch.set_rng_state(rngs[rank]["cpu"])
+    if fused.dev.type == "cuda" and "cuda" in rngs[rank]:
+        torch.cuda.set_rng_state(rngs[rank]["cuda"], fused.dev)
     net.sync_shadow()
     net.mark_updated()
     return int(blob["iteration"]) + 1
@@ -393,11 +421,17 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
     unet.eval()
     unet.use_graphs = use_graphs and device.type == "cuda"
 
-    if world > 1:   # identical LoRA init on every rank
-        torch.manual_seed(1234)
+    if world > 1:   # identical LoRA init on every rank ...
+        torch.manual_seed(DP_BASE_SEED)
     network = LoRANetwork(unet, rank=config.network.rank, multiplier=1.0, alpha=config.network.alpha,
                           train_method=config.network.training_method, target_replace_modules=modules
                           ).to(device, dtype=weight_dtype)
+
+    if world > 1:
+        # ... and from here on every rank draws its OWN prompt pair / resolution / crops / latents (the reference's
+        # sampling sites train_lora.py:148-156,175-177 all use the global CPU stream); only k comes from the shared
+        # generator below
+        torch.manual_seed(DP_BASE_SEED + 1 + rank)
 
     opt_name = config.train.optimizer.lower()
     optimizer_kwargs = _parse_optimizer_args(config.train.optimizer_args)
@@ -475,16 +509,18 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
             wandb.log({"loss": loss.item(), "iteration": i, "lr": lr_scheduler.get_last_lr()[0]})
         _dummy.step()
         lr_scheduler.step()
-        if i % config.save.per_steps == 0 and i != 0 and i != config.train.iterations - 1 and rank == 0:
-            print("Saving...")
-            save_path.mkdir(parents=True, exist_ok=True)
-            network.save_weights(save_path / f"{config.save.name}_{i}steps.safetensors", dtype=save_weight_dtype,
-                                 metadata=metadata)
-            if save_state:
+        if i % config.save.per_steps == 0 and i != 0 and i != config.train.iterations - 1:
+            if rank == 0:
+                print("Saving...")
+                save_path.mkdir(parents=True, exist_ok=True)
+                network.save_weights(save_path / f"{config.save.name}_{i}steps.safetensors", dtype=save_weight_dtype,
+                                     metadata=metadata)
+            if save_state:      # collective: gathers every rank's RNG streams, rank 0 writes
                 save_training_state(save_path / f"{config.save.name}_state.pt", fused, i, lr_scheduler)
         if stop_after is not None and i >= stop_after:
-            if save_state and rank == 0:
-                save_path.mkdir(parents=True, exist_ok=True)
+            if save_state:
+                if rank == 0:
+                    save_path.mkdir(parents=True, exist_ok=True)
                 save_training_state(save_path / f"{config.save.name}_state.pt", fused, i, lr_scheduler)
             break
     if rank == 0:

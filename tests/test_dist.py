@@ -106,3 +106,58 @@ def test_two_rank_step_equals_gradient_average():
               1e-2, net2.slab.numel()).run()
     assert torch.equal(net2.slab.detach()[:net2.numel], res[0][0])
     assert rel(net.slab.detach()[:net.numel], res[0][0]) < 2e-2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# train() itself under data parallelism (every rank used to draw the SAME prompt pair and noise)
+def _train_worker(rank, world, port, q, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    _setup()
+    from leco_amd import config_util, prompt_util, train as T
+    seen = []
+    orig = T.FusedStep.step
+
+    def spy(self, pair, timesteps_to, latents, **kw):
+        seen.append((int(timesteps_to), float(latents.double().sum()), pair.target.flatten()[0].item()))
+        return orig(self, pair, timesteps_to, latents, **kw)
+    T.FusedStep.step = spy
+    cfg = config_util.RootConfig(
+        prompts_file="unused", pretrained_model=dict(name_or_path="synthetic:tiny"),
+        network=dict(type="lierla", rank=4, alpha=1.0),
+        train=dict(precision="bfloat16", noise_scheduler="ddim", iterations=4, lr=1e-3, optimizer="AdamW",
+                   lr_scheduler="constant", max_denoising_steps=4),
+        save=dict(name="dp", path=out_dir, per_steps=100), logging={}, other={})
+    prompts = [prompt_util.PromptSettings(target=t, positive=t, unconditional="", neutral="", action="erase",
+                                          guidance_scale=1.0, resolution=64, batch_size=1) for t in ("van gogh", "monet")]
+    with contextlib.redirect_stdout(io.StringIO()):
+        net, _ = T.train(cfg, prompts, device=torch.device("cpu"), use_graphs=False, progress=False, save_state=True,
+                         stop_after=1)
+    q.put((rank, seen, net.slab.detach()[:net.numel].clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_under_dp_draws_per_rank_data_and_a_shared_k(tmp_path):
+    """rank r draws its own prompt pair and noise, `k` comes from a shared-seed generator, the LoRA
+    parameters stay identical; the resumable state holds one RNG stream per rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(2):
+        r, seen, slab = q.get(timeout=900)
+        res[r] = (seen, slab)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    s0, s1 = res[0][0], res[1][0]
+    assert len(s0) == len(s1) == 2
+    assert [k for k, _, _ in s0] == [k for k, _, _ in s1], "ranks must run the same number of denoising passes"
+    assert all(a[1] != b[1] for a, b in zip(s0, s1)), "ranks drew identical initial latents"
+    assert torch.equal(res[0][1], res[1][1]), "LoRA parameters diverged across ranks"
+    blob = torch.load(tmp_path / "dp_state.pt", map_location="cpu", weights_only=True)
+    assert len(blob["rng"]) == 2 and not torch.equal(blob["rng"][0]["cpu"], blob["rng"][1]["cpu"])

@@ -95,6 +95,33 @@ def test_gemm_fused_lora_down_projection(dev, tile, t_rows, split, M, N, K):
     assert rel_err(o32, ref) < TOL32
 
 
+@pytest.mark.parametrize("tile,t_rows,M,N,K", [(3, 16, 1024, 3840, 1280), (3, 16, 1024, 1280, 320), (1, 16, 4096, 1920, 640),
+                                               (2, 32, 2048, 640, 640), (4, 16, 4096, 1280, 1280)])
+def test_gemm_fused_lora_full_grid_deep_k_is_race_free(dev, tile, t_rows, M, N, K):
+    """Grids that put two workgroups on a CU, K deep enough for the steady-state loop, repeated launches: the shapes
+    the full-size UNet runs and the tiny tests never reached (round-1 NaN: proj_in 1024 x 1280 x 1280 on the 64 x 64
+    fused-down-projection tile, wrong on a fraction of the launches only).  The emulator tier checks a cut-down grid."""
+    torch.manual_seed(15)
+    if dev.type == "cpu":
+        M, N = min(M, 256), min(N, 384)
+    R = 12 if t_rows == 16 else 24
+    a = torch.randn(M, K).to(bf).to(dev); w = (torch.randn(N, K) / K ** 0.5).to(bf).to(dev)
+    tw = torch.zeros(32, K); tw[:R] = torch.randn(R, K) / K ** 0.5
+    tw = tw.to(bf).to(dev)
+    up = torch.zeros(N, 32); up[:, :R] = torch.randn(N, R) * 0.3
+    up = up.to(bf).to(dev)
+    T = (a.float() @ tw.float().T).to(bf)
+    ref = a.float() @ w.float().T + T.float() @ up.float().T
+    for rep in range(6 if dev.type == "cuda" else 1):
+        out = torch.zeros(M, N, dtype=bf, device=dev); tout = torch.zeros(M, 32, dtype=bf, device=dev)
+        g = hip.gemm_args(a, w, out, m=M, n=N, k=K, w_ext=up, ext_k=32, t_w=tw, t_rows=t_rows, t_out=tout)
+        hip.gemm(g, ops.default_stream(), tile, 1, None)
+        _sync(dev)
+        assert torch.isfinite(out.float()).all(), rep
+        assert (out.float() - ref).abs().max().item() < 0.05 * ref.abs().max().item(), rep
+        assert rel_err(out, ref) < TOLBF, rep
+
+
 @pytest.mark.parametrize("tile,M,F,K,lora", [(0, 300, 128, 192, False), (1, 200, 256, 320, True), (4, 520, 128, 128, True)])
 def test_gemm_fused_geglu_epilogue(dev, tile, M, F, K, lora):
     """LECO_ACT_GEGLU: interleaved value / gate weight rows, value * gelu(gate) written as [M][F] (diffusers GEGLU)."""
