@@ -521,6 +521,12 @@ class Engine:
         plan.lists.clear()
         plan.bufs.clear()
 
+    def release(self) -> None:
+        """Drop every plan (instantiated hipGraphs, activation buffers).  The engine stays usable: plans are rebuilt on
+        demand."""
+        for key in list(self.plans):
+            self.drop_plan(key)
+
 
 class PlanBuilder:
     def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True):
@@ -1087,6 +1093,11 @@ class UNet2DConditionModel(nn.Module):
         if self._engine is None:
             self._engine = Engine(self, self.device)
         return self._engine
+
+    def release(self) -> None:
+        """Free the launch plans (hipGraph execs + activation buffers) this model has built."""
+        if self._engine is not None:
+            self._engine.release()
 
     # ---- execution ----------------------------------------------------------------------------------
     def _run(self, plan: Plan, which: str) -> None:

@@ -1,0 +1,232 @@
+"""Full-size parity on gfx950 (`-m gpu`) of the launch plans a training step ACTUALLY runs, at the BASELINE.json
+configurations -- the round-1 NaN lived in plans no test reached (forward-only B = 2 bs with the fused GEGLU
+epilogue and fused LoRA down-projection, batched frozen B = 6 bs, the backward at 64^2 latents).
+
+One `FusedStep.step` with hipGraphs on (exactly what bench.py / train() execute) against ONE iteration of the
+reference loop restated on the fp32 oracle (oracle/step_ref.leco_step = train_lora.py:141-281; UNet / DDIM / LoRA
+oracles), both on the GPU box:
+
+    denoised latents  <- k passes of the forward-only LoRA-ON plan + CFG/DDIM kernel   (train_util.py:172-193)
+    positive / neutral / unconditional predictions <- the batched LoRA-OFF plan         (train_lora.py:202-237)
+    target prediction <- the training plan, LoRA ON                                      (train_lora.py:244-256)
+    loss, LoRA gradients (backward plan), AdamW-updated parameters                       (train_lora.py:265-281)
+
+Tolerance: relative L2 vs the fp32 oracle, calibrated by the error the SAME oracle graph makes when
+run in plain torch bf16 on the same device: rel_hip <= 1.25 * rel_torch_bf16 (floors for quantities whose bf16
+error happens to be tiny).  Results are printed (`-s`) and copied into profiles/ by tools/gpu_round_run.sh."""
+import contextlib
+import io
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import pytest
+import torch
+
+from conftest import rel_err
+from leco_amd import model_util, prompt_util
+from leco_amd.lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV, LoRANetwork
+from leco_amd.scheduler import create_noise_scheduler
+from leco_amd.train import FusedStep
+from leco_amd.unet import UNet2DConditionModel
+from oracle import lora_ref, step_ref
+from oracle import unet_ref as R
+from oracle.ddim_ref import DDIMSchedulerRef
+
+bf = torch.bfloat16
+pytestmark = pytest.mark.gpu
+NAMES = ("target", "positive", "neutral", "unconditional")
+ARCH = {"sd15": (R.sd15_config, 768), "sd21": (R.sd21_config, 1024), "sdxl": (R.sdxl_config, 2048)}
+
+
+def _device():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from conftest import _bind_hip
+    _bind_hip()
+    return torch.device("cuda:0")
+
+
+def _models(arch, dev, seed, m):
+    """Oracle + HIP model with the same bf16-representable synthetic weights.  Built and initialised ON the device
+    (SURVEY 8d rule: U(+-1/sqrt(fan_in)) matrices, norm gamma 1 / beta 0, small biases): the CPU constructors' default
+    init alone costs ~20 s per SD1.5-sized model."""
+    with torch.device(dev):
+        ref = R.UNet2DConditionModel(ARCH[arch][0]())
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if p.ndim >= 2:
+                p.copy_(((torch.rand(p.shape, generator=gen, device=dev) * 2 - 1) / p[0].numel() ** 0.5).to(bf).float())
+            elif "norm" in name:
+                p.fill_(1.0 if name.endswith("weight") else 0.0)
+            else:
+                p.copy_(((torch.rand(p.shape, generator=gen, device=dev) * 2 - 1) * 0.02).to(bf).float())
+    ref.requires_grad_(False)
+    m.load_state_dict(ref.state_dict())
+    m.to(dev, bf)
+    m.requires_grad_(False)
+    return ref
+
+
+def _loras(ref, m, rank, c3lier, gen):
+    targets = list(DEFAULT_TARGET_REPLACE) + (list(UNET_TARGET_REPLACE_MODULE_CONV) if c3lier else [])
+    with contextlib.redirect_stdout(io.StringIO()):
+        rnet = lora_ref.LoRANetworkRef(ref, rank=rank, targets=targets)
+        net = LoRANetwork(m, rank=rank, multiplier=1.0, alpha=1.0, target_replace_modules=targets)
+    assert [l.lora_name for l in rnet.unet_loras] == [l.lora_name for l in net.unet_loras]
+    dev = next(ref.parameters()).device
+    rnet.to(dev)
+    with torch.no_grad():
+        for rl, l in zip(rnet.unet_loras, net.unet_loras):
+            fan_in = rl.lora_down.weight[0].numel()
+            d = ((torch.rand(rl.lora_down.weight.shape, generator=gen) * 2 - 1) / fan_in ** 0.5).to(bf).float()
+            u = (torch.randn(rl.lora_up.weight.shape, generator=gen) * 0.02).to(bf).float()
+            rl.lora_down.weight.copy_(d)
+            rl.lora_up.weight.copy_(u)
+            l.lora_down.weight.copy_(d.reshape(l.lora_down.weight.shape))
+            l.lora_up.weight.copy_(u.reshape(l.lora_up.weight.shape))
+    net.mark_updated()
+    return rnet, net
+
+
+def _ref_grads(rnet):
+    return torch.cat([p.grad.reshape(-1).float() for l in rnet.unet_loras for p in (l.lora_down.weight, l.lora_up.weight)])
+
+
+def _oracle_step(ref, rnet, emb, lat, k, bs, gscale, action, dtype, pooled=None, ids=None, v_pred=False):
+    """One reference iteration on the oracle graph in `dtype`; returns tensors in fp32 + the LoRA gradients."""
+    ref.to(dtype)
+    rnet.to(dtype)
+    for p in rnet.parameters():
+        p.grad = None
+    sched = DDIMSchedulerRef(prediction_type="v_prediction" if v_pred else "epsilon")
+    e = {n: v.to(dtype) for n, v in emb.items()}
+    pl = None if pooled is None else {n: v.to(dtype) for n, v in pooled.items()}
+    out = step_ref.leco_step(ref, rnet, sched, e, lat.to(dtype), k, 50, guidance_scale=gscale, action=action, batch_size=bs,
+                             pooled=pl, add_time_ids=None if ids is None else ids.to(dtype))
+    if os.environ.get("LECO_FS_NOBWD"):      # experiment switch (segfault hunt): skip the oracle's autograd pass
+        for p in rnet.parameters():
+            p.grad = torch.zeros_like(p)
+    else:
+        out["loss"].float().backward()
+    res = dict(denoised=out["denoised"].float(), loss=float(out["loss"].detach()), grads=_ref_grads(rnet), t_cur=out["t_cur"])
+    res.update({n: out["preds"][n].detach().float() for n in NAMES})
+    ref.to(torch.float32)
+    rnet.to(torch.float32)
+    return res
+
+
+def _check_step(arch, res, bs, rank, k, **kw):
+    dev = _device()
+    with torch.device(dev):
+        m = UNet2DConditionModel(model_util.SYNTHETIC[arch]())
+    try:
+        return _check_step_on(dev, m, arch, res, bs, rank, k, **kw)
+    finally:        # several multi-GB models run in one process: give graphs and buffers back before the next one
+        m.release()
+        del m
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+
+
+def _check_step_on(dev, m, arch, res, bs, rank, k, c3lier=False, v_pred=False, gscale=1.0, action="erase", seed=1234,
+                   lr=1e-4):
+    ref = _models(arch, dev, seed, m)
+    g = torch.Generator().manual_seed(seed + 1)
+    rnet, net = _loras(ref, m, rank, c3lier, g)
+    cdim = ARCH[arch][1]
+    xl = arch == "sdxl"
+    emb = {n: torch.randn(1, 77, cdim, generator=g).to(bf).float().to(dev) for n in NAMES}
+    pooled = {n: torch.randn(1, 1280, generator=g).to(bf).float().to(dev) for n in NAMES} if xl else None
+    ids = torch.tensor([[float(res), float(res), 0.0, 0.0, float(res), float(res)]], device=dev) if xl else None
+    lat = torch.randn(bs, 4, res // 8, res // 8, generator=g).to(dev)
+    gold = _oracle_step(ref, rnet, emb, lat, k, bs, gscale, action, torch.float32, pooled, ids, v_pred)
+    cal_out = _oracle_step(ref, rnet, emb, lat, k, bs, gscale, action, bf, pooled, ids, v_pred)
+    cal = {n: rel_err(cal_out[n], gold[n]) for n in ("denoised", "grads") + NAMES}
+    cal["loss"] = abs(cal_out["loss"] - gold["loss"]) / gold["loss"]
+    # ---- the HIP path, as train() / bench.py run it
+    m.use_graphs = True
+    if xl:
+        mk = lambda n: prompt_util.PromptEmbedsXL(emb[n], pooled[n])
+    else:
+        mk = lambda n: emb[n]
+    settings = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=gscale,
+                                          batch_size=bs, resolution=res, action=action)
+    pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), mk("target"), mk("positive"), mk("unconditional"), mk("neutral"),
+                                        settings)
+    sched = create_noise_scheduler("ddim", prediction_type="v_prediction" if v_pred else "epsilon")
+    fs = FusedStep(m, net, sched, 50, lr=lr)
+    before = net.slab.detach()[:net.numel].clone()
+    loss = fs.step(pair, k, lat.clone(), add_time_ids=ids)
+    torch.cuda.synchronize()
+    st = fs._state[(bs, res // 8, res // 8)]
+    got = dict(denoised=st["x"], target=st["plan"].pred[bs:], grads=net.grad[:net.numel])
+    got.update({n: st["preds"][n][bs:] for n in ("positive", "neutral", "unconditional")})
+    err = {n: rel_err(got[n], gold[n]) for n in got}
+    err["loss"] = abs(loss.item() - gold["loss"]) / gold["loss"]
+    print(f"\n{arch} {res}^2 bs={bs} rank={rank}{' c3lier' if c3lier else ''}{' v-pred' if v_pred else ''} k={k} "
+          f"t_cur={gold['t_cur']} loss={loss.item():.4e} (oracle {gold['loss']:.4e})")
+    for n in ("denoised",) + NAMES + ("loss", "grads"):
+        print(f"    {n:14s} rel_hip={err[n]:.3e}   rel_torch_bf16={cal[n]:.3e}")
+    assert all(torch.isfinite(v.float()).all() for v in got.values()) and torch.isfinite(loss).all()
+    for n in ("denoised",) + NAMES:
+        assert err[n] <= max(1.25 * cal[n], 2e-3), (n, err[n], cal[n])
+    assert err["loss"] <= max(1.25 * cal["loss"], 3e-2), (err["loss"], cal["loss"])
+    assert err["grads"] <= max(1.25 * cal["grads"], 3e-2), (err["grads"], cal["grads"])
+    # AdamW moved every parameter that has a gradient, by at most lr (first step: |update| <= lr (1 + wd |p|))
+    after = net.slab.detach()[:net.numel]
+    delta = (after - before).abs()
+    assert torch.isfinite(after).all() and delta.max().item() <= lr * 1.05 and (delta > 0).float().mean().item() > 0.9
+    # a second step on the updated parameters stays finite (re-packed LoRA operands, graph replay)
+    loss2 = fs.step(pair, 1, lat.clone(), add_time_ids=ids)
+    assert torch.isfinite(loss2).all() and torch.isfinite(net.grad).all()
+    return err, cal
+
+
+CASES = {
+    # BASELINE config 2 (the headline benchmark shape): SD1.5, 512^2, prompt batch 2, rank-4 lierla
+    "sd15_512_bs2_rank4": dict(arch="sd15", res=512, bs=2, rank=4, k=2),
+    # same shapes, the other branch of the objective (action = enhance, guidance_scale 3), k = 3
+    "sd15_512_bs2_rank4_enhance_g3": dict(arch="sd15", res=512, bs=2, rank=4, k=3, gscale=3.0, action="enhance", seed=4321),
+    # BASELINE config 3: SD2.1 (linear projections, head dim 64), v-prediction, 768^2, prompt batch 2
+    "sd21_768_bs2_rank4_vpred": dict(arch="sd21", res=768, bs=2, rank=4, k=2, v_pred=True, seed=77),
+    # BASELINE config 4: SD1.5, rank-8 c3lier (conv + time_emb_proj LoRA, 278 modules), 512^2, prompt batch 4
+    "sd15_512_bs4_rank8_c3lier": dict(arch="sd15", res=512, bs=4, rank=8, k=2, c3lier=True, seed=99),
+    # BASELINE config 5: SDXL (depth 2 / 10 transformers, text_time add-embedding), rank 16, 1024^2, prompt batch 1
+    "sdxl_1024_bs1_rank16": dict(arch="sdxl", res=1024, bs=1, rank=16, k=2, seed=5),
+}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_full_size_step_vs_oracle(case):
+    """Each configuration runs in its own interpreter (`python tests/test_fullsize.py <case>`): one process then holds
+    one fp32 oracle + one HIP model, and a crash in one configuration cannot take the rest of the suite down.
+    (Open issue, DESIGN.md section 8: capturing graphs for a SECOND multi-GB model in a process that has run the fp32
+    oracle's autograd backward on the GPU segfaults inside hipStreamBeginCapture on ROCm 7.2.)"""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), case], capture_output=True, text=True, timeout=1500,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = "\n".join(l for l in r.stdout.splitlines() if "rel_hip" in l or "loss=" in l)
+    print("\n" + out)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "PASS " + case in r.stdout
+
+
+if __name__ == "__main__":
+    import sys
+    for name in sys.argv[1:]:
+        try:
+            _check_step(**CASES[name])
+        except AssertionError:
+            if not os.environ.get("LECO_FS_NOBWD"):
+                raise
+        print("PASS " + name, flush=True)
