@@ -35,31 +35,65 @@ def step_flops(bs: int, k: int) -> float:
     return 2 * bs * F_FWD_SD15_512 * (k + 5 + ATTN_SHARE)
 
 
-def cpu_baseline(seconds_budget: float = 30.0):
-    """The oracle (CPU restatement of the reference's diffusers UNet) timed on the host cores:
-    whole fp32 B=2 SD1.5 forward passes at 512^2 (config 0: bs=1), extrapolated to a k=25 step with
-    W_ref(k): t_step = (k + 4) t_fwd + (1 + 1 + a) t_fwd."""
+def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 150.0):
+    """The reference loop on the host CPU (BASELINE.json configs[0]: SD1.5, rank 4, 512^2, prompt batch 1, fp32,
+    DDIM, AdamW), as a port: `oracle/step_ref.leco_step` restates one iteration of train_lora.py:141-281 on the
+    oracle UNet / DDIM / LoRA (the reference's own files need `diffusers` and do not exist on the GPU box), followed
+    by `loss.backward()`, `optimizer.step()`, `lr_scheduler.step()` and the reference's per-step `flush()`
+    (train_lora.py:279-290).  FULL optimizer steps are timed, one per entry of `ks` (k denoising passes each); a step
+    costs a + b k, so two steps with different k give both coefficients, which are then evaluated at the k mean of
+    the GPU run and scaled by the prompt batch (2 x the samples -> 2 x the time; a CPU has no idle lanes to fill)."""
+    import gc
+    from oracle import lora_ref, step_ref
     from oracle import unet_ref as R
-    torch.manual_seed(0)
-    with torch.device("cpu"):
-        m = R.UNet2DConditionModel(R.sd15_config())
-    m.requires_grad_(False)
-    x = torch.randn(2, 4, 64, 64)
-    ctx = torch.randn(2, 77, 768)
-    times = []
-    t_start = time.perf_counter()
+    from oracle.ddim_ref import DDIMSchedulerRef
+    torch.manual_seed(1234)
+    unet = R.init_synthetic_(R.UNet2DConditionModel(R.sd15_config()), seed=1234)
+    unet.requires_grad_(False)
+    unet.eval()
+    net = lora_ref.LoRANetworkRef(unet, rank=4, multiplier=1.0, alpha=1.0)
+    g = torch.Generator().manual_seed(99)
     with torch.no_grad():
-        while len(times) < 3 and (time.perf_counter() - t_start) < seconds_budget:
-            t0 = time.perf_counter()
-            m(x, torch.tensor(500), encoder_hidden_states=ctx)
-            times.append(time.perf_counter() - t0)
-    t_fwd = min(times)
-    k = 25
-    t_step = (k + 4) * t_fwd + (2 + ATTN_SHARE) * t_fwd
+        for l in net.unet_loras:
+            l.lora_up.weight.copy_(torch.randn(l.lora_up.weight.shape, generator=g) * 0.02)
+    params = [p for l in net.unet_loras for p in (l.lora_down.weight, l.lora_up.weight)]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    lrs = torch.optim.lr_scheduler.ConstantLR(opt, factor=1, total_iters=1000)
+    sched = DDIMSchedulerRef()
+    eg = torch.Generator().manual_seed(4321)
+    emb = {n: torch.randn(1, 77, 768, generator=eg) for n in ("target", "neutral")}
+    emb["positive"], emb["unconditional"] = emb["target"], emb["neutral"]       # 'van gogh' erase: 2 distinct prompts
+    times, losses = [], []
+    t_all = time.perf_counter()
+    for i, k in enumerate(ks):
+        if times and time.perf_counter() - t_all + times[-1] * 1.3 > budget_s:
+            break
+        lat = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(1000 + i))
+        t0 = time.perf_counter()
+        out = step_ref.leco_step(unet, net, sched, emb, lat, k, 50, guidance_scale=1.0, action="erase", batch_size=1)
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+        lrs.step()
+        del out
+        gc.collect()
+        times.append(time.perf_counter() - t0)
+        losses.append(None)
+    if len(times) >= 2 and ks[1] != ks[0]:
+        b = (times[1] - times[0]) / (ks[1] - ks[0])
+        a = times[0] - b * ks[0]
+        how = f"a + b k with a = {a:.1f} s, b = {b:.1f} s from the two steps"
+    else:   # one step only: W_ref(k) = 2 bs F_fwd (k + 5 + a_attn)
+        b = times[0] / (ks[0] + 5 + ATTN_SHARE)
+        a = b * (5 + ATTN_SHARE)
+        how = f"W_ref(k): {b:.1f} s per forward-equivalent from the one step"
+    t_step = bs * (a + b * k_mean)
     return {"value": 1.0 / t_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} fp32 forward passes of the oracle SD1.5 UNet (B=2, 512^2, bs=1) = {t_fwd:.2f} s "
-                      f"each, extrapolated to one k=25 step with W_ref(k) (fwd-equivalents: k+4 fwd, 1 fwd + bwd)",
-            "host_cpus": os.cpu_count()}
+            "sample": f"{len(times)} full fp32 optimizer steps of the ported reference loop at prompt batch 1 with k = "
+                      f"{list(ks[:len(times)])}: {', '.join(f'{t:.1f} s' for t in times)}; evaluated at k = {k_mean:.1f} "
+                      f"and prompt batch {bs} ({how})",
+            "steps_timed": len(times), "k": list(ks[:len(times)]), "step_seconds": times,
+            "host_cpus": os.cpu_count(), "threads": torch.get_num_threads()}
 
 
 def dominant_kernel_roofline(dev):
@@ -124,12 +158,23 @@ def main():
                                                      "(0 = the seeded reference distribution; the headline number uses 0)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: re-launch this script as N ranks (one process per GPU) under torchrun
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     from leco_amd import model_util, prompt_util, train_util
     from leco_amd.lora import LoRANetwork
     from leco_amd.train import FusedStep, init_distributed
 
     rank, world, local = init_distributed()
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"launch with torchrun --nproc-per-node {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
@@ -219,7 +264,7 @@ def main():
         out["roofline"]["dominant_kernel"] = {"error": repr(e)}
     if world == 1 and not args.no_cpu_baseline:
         try:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(sum(timed_ks) / len(timed_ks), args.bs)
         except Exception as e:  # the baseline leg must never hide the GPU number
             out["cpu_baseline"] = {"value": None, "error": repr(e)}
     print(json.dumps(out))

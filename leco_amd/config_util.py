@@ -1,79 +1,104 @@
-"""Training-config YAML schema of the reference (`config_util.py:13-72`: sections pretrained_model / network /
-train / save / logging / other under a root with `prompts_file`), `parse_precision` (`:75-83`) and
-`load_config_from_yaml` (`:86-104`).
-
-The sections are declared once in `_SECTIONS` (field -> (type, default)) and turned into pydantic-v2 models with
-`create_model`; the same table drives the loader's "missing optional section -> its defaults" rule (`:92-102`; under
-pydantic v2 a bare `Optional[X]` would be *required*, so the optional sections default to None here) and the
-`describe()` helper used in error messages.  Unknown keys are ignored and YAML strings such as `lr: 1e-4` are coerced
-to float, as with the reference's models."""
-from typing import Dict, Literal, Optional, Tuple
+"""Config YAML schema -- same keys, defaults and loader behaviour as the reference's
+``config_util.py`` (RootConfig :60-72, parse_precision :75-83, load_config_from_yaml :86-104),
+written for pydantic v2 (under v2 the reference's bare ``Optional[X]`` sections become
+required; here they default to None and are filled in by the loader, which is what the
+reference intends at :92-102).  Unknown keys are ignored and ``lr: 1e-4`` (a YAML string)
+is coerced to float, as in the reference."""
+from typing import Literal, Optional
 
 import torch
 import yaml
-from pydantic import BaseModel, create_model
+from pydantic import BaseModel, field_validator
 
 from .lora import TRAINING_METHODS
 
 PRECISION_TYPES = Literal["fp32", "fp16", "bf16", "float32", "float16", "bfloat16"]
 NETWORK_TYPES = Literal["lierla", "c3lier"]
-SCHEDULER_NAMES = Literal["ddim", "ddpm", "lms", "euler_a"]
-_REQUIRED = ...
 
-# section name -> (model class name, optional at the root?, {field: (annotation, default)})
-_SECTIONS: Dict[str, Tuple[str, bool, Dict[str, tuple]]] = {
-    "pretrained_model": ("PretrainedModelConfig", False, {
-        "name_or_path": (str, _REQUIRED), "v2": (bool, False), "v_pred": (bool, False),
-        "clip_skip": (Optional[int], None)}),
-    "network": ("NetworkConfig", False, {
-        "type": (NETWORK_TYPES, "lierla"), "rank": (int, 4), "alpha": (float, 1.0),
-        "training_method": (TRAINING_METHODS, "full")}),
-    "train": ("TrainConfig", True, {
-        "precision": (PRECISION_TYPES, "bfloat16"), "noise_scheduler": (SCHEDULER_NAMES, "ddim"),
-        "iterations": (int, 500), "lr": (float, 1e-4), "optimizer": (str, "adamw"), "optimizer_args": (str, ""),
-        "lr_scheduler": (str, "constant"), "max_denoising_steps": (int, 50)}),
-    "save": ("SaveConfig", True, {
-        "name": (str, "untitled"), "path": (str, "./output"), "per_steps": (int, 200),
-        "precision": (PRECISION_TYPES, "float32")}),
-    "logging": ("LoggingConfig", True, {"use_wandb": (bool, False), "verbose": (bool, False)}),
-    "other": ("OtherConfig", True, {"use_xformers": (bool, False)}),
-}
 
-_MODELS = {sec: create_model(cls, __base__=BaseModel, __module__=__name__, **fields)
-           for sec, (cls, _, fields) in _SECTIONS.items()}
-PretrainedModelConfig = _MODELS["pretrained_model"]
-NetworkConfig = _MODELS["network"]
-TrainConfig = _MODELS["train"]
-SaveConfig = _MODELS["save"]
-LoggingConfig = _MODELS["logging"]
-OtherConfig = _MODELS["other"]
+class PretrainedModelConfig(BaseModel):
+    name_or_path: str
+    v2: bool = False
+    v_pred: bool = False
+    clip_skip: Optional[int] = None
 
-RootConfig = create_model(
-    "RootConfig", __base__=BaseModel, __module__=__name__, prompts_file=(str, _REQUIRED),
-    **{sec: ((Optional[_MODELS[sec]], None) if optional else (_MODELS[sec], _REQUIRED))
-       for sec, (_, optional, _f) in _SECTIONS.items()})
 
-_DTYPES = {torch.float32: ("fp32", "float32"), torch.float16: ("fp16", "float16"), torch.bfloat16: ("bf16", "bfloat16")}
+MAX_LORA_RANK = 16   # leco_lora_wgrad keeps <= 16 rank columns in registers; q|k|v share one 64-wide K-extension tile
+
+
+class NetworkConfig(BaseModel):
+    type: NETWORK_TYPES = "lierla"
+    rank: int = 4
+    alpha: float = 1.0
+    training_method: TRAINING_METHODS = "full"
+
+    @field_validator("rank")
+    @classmethod
+    def _rank_fits_the_fused_lora_tile(cls, rank: int) -> int:
+        # the reference accepts any rank; the MI355X path fuses the low-rank product into the weight GEMM as one
+        # K-extension tile, which bounds it (README "Limits").  Fail at config time, not after the model has loaded.
+        if not 1 <= rank <= MAX_LORA_RANK:
+            raise ValueError(f"network.rank={rank}: the fused LoRA kernels support ranks 1..{MAX_LORA_RANK}")
+        return rank
+
+
+class TrainConfig(BaseModel):
+    precision: PRECISION_TYPES = "bfloat16"
+    noise_scheduler: Literal["ddim", "ddpm", "lms", "euler_a"] = "ddim"
+    iterations: int = 500
+    lr: float = 1e-4
+    optimizer: str = "adamw"
+    optimizer_args: str = ""
+    lr_scheduler: str = "constant"
+    max_denoising_steps: int = 50
+
+
+class SaveConfig(BaseModel):
+    name: str = "untitled"
+    path: str = "./output"
+    per_steps: int = 200
+    precision: PRECISION_TYPES = "float32"
+
+
+class LoggingConfig(BaseModel):
+    use_wandb: bool = False
+    verbose: bool = False
+
+
+class OtherConfig(BaseModel):
+    use_xformers: bool = False
+
+
+class RootConfig(BaseModel):
+    prompts_file: str
+    pretrained_model: PretrainedModelConfig
+    network: NetworkConfig
+    train: Optional[TrainConfig] = None
+    save: Optional[SaveConfig] = None
+    logging: Optional[LoggingConfig] = None
+    other: Optional[OtherConfig] = None
 
 
 def parse_precision(precision: str) -> torch.dtype:
-    for dtype, names in _DTYPES.items():
-        if precision in names:
-            return dtype
+    if precision in ("fp32", "float32"):
+        return torch.float32
+    if precision in ("fp16", "float16"):
+        return torch.float16
+    if precision in ("bf16", "bfloat16"):
+        return torch.bfloat16
     raise ValueError(f"Invalid precision type: {precision}")
 
 
-def describe() -> str:
-    """One line per section with its fields and defaults (for `--help`-style messages)."""
-    return "\n".join(f"{sec}: " + ", ".join(f"{k}={'<required>' if d is _REQUIRED else d!r}" for k, (_, d) in fields.items())
-                     for sec, (_, _, fields) in _SECTIONS.items())
-
-
-def load_config_from_yaml(config_path: str):
-    with open(config_path, "r") as fh:
-        raw = yaml.load(fh, Loader=yaml.FullLoader)
-    root = RootConfig(**raw)
-    for sec, (_, optional, _f) in _SECTIONS.items():
-        if optional and getattr(root, sec) is None:
-            setattr(root, sec, _MODELS[sec]())
+def load_config_from_yaml(config_path: str) -> RootConfig:
+    with open(config_path, "r") as f:
+        config = yaml.load(f, Loader=yaml.FullLoader)
+    root = RootConfig(**config)
+    if root.train is None:
+        root.train = TrainConfig()
+    if root.save is None:
+        root.save = SaveConfig()
+    if root.logging is None:
+        root.logging = LoggingConfig()
+    if root.other is None:
+        root.other = OtherConfig()
     return root

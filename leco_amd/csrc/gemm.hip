@@ -564,11 +564,15 @@ template <int BM, int BN, bool CONV, int NS, int NWM, int TF>
 void launch_k(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
     constexpr int lds_bytes = NS * (BM + BN + 16 * TF) * BK * (int)sizeof(bf16_t);
     static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
-    static bool attr_set = false;
-    if (!attr_set) {  // > 64 KB of dynamic LDS needs the opt-in attribute (once per instantiation)
+    // > 64 KB of dynamic LDS needs the opt-in attribute: once per instantiation AND device (the attribute lives on
+    // the device's copy of the function; one process per GPU is the rule, but nothing here may depend on it)
+    static bool attr_set[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, NS, NWM, TF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        attr_set = true;
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, NS, NWM, TF>), grid, dim3(NWM * 128), lds_bytes, s, a, rt);
 }

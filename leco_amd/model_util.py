@@ -7,8 +7,9 @@
 * ``synthetic:<sd15|sd21|sdxl|tiny>`` builds a seeded random-init UNet of that architecture and a
   deterministic stand-in text encoder (there are no checkpoints and no network on the build /
   benchmark boxes);
-* single-file ``.ckpt`` / ``.safetensors`` checkpoints (LDM key layout) are a "next" row
-   and raise for now.
+* single-file ``.ckpt`` / ``.safetensors`` checkpoints (LDM key layout) go through
+  ``leco_amd/ckpt_convert.py`` (architecture detected from tensor shapes, key map derived from the block
+  structure; CLIP-L / OpenCLIP-H text towers rebuilt as ``transformers`` models).
 """
 from __future__ import annotations
 

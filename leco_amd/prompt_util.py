@@ -87,12 +87,12 @@ class PromptEmbedsPair:
         self.action = settings.action
 
     def _erase(self, target_latents, positive_latents, unconditional_latents, neutral_latents):
-        """Target latents are going not to have the positive concept."""
+        """action == "erase": push the target prediction AWAY from the positive concept (neutral - g (positive - uncond))."""
         return self.loss_fn(target_latents,
                             neutral_latents - self.guidance_scale * (positive_latents - unconditional_latents))
 
     def _enhance(self, target_latents, positive_latents, unconditional_latents, neutral_latents):
-        """Target latents are going to have the positive concept."""
+        """action == "enhance": pull the target prediction TOWARDS the positive concept (neutral + g (positive - uncond))."""
         return self.loss_fn(target_latents,
                             neutral_latents + self.guidance_scale * (positive_latents - unconditional_latents))
 

@@ -268,7 +268,8 @@ class LoraSiteState:
         self.R16 = (self.R + 15) // 16 * 16
         self.Rp = 64 if site.conv3 else (self.R + 31) // 32 * 32
         if self.Rp > 64:
-            raise ValueError(f"LoRA rank {r} x {g} fused groups exceeds the 64-wide K-extension tile")
+            raise ValueError(f"LoRA rank {r} x {g} fused projections exceeds the 64-wide K-extension tile "
+                             f"(network.rank <= 16 is supported, config_util.MAX_LORA_RANK)")
         K, N = site.lora_k, site.n
         # dn_s / up_t get Rp rows (rows beyond R16 stay zero) so they can be GEMM weight operands
         self.dn_s = torch.zeros(self.Rp, K, dtype=bf16, device=dev)
@@ -1136,7 +1137,22 @@ class UNet2DConditionModel(nn.Module):
         net = self.engine().network
         return net is not None and net.multiplier != 0
 
+    def _reject_foreign_patches(self) -> None:
+        """The reference's LoRAModule (lora.py:97-100) works by re-assigning ``org_module.forward``.  The leaves here
+        only HOLD weights -- the launch plans never call ``leaf.forward`` -- so such a patch would silently do nothing:
+        refuse it and point at the slab-backed drop-in."""
+        leaves = getattr(self, "_leaves", None)
+        if leaves is None:
+            leaves = self._leaves = [(n, m) for n, m in self.named_modules() if isinstance(m, (nn.Linear, nn.Conv2d))]
+        for name, m in leaves:
+            if "forward" in m.__dict__:
+                raise RuntimeError(
+                    f"{name}.forward has been re-assigned (a LoRA network that patches module.forward, such as the "
+                    "reference's lora.LoRANetwork): this UNet executes static launch plans and never calls leaf modules. "
+                    "Use leco_amd.lora.LoRANetwork (same constructor, names and save format).")
+
     def forward(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None):
+        self._reject_foreign_patches()
         eng = self.engine()
         lora_on = self.lora_active()
         plan = self.prepare(sample.shape, lora_on)

@@ -5,7 +5,7 @@ PARITY UNPINNED: the scheduler lives in the un-vendored dependency diffusers==0.
 (requirements.txt:1); this restates its published algorithm.
 Anchors: ctor args at model_util.py:239-246; call sites train_lora.py:143-145,195-199,
 train_util.py:55,153,184,190.  The timestep tables [980..0] / [999..0] and the closed-form
-alphas_cumprod are checked in tests/test_scheduler.py.
+alphas_cumprod are checked in tests/test_host.py (scheduler tests).
 """
 import numpy as np
 import torch

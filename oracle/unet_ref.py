@@ -7,7 +7,7 @@ which is absent from /root/reference and from this image.  This file restates
 the *published* algorithm; it is anchored only by
   * the reference's own call sites (train_util.py:156-160, :239-244),
   * the public parameter counts 859 520 964 (SD1.5) / 865 910 724 (SD2.1) /
-    2 567 463 684 (SDXL), which ``tests/test_oracle_unet.py`` reproduces,
+    2 567 463 684 (SDXL), which ``tests/test_oracle_golden.py`` reproduces,
   * the LoRA module census 192 / 278 / 722 produced by the reference's own
     ``lora.py`` when applied to this tree (tests/test_reference_crosscheck.py).
 

@@ -36,6 +36,7 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 template <class F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
 
 namespace emu {
