@@ -124,8 +124,9 @@ int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, floa
                     int64_t g_sj, int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
                     leco_stream_t stream);
 
-/* same as leco_gemm with an explicit tile choice: 0 heuristic, 1 = 128x128, 2 = 128x160,
- * 3 = 64x64 (tests / tuning). */
+/* same as leco_gemm with an explicit tile choice: 0 heuristic, 1 = 128x128 (wave shape by grid size), 2 = 128x160,
+ * 3 = 64x64, 4 = 256x128, 5 = 128x128 as 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU
+ * (tests / the launch-shape tuner leco_amd/tune.py). */
 int leco_gemm_tile(const leco_gemm_args* args, int tile, leco_stream_t stream);
 /* full form: additionally split_k (0 = heuristic, 1 = none, n = that many K slices) with a
  * caller-owned fp32 workspace for the partial slabs (split_k * m * n * 4 bytes; a too small

@@ -40,7 +40,7 @@ constexpr int BK = 64;
 
 // Tuning aid (tools/ablate_gemm.py builds side libraries with -DLECO_GEMM_ABLATE=<bit mask>): 1 = no MFMA,
 // 2 = no steady-state DMA, 4 = no W-operand DMA, 8 = no A-operand DMA, 16 = no steady-state fragment
-// reads, 32 = no LDS swizzle, 64 = no steady-state waits / barriers.  Results are garbage with any bit
+// reads, 32 = no LDS swizzle, 64 = no steady-state waits / barriers, 128 = no epilogue.  Results are garbage with any bit
 // set; only the timing is meaningful.  0 in the product build.
 #ifndef LECO_GEMM_ABLATE
 #define LECO_GEMM_ABLATE 0
@@ -50,6 +50,18 @@ __device__ const u32x4 g_zero_page[4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}, {0u
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * BK + ((chunk ^ (row & 7)) << 3);
+}
+
+// gelu(x) = x Phi(x) (the erf form diffusers' GEGLU uses, F.gelu) with erf by Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7,
+// far below the bf16 rounding of the result): one v_rcp + one v_exp instead of libm's branchy erff, which made the fused
+// GEGLU epilogue cost MORE than the K loop it follows (tools/ablate_gemm.py --plain: 48 of 86 us on the level-0 tile).
+// x < 0 uses q = 1 - erf directly: no cancellation in the tail.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.7071067811865476f;
+    const float t = fast_rcp(1.f + 0.3275911f * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float hq = 0.5f * x * poly * fast_exp2(-z * z * 1.4426950408889634f);   // 0.5 x (1 - erf(|x| / sqrt 2))
+    return x >= 0.f ? x - hq : hq;
 }
 
 struct GemmRt {      // launch-time extras (not part of the C ABI struct)
@@ -439,6 +451,15 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     bf16_t* cp = (bf16_t*)p.c;
     const bf16_t* res = (const bf16_t*)p.residual;
     float* wsp = rt.split_k > 1 ? rt.ws + (int64_t)split * M * N : nullptr;
+    if (LECO_GEMM_ABLATE & 128) {   // timing aid: no epilogue (one store per lane keeps the accumulators live)
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) v += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (v == 12345.678f && cp) cp[tid] = (bf16_t)1;
+        return;
+    }
 #pragma unroll
     for (int h = 0; h < BM / 64; ++h) {
         barrier_keep_dma();                      // ring buffers / previous half no longer read
@@ -452,18 +473,17 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             }
         }
         barrier_keep_dma();
-        for (int e = tid; e < 64 * NC8; e += NT) {
-            const int rl = e / NC8, cc = e - rl * NC8;
-            const int m = m0 + h * 64 + rl, n = n0 + cc * 8;
-            if (m >= M || n >= N) continue;
-            const f32x4 v0 = *(const f32x4*)(stg + rl * SROW + cc * 8);
-            const f32x4 v1 = *(const f32x4*)(stg + rl * SROW + cc * 8 + 4);
-            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-            if (BN == 128 && p.act == LECO_ACT_GEGLU) {
-                // columns [0, 64) of the tile: value block, [64, 128): its gate block (interleaved weight rows)
-                if (cc >= 8) continue;
-                const f32x4 g0 = *(const f32x4*)(stg + rl * SROW + 64 + cc * 8);
-                const f32x4 g1 = *(const f32x4*)(stg + rl * SROW + 64 + cc * 8 + 4);
+        if (BN == 128 && p.act == LECO_ACT_GEGLU) {
+            // columns [0, 64) of the tile: value block, [64, 128): its gate block (interleaved weight rows); every
+            // thread owns 8 value columns of one row and their 8 gates
+            for (int e = tid; e < 64 * 8; e += NT) {
+                const int rl = e >> 3, cc = e & 7;
+                const int m = m0 + h * 64 + rl, n = n0 + cc * 8;
+                if (m >= M) continue;                    // (N % 128 == 0 is validated: the tile is inside the problem)
+                const float* sr = stg + rl * SROW + cc * 8;
+                const f32x4 v0 = *(const f32x4*)sr, v1 = *(const f32x4*)(sr + 4);
+                const f32x4 g0 = *(const f32x4*)(sr + 64), g1 = *(const f32x4*)(sr + 68);
+                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 float gt[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
                 if (p.bias) {
                     const f32x4 a0 = *(const f32x4*)(p.bias + n), a1 = *(const f32x4*)(p.bias + n + 4);
@@ -472,11 +492,19 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
                     for (int r = 0; r < 4; ++r) { v[r] += a0[r]; v[4 + r] += a1[r]; gt[r] += b0[r]; gt[4 + r] += b1[r]; }
                 }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] *= 0.5f * gt[r] * (1.f + erff(gt[r] * 0.7071067811865476f));
+                for (int r = 0; r < 8; ++r) v[r] *= gelu_fast(gt[r]);
                 const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
                 *(u32x4*)(cp + (int64_t)m * p.ldc + (n0 >> 1) + cc * 8) = o;
-                continue;
             }
+            continue;
+        }
+        for (int e = tid; e < 64 * NC8; e += NT) {
+            const int rl = e / NC8, cc = e - rl * NC8;
+            const int m = m0 + h * 64 + rl, n = n0 + cc * 8;
+            if (m >= M || n >= N) continue;
+            const f32x4 v0 = *(const f32x4*)(stg + rl * SROW + cc * 8);
+            const f32x4 v1 = *(const f32x4*)(stg + rl * SROW + cc * 8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             if (wsp) {   // split-K: raw partial sums, the epilogue runs in splitk_finish_kernel
                 *(f32x4*)(wsp + (int64_t)m * N + n) = v0;
                 *(f32x4*)(wsp + (int64_t)m * N + n + 4) = v1;
@@ -596,7 +624,7 @@ void launch_ns(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t
 // a persistent cross-tile-prefetching variant: -2..3.5 % -- both removed).  LECO_GEMM_W4_MIN_BLOCKS overrides the
 // threshold (tools/switch_sweep.sh).
 template <int BM, int BN, bool CONV>
-void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
+void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s, int shape) {
     if constexpr (BM == 64) {
         launch_ns<BM, BN, CONV, 4, 2>(a, rt, grid, s);
     } else {
@@ -605,14 +633,16 @@ void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_
                 const char* e = getenv("LECO_GEMM_W4_MIN_BLOCKS");
                 return e ? atol(e) : 512L;
             }();
-            if ((long)grid.x * grid.y >= w4_min_blocks) return launch_ns<BM, BN, CONV, 2, 2>(a, rt, grid, s);
+            // shape: 0 = by grid size, 1 = force the 4-wave / two-workgroups-per-CU form, 2 = force the 8-wave form
+            if (shape == 1 || (shape == 0 && (long)grid.x * grid.y >= w4_min_blocks))
+                return launch_ns<BM, BN, CONV, 2, 2>(a, rt, grid, s);
         }
         launch_ns<BM, BN, CONV, 4, 4>(a, rt, grid, s);
     }
 }
 
 template <int BM, int BN>
-int launch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s) {
+int launch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, int shape = 0) {
     const int tm = cdiv(a.m, BM), tn = cdiv(a.n, BN);
     GemmRt rt{tn, split_k, ws};
     dim3 grid((unsigned)(tm * tn), (unsigned)split_k);
@@ -620,8 +650,8 @@ int launch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s) {
         if (a.a_mode == LECO_A_PLAIN) launch_ns<BM, BN, false, 3, 4>(a, rt, grid, s);
         else launch_ns<BM, BN, true, 3, 4>(a, rt, grid, s);
     } else {
-        if (a.a_mode == LECO_A_PLAIN) launch_one<BM, BN, false>(a, rt, grid, s);
-        else launch_one<BM, BN, true>(a, rt, grid, s);
+        if (a.a_mode == LECO_A_PLAIN) launch_one<BM, BN, false>(a, rt, grid, s, shape);
+        else launch_one<BM, BN, true>(a, rt, grid, s, shape);
     }
     if (split_k > 1) {
         const int64_t quads = (int64_t)a.m * a.n / 4;
@@ -673,7 +703,8 @@ int validate(const leco_gemm_args& a) {
 }  // namespace
 }  // namespace leco
 
-// tile: 0 = heuristic, 1 = 128x128, 2 = 128x160, 3 = 64x64, 4 = 256x128.  split_k: 0 = heuristic (needs a
+// tile: 0 = heuristic, 1 = 128x128 (wave shape by grid size), 2 = 128x160, 3 = 64x64, 4 = 256x128, 5 = 128x128 as
+// 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU.  split_k: 0 = heuristic (needs a
 // workspace), 1 = none, >1 = that many K slices.  workspace: fp32 scratch for split-K partials.
 extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* workspace,
                             int64_t workspace_bytes, leco_stream_t stream) {
@@ -684,7 +715,8 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
     hipStream_t s = (hipStream_t)stream;
     const int m = args->m, n = args->n, nk = args->k / BK;
     if (args->act == LECO_ACT_GEGLU) {   // value / gate pairing lives inside one 128-column tile
-        if (tile != 0 && tile != 1 && tile != 4) return fail(-EINVAL, "leco_gemm: LECO_ACT_GEGLU needs a 128-column tile");
+        if (tile != 0 && tile != 1 && tile != 4 && tile != 5 && tile != 6)
+            return fail(-EINVAL, "leco_gemm: LECO_ACT_GEGLU needs a 128-column tile");
         if (tile == 0) tile = 1;
         split_k = 1;
     }
@@ -700,7 +732,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
             if (tile == 1 && workspace != nullptr && m >= 1024 && nk >= 64) tile = 4;
         }
     }
-    const int bm = tile == 3 ? 64 : (tile == 4 ? 256 : 128), bn = tile == 3 ? 64 : (tile == 2 ? 160 : 128);
+    const int bm = tile == 3 ? 64 : (tile == 4 ? 256 : 128), bn = tile == 3 ? 64 : (tile == 2 ? 160 : 128);   // 1, 5, 6: 128x128
     const long tiles = (long)cdiv(m, bm) * cdiv(n, bn);
     if (split_k == 0) {
         split_k = 1;
@@ -745,6 +777,8 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         case 2: return launch<128, 160>(*args, split_k, (float*)workspace, s);
         case 3: return launch<64, 64>(*args, split_k, (float*)workspace, s);
         case 4: return launch<256, 128>(*args, split_k, (float*)workspace, s);
+        case 5: return launch<128, 128>(*args, split_k, (float*)workspace, s, 1);
+        case 6: return launch<128, 128>(*args, split_k, (float*)workspace, s, 2);
         default: return fail(-EINVAL, "leco_gemm: bad tile id %d", tile);
     }
 }

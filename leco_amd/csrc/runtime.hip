@@ -17,7 +17,7 @@ extern "C" int leco_graph_end_capture(leco_stream_t stream, leco_graph_t* out) {
     if (e != hipSuccess || !g) return fail(-EIO, "hipStreamEndCapture: %s", hipGetErrorString(e));
     hipGraphExec_t ex = nullptr;
     e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    hipGraphDestroy(g);
+    (void)hipGraphDestroy(g);
     if (e != hipSuccess) return fail(-EIO, "hipGraphInstantiate: %s", hipGetErrorString(e));
     *out = (leco_graph_t)ex;
     return 0;
@@ -28,6 +28,6 @@ extern "C" int leco_graph_launch(leco_graph_t graph, leco_stream_t stream) {
     return 0;
 }
 extern "C" int leco_graph_destroy(leco_graph_t graph) {
-    if (graph) hipGraphExecDestroy((hipGraphExec_t)graph);
+    if (graph) (void)hipGraphExecDestroy((hipGraphExec_t)graph);
     return 0;
 }

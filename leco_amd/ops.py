@@ -106,9 +106,15 @@ def run_plan(plan: Sequence[Op], stream=None) -> None:
 
 # ---------------------------------------------------------------------------------------------
 def gemm(args: GemmArgs, keep=None, ws: Optional[torch.Tensor] = None, tile: int = 0, split_k: int = 0) -> Op:
-    """``ws``: fp32 scratch for split-K partial slabs (without it the GEMM never splits)."""
+    """``ws``: fp32 scratch for split-K partial slabs (without it the GEMM never splits).  ``tile == 0 and
+    split_k == 0``: the launch shape comes from the tuner (leco_amd/tune.py: table / measurement), else the C heuristic."""
+    if tile == 0 and split_k == 0:
+        from . import tune
+        tile, split_k = tune.choose(args, ws)
+        if ws is None and split_k == 0:
+            split_k = 1
     if ws is None:
-        return Op("leco_gemm_ex", (C.byref(args), tile, 1, None, 0), keep=(args, keep))
+        return Op("leco_gemm_ex", (C.byref(args), tile, max(1, split_k), None, 0), keep=(args, keep))
     return Op("leco_gemm_ex", (C.byref(args), tile, split_k, ws.data_ptr(), ws.numel() * ws.element_size()),
               keep=(args, keep, ws))
 

@@ -48,6 +48,18 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+def plain_cases():
+    """the short-K / small-M plain projections of one SD1.5 B=4 pass (tools/plan_profile.py), with their LoRA tile"""
+    out = []
+    for name, M, N, K, geglu, res in [("L0 out 320x320", 16384, 320, 320, 0, 1), ("L0 qkv", 16384, 960, 320, 0, 0),
+                                      ("L0 geglu", 16384, 2560, 320, 1, 0), ("L0 ff2", 16384, 320, 1280, 0, 1),
+                                      ("L1 out 640x640", 4096, 640, 640, 0, 1), ("L1 geglu", 4096, 5120, 640, 1, 0),
+                                      ("L2 out 1280", 1024, 1280, 1280, 0, 1), ("L2 ff2 K5120", 1024, 1280, 5120, 0, 1),
+                                      ("L2 geglu", 1024, 10240, 1280, 1, 0)]:
+        out.append((name, M, N, K, geglu, res))
+    return out
+
+
 CASES = [("conv L0 320", 16384, 320, 2880, (4, 64, 64, 64, 64), 0), ("conv L1 640", 4096, 640, 5760, (4, 32, 32, 32, 32), 0),
          ("conv L1 640 t4", 4096, 640, 5760, (4, 32, 32, 32, 32), 4),
          ("conv L2 1280", 1024, 1280, 11520, (4, 16, 16, 16, 16), 0), ("conv L2 1280 t4", 1024, 1280, 11520, (4, 16, 16, 16, 16), 4),
@@ -65,9 +77,24 @@ if "--build-only" in sys.argv:
             print(build_variant(v))
     sys.exit(0)
 ws = torch.empty(32 * 1024 * 1024, device=dev)
+PLAIN = "--plain" in sys.argv
 
 for v in VARIANTS:
     hip._use_library(build_variant(v) if v else hip.LIB_PATH)
+    if PLAIN:
+        for name, M, N, K, geglu, res in plain_cases():
+            x = torch.randn(M, K, device=dev).to(bf)
+            w = (torch.randn(N, K, device=dev) / K ** 0.5).to(bf)
+            nout = N // 2 if geglu else N
+            out = torch.empty(M, nout, dtype=bf, device=dev)
+            tw = torch.zeros(32, K, dtype=bf, device=dev); up = torch.zeros(N, 32, dtype=bf, device=dev)
+            bias = torch.zeros(N, device=dev); r = torch.zeros(M, N, dtype=bf, device=dev) if res else None
+            for lora in (1, 0):
+                kw = dict(w_ext=up, ext_k=32, t_w=tw, t_rows=16) if lora else {}
+                g = hip.gemm_args(x, w, out, m=M, n=N, k=K, bias=bias, residual=r, act=2 if geglu else 0, ldc=nout, **kw)
+                t = timeit(lambda: hip.gemm(g, None, 0, 0, ws))
+                print(f"ablate={v:3d} {name:16s} lora={lora} {t:8.1f} us  ({2.0*M*N*K/t/1e6:7.1f} TF/s nominal)", flush=True)
+        continue
     for name, M, N, K, conv, tile in CASES:
         x = torch.randn(M if conv is None else conv[0] * conv[3] * conv[4], K if conv is None else K // 9, device=dev).to(bf)
         w = (torch.randn(N, K, device=dev) / K ** 0.5).to(bf)
