@@ -41,16 +41,23 @@ constexpr int KT = 64;  // keys per tile
 #ifndef LECO_ATTN_ABLATE
 #define LECO_ATTN_ABLATE 0
 #endif
-// forward-softmax variants (bit mask): 1 = full tiles skip the key-bound masking, 2 = ... and fold the scale into
-// an fma in front of exp2.  0 in the product build: on gfx950 both variants measured SLOWER (246 / 258 vs 228 us for 4x8x4096^2x40)
-// although they remove a third of the VALU instructions -- kept for tools/ablate_attn.py.
-#ifndef LECO_ATTN_OPT
-#define LECO_ATTN_OPT 0
+// occupancy floor (waves per SIMD) of the d <= 40 forward kernels: 4 caps the kernel at 128 VGPRs (it needs 132 without
+// the cap); tools/ablate_attn.py occN times the alternatives
+#ifndef LECO_ATTN_OCC40
+#define LECO_ATTN_OCC40 4
 #endif
-
-template <int D, int QF>
-__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void attn_fwd_kernel(AttnArgs p) {
+// MASKED: the key count is not a multiple of the 64-key tile (cross-attention, 77 keys): every tile applies the key
+// bound.  Self-attention (4096 / 1024 / 256 keys) runs the instantiation without a single compare or select.
+// The softmax is VALU-bound here (per 64-key x 32-query wave tile: 28 MFMAs = 448 cycles, but 34 quarter-rate v_exp +
+// ~190 other VALU instructions), so every instruction that is not needed is removed:
+//   * the scale rides in the fma in front of exp2: e = exp2(s * scale - m); the row max is taken on the raw scores and
+//     scaled once (scale > 0);
+//   * ONES (head dims whose padded width has a spare column, d = 40 -> 48): the spare V column holds 1.0, so the PV
+//     MFMA accumulates the softmax row sum l = sum P next to O -- no VALU adds, and l is rescaled with O for free.
+template <int D, int QF, bool MASKED>
+__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OCC40 : (D <= 80 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
+    constexpr bool ONES = DV > D;
     constexpr int NKS = DK / 32, NFD = DV / 16, NDC = D / 8;
     constexpr int KROW = DK + 8;   // padded K row (elements)
     // V stays ROW-major in LDS ([key][d], staged with the same 16-byte stores as K); the PV operand
@@ -133,10 +140,11 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
             *(u32x4*)(smem + buf * BUF + key * KROW + ch * 8) = zero4;
         }
     }
-    if (DV > D) {
+    if (DV > D) {   // V columns [D, DV): column D = 1.0 (the row-sum column), the rest 0
+        const u32x4 one_then_zero = {0x00003f80u, 0u, 0u, 0u};
         for (int e = tid; e < 2 * KT; e += 256) {
             const int buf = e / KT, key = e - buf * KT;
-            *(u32x4*)(smem + buf * BUF + KT * KROW + key * VROW + NDC * 8) = zero4;
+            *(u32x4*)(smem + buf * BUF + KT * KROW + key * VROW + NDC * 8) = one_then_zero;
         }
     }
     fetch(0);
@@ -148,8 +156,6 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
         const bool more = kv0 + KT < p.skv;
         if (more && LECO_ATTN_ABLATE != 2) fetch(kv0 + KT);
 
-        auto compute = [&](auto mask_c) {
-        constexpr bool MASK = decltype(mask_c)::value;
         // S^T = K Q^T : lane holds S[q = fr][key = kv0 + 16 f + 4 fg + r]
         f32x4 acc_s[QF][4];
 #pragma unroll
@@ -170,56 +176,45 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
             }
         }
 
-        // online softmax per owned query row; P^T operand built in registers.  Full tiles (MASK = false) skip
-        // the key-bound compares / selects and fold the scale into one fma in front of exp2; the ragged last
-        // tile keeps the plain scale -> mask -> max -> exp2 form.
+        // online softmax per owned query row on the RAW scores; P^T operand built in registers
         u32x4 pw[QF][2];
         float alpha[QF];
 #pragma unroll
         for (int u = 0; u < QF; ++u) {
-            constexpr bool FOLD = !MASK && (LECO_ATTN_OPT & 2);
             float mx = -INFINITY;
 #pragma unroll
             for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if (FOLD) {
-                        mx = fmaxf(mx, acc_s[u][f][r]);          // raw scores; scale applied once to the max
-                    } else {
+                    if (MASKED) {
                         const int key = kv0 + 16 * f + 4 * fg + r;
-                        float sv = acc_s[u][f][r] * p.scale_log2;
-                        if (MASK) sv = key < p.skv ? sv : -INFINITY;
-                        acc_s[u][f][r] = sv;
-                        mx = fmaxf(mx, sv);
+                        acc_s[u][f][r] = key < p.skv ? acc_s[u][f][r] : -INFINITY;
                     }
+                    mx = fmaxf(mx, acc_s[u][f][r]);
                 }
             mx = fmaxf(mx, shfl_xor(mx, 16));
             mx = fmaxf(mx, shfl_xor(mx, 32));
-            if (FOLD) mx *= p.scale_log2;
-            const float m_new = fmaxf(m_run[u], mx);
+            const float m_new = fmaxf(m_run[u], mx * p.scale_log2);     // scale > 0: max and scale commute
             alpha[u] = fast_exp2(m_run[u] - m_new);
             m_run[u] = m_new;
             float rs = 0.f;
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 float e0, e1, e2, e3;
-                if (FOLD) {
+                if (LECO_ATTN_ABLATE != 1) {
                     e0 = fast_exp2(fmaf(acc_s[u][f][0], p.scale_log2, -m_new));
                     e1 = fast_exp2(fmaf(acc_s[u][f][1], p.scale_log2, -m_new));
                     e2 = fast_exp2(fmaf(acc_s[u][f][2], p.scale_log2, -m_new));
                     e3 = fast_exp2(fmaf(acc_s[u][f][3], p.scale_log2, -m_new));
-                } else if (LECO_ATTN_ABLATE != 1) {
-                    e0 = fast_exp2(acc_s[u][f][0] - m_new); e1 = fast_exp2(acc_s[u][f][1] - m_new);
-                    e2 = fast_exp2(acc_s[u][f][2] - m_new); e3 = fast_exp2(acc_s[u][f][3] - m_new);
                 } else {
                     e0 = acc_s[u][f][0] - m_new; e1 = acc_s[u][f][1] - m_new;
                     e2 = acc_s[u][f][2] - m_new; e3 = acc_s[u][f][3] - m_new;
                 }
-                rs += (e0 + e1) + (e2 + e3);
+                if (!ONES) rs += (e0 + e1) + (e2 + e3);
                 pw[u][f >> 1][(f & 1) * 2] = pack_bf2(e0, e1);
                 pw[u][f >> 1][(f & 1) * 2 + 1] = pack_bf2(e2, e3);
             }
-            l_run[u] = l_run[u] * alpha[u] + rs;
+            if (!ONES) l_run[u] = l_run[u] * alpha[u] + rs;
         }
 
         // O^T += V^T P^T.  V^T fragment (MFMA A operand: row = d, k = permuted key): MFMA k index
@@ -247,9 +242,6 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
                 }
             }
         }
-        };
-        if ((LECO_ATTN_OPT & 1) && kv0 + KT <= p.skv) compute(std::false_type{});
-        else compute(std::true_type{});
         if (more) stash((tile + 1) & 1);
         __syncthreads();
     }
@@ -257,9 +249,14 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 80 ? 2 : 1) void 
     bf16_t* ob = p.o + (int64_t)b * p.bso + (int64_t)h * D;
 #pragma unroll
     for (int u = 0; u < QF; ++u) {
-        float l = l_run[u];
-        l += shfl_xor(l, 16);
-        l += shfl_xor(l, 32);
+        float l;
+        if (ONES) {   // column D of O^T: fragment D / 16, lanes fg = (D % 16) / 4, element D % 4
+            l = shfl(acc_o[u][D / 16][D % 4], fr + 16 * ((D % 16) / 4));
+        } else {
+            l = l_run[u];
+            l += shfl_xor(l, 16);
+            l += shfl_xor(l, 32);
+        }
         const float inv = 1.f / l;
         const int qrow = q0 + u * 16 + fr;
         if (qrow < p.sq) {
@@ -572,10 +569,15 @@ int launch_fwd(const AttnArgs& a, int batch, hipStream_t s) {
     // two query fragments per wave halve the K/V traffic per query but also the workgroup count: worth it once
     // there are still >= 4 workgroups per CU (measured: 4x8x4096^2x40 218 vs 238 us, 4x8x1024^2x80 35.8 vs 31.8 us)
     const long wgs2 = (long)cdiv(a.sq, 128) * a.heads * batch;
+    const bool masked = a.skv % KT != 0;
     if (force_qf ? force_qf == 2 : wgs2 >= 1024) {
-        hipLaunchKernelGGL((attn_fwd_kernel<D, 2>), dim3(cdiv(a.sq, 128), a.heads, batch), dim3(256), 0, s, a);
+        const dim3 grid(cdiv(a.sq, 128), a.heads, batch);
+        if (masked) hipLaunchKernelGGL((attn_fwd_kernel<D, 2, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<D, 2, false>), grid, dim3(256), 0, s, a);
     } else {
-        hipLaunchKernelGGL((attn_fwd_kernel<D, 1>), dim3(cdiv(a.sq, 64), a.heads, batch), dim3(256), 0, s, a);
+        const dim3 grid(cdiv(a.sq, 64), a.heads, batch);
+        if (masked) hipLaunchKernelGGL((attn_fwd_kernel<D, 1, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((attn_fwd_kernel<D, 1, false>), grid, dim3(256), 0, s, a);
     }
     return check_launch("leco_attention_fwd");
 }

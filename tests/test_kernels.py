@@ -315,7 +315,9 @@ def test_attention_fwd_bwd(dev, B, H, Sq, Skv, D):
     ref = (torch.softmax(s, -1) @ vh).transpose(1, 2).reshape(B, Sq, C)
     ref.backward(do.float().cpu())
     assert rel_err(o.cpu(), ref) < TOLBF
-    assert rel_err(lse.cpu(), torch.logsumexp(s, -1)) < 1e-5
+    # d = 40: the row sum comes out of the PV MFMA (a 1.0 column in the padded V tile), i.e. it is the sum of the
+    # bf16-ROUNDED probabilities -- the same values the output was accumulated from
+    assert rel_err(lse.cpu(), torch.logsumexp(s, -1)) < (2e-4 if D == 40 else 1e-5)
     assert rel_err(dq.cpu(), qq.grad) < 4e-3
     assert rel_err(dk.cpu(), kk.grad) < 4e-3
     assert rel_err(dv.cpu(), vv.grad) < 4e-3

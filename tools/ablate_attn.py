@@ -1,5 +1,5 @@
-"""Attention-forward ablation on the GPU box.  argv: integers n build -DLECO_ATTN_ABLATE=n, `optN` builds
--DLECO_ATTN_OPT=N (softmax variants), a path names a prebuilt library.  Variants are cached under tools/_ablate
+"""Attention-forward ablation on the GPU box.  argv: integers n build -DLECO_ATTN_ABLATE=n, `occN` builds
+-DLECO_ATTN_OCC40=N (occupancy floor of the d <= 40 kernels), a path names a prebuilt library.  Variants are cached under tools/_ablate
 so they can be built in the (GPU-less) dev container and travel with the snapshot (`--build-only`)."""
 import os
 import subprocess
@@ -23,7 +23,7 @@ def build_variant(v):
     out = os.path.join(d, f"libleco_attn_{v}.so")
     if os.path.exists(out) and os.path.getmtime(out) > os.path.getmtime(os.path.join(B.CSRC, "attention.hip")):
         return out
-    define = f"-DLECO_ATTN_OPT={str(v)[3:]}" if str(v).startswith("opt") else f"-DLECO_ATTN_ABLATE={v}"
+    define = f"-DLECO_ATTN_OCC40={str(v)[3:]}" if str(v).startswith("occ") else f"-DLECO_ATTN_ABLATE={v}"
     srcs = [os.path.join(B.CSRC, f) for f in sorted(os.listdir(B.CSRC)) if f.endswith((".hip", ".cpp"))]
     subprocess.run([B.HIPCC, *B.FLAGS, define, "-shared", "-x", "hip", *srcs, "-o", out], check=True)
     return out
