@@ -118,11 +118,14 @@ typedef struct leco_lora_site {
 int leco_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_stream_t stream);
 
 /* G[j*g_sj + c*g_sc] += scale * sum_m P[m][p_off+j] * Q[m][q_off+c], j<r, c<cols (LoRA weight
- * gradients; fp32 atomics into the flat gradient slab).  P, Q bf16.  Replaces autograd's
- * wgrad of lora_down / lora_up (train_lora.py:279). */
+ * gradients into the flat gradient slab).  P, Q bf16.  Replaces autograd's wgrad of lora_down / lora_up
+ * (train_lora.py:279).  part == NULL: the 128-row slabs of M accumulate with fp32 atomics (fast, summation order
+ * varies run to run).  part != NULL (DETERMINISTIC mode): every slab writes its contribution to the caller's fp32
+ * scratch (ceil(m/128) * r * cols floats <= part_bytes) and a second launch adds them in slab order: bitwise
+ * reproducible gradients. */
 int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g,
                     int64_t g_sj, int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
-                    leco_stream_t stream);
+                    float* part, int64_t part_bytes, leco_stream_t stream);
 
 /* same as leco_gemm with an explicit tile choice: 0 heuristic, 1 = 128x128 (wave shape by grid size), 2 = 128x160,
  * 3 = 64x64, 4 = 256x128, 5 = 128x128 as 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU
@@ -140,7 +143,7 @@ int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* worksp
 int leco_lora_wgrad_conv(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj,
                          int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale, int32_t a_mode,
                          int32_t h_out, int32_t w_out, int32_t h_in, int32_t w_in, int32_t kh, int32_t kw,
-                         leco_stream_t stream);
+                         float* part, int64_t part_bytes, leco_stream_t stream);
 /* out[b][c] = sum of the rows_per_group rows of sample b of x[.][c] (fp32): gradient of the per-sample
  * time-embedding bias added by ResnetBlock2D (needed only when time_emb_proj carries a LoRA). */
 int leco_rowgroup_sum(const void* x, int64_t ldx, float* out, int64_t ldo, int32_t groups,

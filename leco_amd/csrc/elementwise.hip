@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void esd_loss_kernel(const float* tgt, const f
     for (int m = 32; m >= 1; m >>= 1) part += shfl_xor(part, m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv_n);
+    if (threadIdx.x == 0) *loss = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;   // ONE block: fixed summation order
 }
 
 // ---- fused AdamW over the flat LoRA slab (torch.optim.AdamW semantics, train_lora.py:280) ----------------
@@ -421,7 +421,7 @@ struct WgradConv {   // a_mode == LECO_A_PLAIN: Q row = m.  Otherwise Q row = so
 template <int R>
 __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_t ldp, const bf16_t* Q, int64_t ldq,
                                                           float* G, int64_t g_sj, int64_t g_sc, int M, int r,
-                                                          int cols, float scale, WgradConv cv) {
+                                                          int cols, float scale, WgradConv cv, float* part) {
     // thread (vec = tid & 31, rl = tid >> 5): 8 adjacent columns (one 16-byte load per row) x every 8th row of
     // the slab; the 8 row lanes are then combined through LDS in a fixed order and one atomic per (j, column)
     // leaves the block.
@@ -504,9 +504,25 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_
         if (c0 + tid < cols) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
-                if (jb + jj < r) atomicAdd(&G[(jb + jj) * g_sj + (int64_t)(c0 + tid) * g_sc], t[jj] * scale);
+                if (jb + jj < r) {
+                    if (part)   // deterministic mode: this slab's contribution, summed in slab order by the reduce kernel
+                        part[((int64_t)blockIdx.y * r + jb + jj) * cols + c0 + tid] = t[jj] * scale;
+                    else
+                        atomicAdd(&G[(jb + jj) * g_sj + (int64_t)(c0 + tid) * g_sc], t[jj] * scale);
+                }
         }
     }
+}
+
+// deterministic mode: G[j][c] += sum over the M slabs (in slab order) of part[slab][j][c]
+__global__ __launch_bounds__(256) void lora_wgrad_reduce_kernel(const float* part, int nslabs, int r, int cols, float* G,
+                                                                 int64_t g_sj, int64_t g_sc) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)r * cols) return;
+    const int j = (int)(e / cols), c = (int)(e - (int64_t)j * cols);
+    float acc = 0.f;
+    for (int sl = 0; sl < nslabs; ++sl) acc += part[((int64_t)sl * r + j) * cols + c];
+    G[j * g_sj + (int64_t)c * g_sc] += acc;
 }
 
 // ---- per-sample column sums: out[b][c] = sum over the rows of sample b of x[row][c] (fp32 out; d time-embedding bias)
@@ -609,9 +625,9 @@ extern "C" int leco_cfg_sched_step(const float* pred, float* x, void* x2, const 
 extern "C" int leco_esd_loss(const float* tgt, const float* pos, const float* neu, const float* unc, float g_pred,
                              float g_loss, float sign, int64_t half_n, float* loss, float* dpred,
                              leco_stream_t stream) {
-    (void)hipMemsetAsync(loss, 0, sizeof(float), LECO_STREAM);
-    hipLaunchKernelGGL(esd_loss_kernel, dim3(grid_for(half_n) > 256 ? 256 : grid_for(half_n)), dim3(256), 0,
-                       LECO_STREAM, tgt, pos, neu, unc, g_pred, g_loss, sign, half_n, loss, dpred);
+    // one workgroup (bs*4*h*w = 32 k .. 64 k elements): the loss is reduced in a fixed order -- bitwise reproducible
+    hipLaunchKernelGGL(esd_loss_kernel, dim3(1), dim3(256), 0, LECO_STREAM, tgt, pos, neu, unc, g_pred, g_loss, sign,
+                       half_n, loss, dpred);
     return check_launch("leco_esd_loss");
 }
 extern "C" int leco_adamw(float* p, const float* g, float* m, float* v, void* shadow, const float* hyper,
@@ -641,33 +657,40 @@ extern "C" int leco_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_
     return check_launch("leco_lora_pack");
 }
 static int wgrad_launch(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj, int64_t g_sc,
-                        int32_t m, int32_t r, int32_t cols, float scale, WgradConv cv, hipStream_t s) {
+                        int32_t m, int32_t r, int32_t cols, float scale, WgradConv cv, float* part, int64_t part_bytes,
+                        hipStream_t s) {
     if (r <= 0 || r > 16) return fail(-EINVAL, "lora_wgrad: rank %d unsupported (1..16)", r);
     const dim3 grid(cdiv(cols, 256), cdiv(m, WG_ROWS));
+    if (part && (int64_t)grid.y * r * cols * (int64_t)sizeof(float) > part_bytes)
+        return fail(-EINVAL, "lora_wgrad: deterministic mode needs %lld workspace bytes",
+                    (long long)((int64_t)grid.y * r * cols * (int64_t)sizeof(float)));
     if (r <= 4)
         hipLaunchKernelGGL((lora_wgrad_kernel<4>), grid, dim3(256), 0, s, (const bf16_t*)p, ldp, (const bf16_t*)q, ldq, g,
-                           g_sj, g_sc, m, r, cols, scale, cv);
+                           g_sj, g_sc, m, r, cols, scale, cv, part);
     else if (r <= 8)
         hipLaunchKernelGGL((lora_wgrad_kernel<8>), grid, dim3(256), 0, s, (const bf16_t*)p, ldp, (const bf16_t*)q, ldq, g,
-                           g_sj, g_sc, m, r, cols, scale, cv);
+                           g_sj, g_sc, m, r, cols, scale, cv, part);
     else
         hipLaunchKernelGGL((lora_wgrad_kernel<16>), grid, dim3(256), 0, s, (const bf16_t*)p, ldp, (const bf16_t*)q, ldq, g,
-                           g_sj, g_sc, m, r, cols, scale, cv);
+                           g_sj, g_sc, m, r, cols, scale, cv, part);
+    if (part)
+        hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3(cdiv((long)r * cols, 256)), dim3(256), 0, s, (const float*)part,
+                           (int)grid.y, r, cols, g, g_sj, g_sc);
     return check_launch("leco_lora_wgrad");
 }
 extern "C" int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj,
-                               int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
-                               leco_stream_t stream) {
-    return wgrad_launch(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, WgradConv{LECO_A_PLAIN, 0, 0, 0, 0, 0, 0},
-                        LECO_STREAM);
+                               int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale, float* part,
+                               int64_t part_bytes, leco_stream_t stream) {
+    return wgrad_launch(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, WgradConv{LECO_A_PLAIN, 0, 0, 0, 0, 0, 0}, part,
+                        part_bytes, LECO_STREAM);
 }
 extern "C" int leco_lora_wgrad_conv(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj,
                                     int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale, int32_t a_mode,
                                     int32_t h_out, int32_t w_out, int32_t h_in, int32_t w_in, int32_t kh, int32_t kw,
-                                    leco_stream_t stream) {
+                                    float* part, int64_t part_bytes, leco_stream_t stream) {
     if (a_mode < LECO_A_CONV3_S1 || a_mode > LECO_A_CONV3_UP2) return fail(-EINVAL, "lora_wgrad_conv: bad a_mode %d", a_mode);
     return wgrad_launch(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, WgradConv{a_mode, h_out, w_out, h_in, w_in, kh, kw},
-                        LECO_STREAM);
+                        part, part_bytes, LECO_STREAM);
 }
 extern "C" int leco_rowgroup_sum(const void* x, int64_t ldx, float* out, int64_t ldo, int32_t groups,
                                  int32_t rows_per_group, int32_t cols, leco_stream_t stream) {

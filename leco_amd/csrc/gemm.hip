@@ -201,6 +201,10 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         return (const bf16_t*)((const char*)zero + d);
     };
     const int n_main = kt_end - kt_begin;
+    // tiles that are STAGED: with the fused down-projection the [0 | scale*up] image of the K-extension step rides in the
+    // ring as one more tile (A side: zero page, overwritten by T after the K loop), so that its DMA latency is hidden
+    // behind the last K steps instead of being exposed after them (~1.5 us per LoRA GEMM)
+    const int nstage = nk + (TF ? 1 : 0);
 
     struct Addr { const bf16_t* a[GA]; const bf16_t* w[GW]; };
     // source addresses of main K tile `it` (local index): straight-line VALU/SALU, no memory traffic
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     auto addr_ext = [&](Addr& ad) {   // LoRA K-extension tile
 #pragma unroll
         for (int i = 0; i < GA; ++i)
-            ad.a[i] = (cpos8 < p.ext_k && vmask[i]) ? aext + (int64_t)arow[i] * p.ld_aext + cpos8 : zero;
+            ad.a[i] = (!TF && cpos8 < p.ext_k && vmask[i]) ? aext + (int64_t)arow[i] * p.ld_aext + cpos8 : zero;
 #pragma unroll
         for (int i = 0; i < GW; ++i) ad.w[i] = wxrow[i];
     };
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     // with the MFMAs instead of forming a separate phase after the barrier.
 #pragma unroll
     for (int s0 = 0; s0 < NS; ++s0)
-        if (s0 < nk) stage(s0, s0);
+        if (s0 < nstage) stage(s0, s0);
 
     const int fr = lane & 15, fg = lane >> 4;
     bf16x8 afA[FM], wfA[FNT], afB[FM], wfB[FNT];
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     // steady loop of the 64x64 TF=1 kernel vs its drain loop).  Completing the set on both sides of every loop
     // costs one LDS latency per tile.
     if (nk > 0) {
-        wait_tile(0, nk < NS ? nk : NS);
+        wait_tile(0, nstage < NS ? nstage : NS);
         barrier_keep_dma();
         read_frags(0, 0, afA, wfA);
         lds_wait<0>();
@@ -386,10 +390,10 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         landed(afA, wfA);
         mma(afA, wfA);
         sched_fence();
-        if (it + 1 < nk) wait_tile(it + 1, nk < it + NS ? nk : it + NS);
+        if (it + 1 < nk) wait_tile(it + 1, nstage < it + NS ? nstage : it + NS);
         barrier_keep_dma();
         landed(afB, wfB);
-        if (it + NS < nk && !(LECO_GEMM_ABLATE & 2)) stage(it + NS, it % NS);
+        if (it + NS < nstage && !(LECO_GEMM_ABLATE & 2)) stage(it + NS, it % NS);
         if (it + 1 < nk) read_frags(it + 1, 0, afA, wfA);
         mma(afB, wfB);
         sched_fence();
@@ -397,17 +401,13 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     lds_wait<0>();
 
     if (TF) {
-        // ---- fused K-extension: T (this wave's fragments, fp32) -> bf16 into ring slot 0 as the A side,
-        // scale*up rows DMA'd next to it, one 32-wide MFMA step on the main accumulators.  Lane l holds
-        // T[row 16 i + (l & 15)][column 4 (l >> 4) + r] of its fragment (the swapped-operand D layout).
-        barrier_keep_dma();                       // every wave is done with the ring
-        bf16_t* sA = smem;
+        // ---- fused K-extension: T (this wave's fragments, fp32) -> bf16 into the A side of the extension tile's ring
+        // slot (its scale*up rows were DMA'd during the last K steps), one 32-wide MFMA step on the main accumulators.
+        // Lane l holds T[row 16 i + (l & 15)][column 4 (l >> 4) + r] of its fragment (the swapped-operand D layout).
+        wait_vmcnt<0>();                          // this wave's pieces of the extension tile have landed
+        barrier_keep_dma();                       // ... everyone's; and every wave is done with the K tiles
+        bf16_t* sA = smem + (n_main % NS) * TILE;   // ring slot of the extension tile: sB already holds scale*up
         bf16_t* sB = sA + BM * BK;
-#pragma unroll
-        for (int i = 0; i < GW; ++i) {
-            if (RAGGED && i == GW - 1 && !w_last) break;
-            glds16(wxrow[i], sB + (wave + NW * i) * 8 * BK);
-        }
         bf16_t* tout = (bf16_t*)p.t_out;
         const int tcol = (TF == 2 ? wave_n * 16 : 0) + 4 * fg;
 #pragma unroll
@@ -429,8 +429,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
                 if (TF == 1) { g[8] = 0u; g[9] = 0u; }   // columns 16..31 of the [M][32] image
             }
         }
-        wait_vmcnt<0>();
-        __syncthreads();
+        barrier_keep_dma();                       // T is in LDS (ds_write: lgkmcnt); the t_out stores may still be in flight
         bf16x8 af[FM], wf[FN];
 #pragma unroll
         for (int i = 0; i < FM; ++i) af[i] = *(const bf16x8*)(sA + lds_off(wave_m * WM + i * 16 + fr, fg));

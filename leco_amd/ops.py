@@ -45,9 +45,9 @@ _SIGS = {
     "leco_memset": [_vp, _i32, _i64, _vp],
     "leco_lora_pack": [_vp, _i32, _vp],
     "leco_lora_wgrad_conv": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32,
-                             _i32, _i32, _vp],
+                             _i32, _i32, _vp, _i64, _vp],
     "leco_rowgroup_sum": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp],
-    "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp],
+    "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp],
 }
 _fn_cache = {}
 _fn_lib = None
@@ -223,7 +223,14 @@ def lora_pack(sites_dev: torch.Tensor, nsites: int) -> Op:
     return Op("leco_lora_pack", (ptr(sites_dev), nsites))
 
 
-def lora_wgrad(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale) -> Op:
-    """p, q, g are raw device addresses (ints)."""
-    return Op("leco_lora_wgrad", (p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale))
+def lora_wgrad(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, part: Optional[torch.Tensor] = None) -> Op:
+    """p, q, g are raw device addresses (ints).  ``part``: fp32 scratch -> deterministic (atomic-free) accumulation."""
+    return Op("leco_lora_wgrad", (p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, ptr(part),
+                                  0 if part is None else part.numel() * part.element_size()), keep=(part,))
+
+
+def deterministic_default() -> bool:
+    """LECO_DETERMINISTIC=1: bitwise reproducible steps (LoRA wgrads without atomics; ~1-2 % slower)."""
+    import os
+    return os.environ.get("LECO_DETERMINISTIC", "0") not in ("", "0")
 

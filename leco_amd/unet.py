@@ -362,6 +362,9 @@ class Engine:
         self.network = None  # LoRANetwork (set by attach_lora)
         self.temb_lora_sites: Dict[str, GemmSite] = {}
         self.use_graphs = False
+        # LECO_DETERMINISTIC=1: bitwise reproducible steps -- the LoRA weight gradients (the only fp32 atomics of a step)
+        # are accumulated through per-slab partials in the workspace instead; plans built afterwards pick it up
+        self.deterministic = ops.deterministic_default()
         # shared fp32 scratch for split-K partial slabs (all launches are stream-ordered)
         self.workspace = torch.empty(32 * 1024 * 1024, dtype=torch.float32, device=device)
         self._pack()
@@ -653,6 +656,8 @@ class PlanBuilder:
                             keep=(lora, dy, U)))
         gn, r = site.group_n, lora.r
         cin_total = sum(t.cols for t in xs)
+        det = self.eng.workspace if self.eng.deterministic else None   # atomic-free wgrad accumulation
+        det_bytes = 0 if det is None else det.numel() * det.element_size()
         for g, mod in enumerate(lora.mods):
             if mod is None:
                 continue
@@ -663,18 +668,18 @@ class PlanBuilder:
                 if amode == A_PLAIN:
                     # d lora_down[j][c_off + c] = s * sum_m U[m][g r + j] x[m][c]
                     out.append(ops.lora_wgrad(U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * c_off, cin_total, 1, rows,
-                                              r, t.cols, s))
+                                              r, t.cols, s, det))
                 else:
                     # conv lora_down [r][Cin][3][3]: one gathered product per tap
                     _, ho, wo, hi, wi = conv
                     for tap in range(9):
                         out.append(ops.Op("leco_lora_wgrad_conv", (
                             U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * (c_off * 9 + tap), cin_total * 9, 9, rows, r,
-                            t.cols, s, amode, ho, wo, hi, wi, tap // 3, tap % 3), keep=(U, t)))
+                            t.cols, s, amode, ho, wo, hi, wi, tap // 3, tap % 3, ops.ptr(det), det_bytes), keep=(U, t, det)))
                 c_off += t.cols
             # d lora_up[n][j] = s * sum_m dy[m][g gn + n] T[m][g r + j]
             out.append(ops.lora_wgrad(T.ptr + 2 * g * r, T.ld, dy.ptr + 2 * g * gn, dy.ld,
-                                      net.grad.data_ptr() + 4 * mod.up_off, 1, r, rows, r, gn, s))
+                                      net.grad.data_ptr() + 4 * mod.up_off, 1, r, rows, r, gn, s, det))
         return U
 
     def gemm_bwd(self, site: GemmSite, xs, y: TRef, T: Optional[TRef], conv, amode, rows, residual):

@@ -475,6 +475,26 @@ def test_lora_pack_forward_wgrad(dev):
     assert rel_err(G.cpu(), 0.25 * dy[:, 64:128].float().cpu().T @ T[:, r:2 * r].float().cpu()) < 1e-5
 
 
+def test_lora_wgrad_deterministic_mode(dev):
+    """part != NULL: per-slab partials + an in-order reduce instead of fp32 atomics -- bitwise reproducible, and it
+    ACCUMULATES into G like the atomic form."""
+    torch.manual_seed(16)
+    M, r, cols = 700, 4, 320           # 6 slabs of 128 rows
+    P = torch.randn(M, 32).to(bf).to(dev); Q = torch.randn(M, cols).to(bf).to(dev)
+    ref = 0.5 * P[:, :r].float().cpu().T @ Q.float().cpu()
+    part = torch.empty(6 * r * cols + 8, device=dev)
+    outs = []
+    for _ in range(3):
+        G = torch.full((r, cols), 1.0, device=dev)
+        ops.lora_wgrad(P.data_ptr(), 32, Q.data_ptr(), cols, G.data_ptr(), cols, 1, M, r, cols, 0.5, part).run()
+        _sync(dev)
+        outs.append(G.cpu().clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert rel_err(outs[0] - 1.0, ref) < 1e-5
+    with pytest.raises(hip.LecoError):     # scratch too small
+        ops.lora_wgrad(P.data_ptr(), 32, Q.data_ptr(), cols, G.data_ptr(), cols, 1, M, r, cols, 0.5, part[:100]).run()
+
+
 @pytest.mark.parametrize("name", ["euler_a", "lms", "ddpm"])
 def test_cfg_sched_step_matches_scheduler_objects(dev, name):
     """leco_cfg_sched_step driven by `rows()` reproduces predict_noise's CFG combine (train_util.py:163-166) followed by
