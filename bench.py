@@ -96,51 +96,130 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 150.0):
             "host_cpus": os.cpu_count(), "threads": torch.get_num_threads()}
 
 
-def dominant_kernel_roofline(dev):
-    """The kernel with the largest share of the step (profiles/: the 3x3-conv implicit GEMM) timed live with HIP
-    events on one of its heaviest launches: ResnetBlock conv 640->640 at 32x32, UNet batch 4 (M=4096, N=640,
-    K=5760; algorithmic work 2*M*N*K)."""
-    from leco_amd import hip, ops
-    B, H, C = 4, 32, 640
-    M, N, K = B * H * H, C, 9 * C
-    x = torch.randn(M, C, device=dev).to(torch.bfloat16)
-    w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    ws = torch.empty(32 * 1024 * 1024, device=dev)
-    g = hip.gemm_args(x, w, out, m=M, n=N, k=K, a_mode=hip.A_CONV3_S1, conv=(B, H, H, H, H), lda=C)
-    stream = ops.default_stream()
-    for _ in range(10):
-        hip.gemm(g, stream, 0, 0, ws)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    iters = 50
-    e0.record()
-    for _ in range(iters):
-        hip.gemm(g, stream, 0, 0, ws)
-    e1.record()
-    torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / iters * 1e3
-    tf = 2.0 * M * N * K / us / 1e6
-    return {"name": "gemm_kernel<256,128,conv3x3> (+ split-K finish)", "shape": f"M={M} N={N} K={K}",
-            "us_per_launch": us, "achieved": tf, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": tf / (PEAK_BF16 / 1e12),
-            "algorithmic_bytes": 2 * (M * C + N * K + M * N), "traffic": pmc_fetch_bytes_per_launch("gemm_kernel<256, 128, true")}
+# ---------------------------------------------------------------------------------------------------------------
+# dominant kernel: found LIVE (every distinct launch of a step timed with HIP events on the compute stream, weighted by how
+# often the step issues it), cross-checked against the top row of the committed rocprofv3 kernel trace
+PROFILE_STATS = os.path.join(ROOT, "profiles", "r02_step_kernel_stats.txt")
+PMC_FETCH = os.path.join(ROOT, "profiles", "r02_pmc_dominant_fetch.csv")
+PMC_MFMA = os.path.join(ROOT, "profiles", "r02_pmc_dominant_mfma.csv")
 
 
-def pmc_fetch_bytes_per_launch(kernel_prefix: str):
-    """HBM-side read bytes per launch of one kernel from the committed counter pass (profiles/r01_pmc_fetch_step.csv:
-    rocprofv3 --pmc FETCH_SIZE in its own run, summed per kernel by tools/pmc_summary.py).  FETCH_SIZE is in KB and
-    reports half of the bytes of wide coalesced reads on gfx950 (MI355X_MICROARCH.md, HBM section): x 1024 x 2.
-    Averaged over every launch of that kernel in the profiled step (all conv shapes), not only the timed shape.
-    None when the summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_fetch_step.csv")
+def _launch_identity(op):
+    """-> (kernel names as rocprofv3 prints them, shape key, algorithmic flops) of one plan launch."""
+    from leco_amd import hip
+    a = op.args
+    if op.name == "leco_gemm_ex":
+        g = op.keep[0]
+        parts = hip.gemm_describe(g, a[1], a[2], a[3], a[4]).split(" ; ")
+        names = [p.split(" grid=")[0] for p in parts]
+        ext = g.ext_k if (g.a_ext or g.t_w) else 0
+        key = (op.name, g.m, g.n, g.k, g.a_mode, ext, bool(g.t_w), bool(g.residual), g.act, g.batch, g.h_in, g.h_out, a[1], a[2])
+        return names, key, 2.0 * g.m * g.n * (g.k + ext)
+    if op.name == "leco_attention_fwd":
+        B, H, sq, skv, d = a[13], a[14], a[15], a[16], a[17]
+        qf = 2 if -(-sq // 128) * H * B >= 1024 else 1
+        return [f"attn_fwd_kernel<{d}, {qf}, {'true' if skv % 64 else 'false'}>"], (op.name, B, H, sq, skv, d), 4.0 * B * H * sq * skv * d
+    if op.name == "leco_attention_bwd":
+        B, H, sq, skv, d = a[26], a[27], a[28], a[29], a[30]
+        return ["attention_bwd(3 kernels)"], (op.name, B, H, sq, skv, d), 10.0 * B * H * sq * skv * d
+    return [op.name], (op.name,) + tuple(x for x in a if isinstance(x, int) and 0 <= x < (1 << 20)), 0.0
+
+
+def step_launches(st, k_mean):
+    """[(op, launches per step)] of one reference-faithful step with k_mean denoising passes."""
+    out = []
+    skip = ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step")      # mutate the step state; negligible time
+    for plan, which, w in ((st["dplan"], "ctx_on", 1.0), (st["dplan"], "denoise", float(k_mean)), (st["fplan"], "fwd_off", 1.0),
+                           (st["plan"], "fwd_on", 1.0), (st["plan"], "bwd", 1.0)):
+        out += [(op, w) for op in plan.lists[which] if op.name not in skip]
+    return out
+
+
+def _profile_top_row():
     try:
-        for line in open(path):
-            if line.startswith(kernel_prefix):
-                _, calls, kb = line.rsplit(",", 2)
-                return float(kb) * 1024.0 * 2.0 / float(calls)
-    except (OSError, ValueError):
+        for line in open(PROFILE_STATS):
+            f = line.split(None, 6)
+            if len(f) == 7 and f[0].replace(".", "").isdigit():
+                return {"name": f[6].strip(), "share_pct": float(f[0]), "avg_us": float(f[3])}
+    except OSError:
         pass
     return None
+
+
+def _pmc_row(path, name):
+    try:
+        lines = open(path).read().splitlines()
+        hdr = lines[0].split(",")
+        for line in lines[1:]:
+            if line.startswith(name + ","):
+                vals = line[len(name) + 1:].split(",")
+                return dict(zip(hdr[1:], [float(v) for v in vals]))
+    except (OSError, IndexError, ValueError):
+        pass
+    return None
+
+
+def dominant_kernel_roofline(st, k_mean, only_replay=False):
+    """Times every distinct launch of a step in isolation (HIP events on the compute stream, L2-warm repeats), attributes
+    each to its kernel instantiation, picks the instantiation with the largest share of the step and reports its
+    launch-weighted average duration and algorithmic FLOPs per launch.  MFMA-busy and HBM traffic per launch come from the
+    committed counter passes over EXACTLY these launches (`rocprofv3 --pmc ... -- python bench.py --dominant-only`)."""
+    launches = step_launches(st, k_mean)
+    groups = {}                                   # shape key -> [op, names, flops, launches per step]
+    for op, w in launches:
+        names, key, fl = _launch_identity(op)
+        g = groups.setdefault(key, [op, names, fl, 0.0])
+        g[3] += w
+    top = _profile_top_row()
+    if only_replay:
+        # counter pass: replay the dominant instantiation's launches with their per-step multiplicities, nothing else
+        want = top["name"] if top else None
+        n = 0
+        for op, names, fl, w in groups.values():
+            if want is not None and names == [want]:
+                for _ in range(max(1, int(round(w)))):
+                    op.run()
+                    n += 1
+        torch.cuda.synchronize()
+        return {"replayed": n, "kernel": want}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    per_name = {}
+    for key, (op, names, fl, w) in groups.items():
+        for _ in range(2):
+            op.run()
+        e0.record()
+        for _ in range(8):
+            op.run()
+        e1.record()
+        e1.synchronize()
+        us = e0.elapsed_time(e1) / 8 * 1e3
+        name = names[0] if len(names) == 1 else " + ".join(names)
+        a = per_name.setdefault(name, [0.0, 0.0, 0.0, {}])
+        a[0] += w            # launches per step
+        a[1] += w * us       # us per step
+        a[2] += w * fl       # flops per step
+        a[3][key] = (w, us, fl)
+    total_us = sum(a[1] for a in per_name.values())
+    name, (n, us, fl, shapes) = max(per_name.items(), key=lambda kv: kv[1][1])
+    achieved = fl / us / 1e6 if us else 0.0       # TFLOP/s
+    heavy = max(shapes.items(), key=lambda kv: kv[1][0] * kv[1][1])
+    out = {"name": name, "launches_per_step": n, "us_per_launch": us / n, "flops_per_launch": fl / n,
+           "share_of_step_kernel_time": us / total_us, "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+           "frac": achieved / (PEAK_BF16 / 1e12), "distinct_shapes": len(shapes),
+           "heaviest_shape": {"key": [str(x) for x in heavy[0][1:9]], "launches_per_step": heavy[1][0], "us": heavy[1][1],
+                              "tflops": heavy[1][2] / heavy[1][1] / 1e6 if heavy[1][1] else 0.0},
+           "profile_top_row": top,
+           "agrees_with_profile": bool(top and top["name"] == name)}
+    fetch, mfma = _pmc_row(PMC_FETCH, name), _pmc_row(PMC_MFMA, name)
+    if fetch and fetch.get("calls"):
+        # FETCH_SIZE is in KB and counts a wide coalesced read at half its bytes on gfx950 (MI355X_MICROARCH.md, HBM)
+        out["traffic"] = fetch.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0 / fetch["calls"]
+        out["traffic_note"] = "HBM-side read bytes per launch (FETCH_SIZE KB x 1024 x 2), counter pass over the same launches"
+    else:
+        out["traffic"] = None
+    if mfma and mfma.get("GRBM_GUI_ACTIVE"):
+        out["mfma_busy"] = mfma.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (mfma["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    return out
 
 
 def main():
@@ -154,6 +233,9 @@ def main():
     ap.add_argument("--bs", type=int, default=2)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--rank", type=int, default=4)
+    ap.add_argument("--dominant-only", action="store_true",
+                    help="counter passes: build the plans, replay only the dominant kernel's launches of one step "
+                         "(rocprofv3 --pmc ... -- python bench.py --dominant-only), print nothing else")
     ap.add_argument("--k", type=int, default=0, help="profiling only: fixed number of denoising passes per step "
                                                      "(0 = the seeded reference distribution; the headline number uses 0)")
     args = ap.parse_args()
@@ -211,6 +293,15 @@ def main():
         lat = train_util.get_initial_latents(sched, args.bs, args.res, args.res, 1, generator=noise_gen)
         return fused.step(pair, ks[i], lat)
 
+    if args.dominant_only:
+        unet.use_graphs = False
+        fused.step(pair, 1, train_util.get_initial_latents(sched, args.bs, args.res, args.res, 1, generator=noise_gen))
+        torch.cuda.synchronize()
+        st = fused._state[(args.bs, args.res // 8, args.res // 8)]
+        k_mean = sum(ks[args.warmup:]) / max(1, len(ks[args.warmup:]))
+        print(json.dumps(dominant_kernel_roofline(st, k_mean, only_replay=True)))
+        return
+
     def barrier():
         if world > 1:
             import torch.distributed as dist
@@ -253,15 +344,20 @@ def main():
                                f"reference-faithful pass structure (k+3+1 fwd, 1 bwd)",
                    "global_batch": args.bs * world, "k_sequence_seed": 0 if args.k <= 0 else f"fixed k={args.k} (profiling run)", "k_mean": sum(timed_ks) / len(timed_ks),
                    "hip_graphs": bool(unet.use_graphs), "parallelism": f"dp{world}", "loss": losses[-1], "losses": losses},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                     "frac": achieved / (PEAK_BF16 / 1e12), "traffic": None,
-                     "note": "algorithmic FLOPs W_ref(k)=2*bs*F_fwd*(k+5+a) summed over the timed steps / HIP-event "
-                             "time on the compute stream (rank 0); per-kernel breakdown in profiles/"},
     }
+    whole = {"achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12),
+             "note": "algorithmic FLOPs W_ref(k) = 2 bs F_fwd (k + 5 + a) summed over the timed steps / HIP-event time on the "
+                     "compute stream (rank 0)"}
     try:
-        out["roofline"]["dominant_kernel"] = dominant_kernel_roofline(dev)
+        st = fused._state[(args.bs, args.res // 8, args.res // 8)]
+        dom = dominant_kernel_roofline(st, sum(timed_ks) / len(timed_ks))
+        # the roofline object is the DOMINANT KERNEL's (algorithmic FLOPs per launch / its average launch duration);
+        # the whole-step figure rides along
+        out["roofline"] = {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",
+                           "frac": dom["frac"], "traffic": dom.get("traffic"), "kernel": dom, "whole_step": whole}
     except Exception as e:  # never hide the step number
-        out["roofline"]["dominant_kernel"] = {"error": repr(e)}
+        out["roofline"] = {"bound": "mfma", "achieved": whole["achieved"], "peak": whole["peak"], "unit": "TFLOP/s",
+                           "frac": whole["frac"], "traffic": None, "whole_step": whole, "kernel": {"error": repr(e)}}
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(sum(timed_ks) / len(timed_ks), args.bs)

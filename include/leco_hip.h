@@ -137,6 +137,11 @@ int leco_gemm_tile(const leco_gemm_args* args, int tile, leco_stream_t stream);
  * need this to fill 256 CUs. */
 int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* workspace,
                  int64_t workspace_bytes, leco_stream_t stream);
+/* dry run of leco_gemm_ex: writes the kernel instantiation(s) that call would launch -- "gemm_kernel<BM, BN, CONV, NS,
+ * NWM, TF> grid=.. split=.." as rocprofv3 names them, " ; "-separated when a call expands to two GEMMs -- into out.
+ * Nothing is launched.  Measurement tooling (bench.py attributes plan launches to profile rows with it). */
+int leco_gemm_describe(const leco_gemm_args* args, int tile, int split_k, void* workspace,
+                       int64_t workspace_bytes, char* out, int32_t out_len);
 
 /* same with Q gathered like the A operand of a 3x3 conv (one call per tap; a_mode LECO_A_CONV3_S1/S2/UP2):
  * the wgrad of a conv lora_down (c3lier, lora.py:72-81).  m = batch*h_out*w_out output rows. */

@@ -60,6 +60,7 @@ def _declare(lib: C.CDLL) -> None:
         "leco_gemm": ([C.POINTER(GemmArgs), vp], C.c_int),
         "leco_gemm_tile": ([C.POINTER(GemmArgs), C.c_int, vp], C.c_int),
         "leco_gemm_ex": ([C.POINTER(GemmArgs), C.c_int, C.c_int, vp, i64, vp], C.c_int),
+        "leco_gemm_describe": ([C.POINTER(GemmArgs), C.c_int, C.c_int, vp, i64, C.c_char_p, C.c_int32], C.c_int),
     }
     for name, (args, res) in sig.items():
         fn = getattr(lib, name)
@@ -171,6 +172,13 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, 
     g.t_w, g.ld_tw, g.t_rows = ptr(t_w), k, t_rows
     g.t_out, g.ld_tout = ptr(t_out), ld_tout or 32
     return g
+
+
+def gemm_describe(args: GemmArgs, tile: int = 0, split_k: int = 1, ws_ptr=None, ws_bytes: int = 0) -> str:
+    """The kernel instantiation(s) `leco_gemm_ex` would launch for these arguments, named as rocprofv3 names them."""
+    buf = C.create_string_buffer(256)
+    check(lib().leco_gemm_describe(C.byref(args), tile, split_k, ws_ptr, ws_bytes, buf, 256), "leco_gemm_describe")
+    return buf.value.decode()
 
 
 def gemm(args: GemmArgs, stream=None, tile: int = 0, split_k: int = 1, ws: Optional[torch.Tensor] = None) -> None:

@@ -359,6 +359,25 @@ def test_dropin_autograd_path_equals_fused_gradients(dev):
     assert rel_err(y_off.float().cpu(), GOLD["unet.y_t500"]) < 3e-2
 
 
+def _device_models(rcfg, cfg, dev, seed):
+    """fp32 oracle + HIP model with the same bf16-representable synthetic weights, constructed and initialised ON the
+    device (the CPU constructors' default init costs ~20 s per SD1.5-sized model)."""
+    with torch.device(dev):
+        ref = R.UNet2DConditionModel(rcfg)
+        m = UNet2DConditionModel(cfg) if cfg is not None else UNet2DConditionModel()
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if p.ndim >= 2:
+                p.copy_(((torch.rand(p.shape, generator=gen, device=dev) * 2 - 1) / p[0].numel() ** 0.5).to(bf).float())
+            elif "norm" in name:
+                p.fill_(1.0 if name.endswith("weight") else 0.0)
+            else:
+                p.copy_(((torch.rand(p.shape, generator=gen, device=dev) * 2 - 1) * 0.02).to(bf).float())
+    m.load_state_dict(ref.state_dict())
+    return ref, m.to(dev, bf)
+
+
 @pytest.mark.gpu
 def test_sd21_768_full_size_forward_vs_oracle_on_gpu():
     """BASELINE config 3 architecture: SD2.1 (linear projections, head dim 64) at 768^2 (latent 96^2), B=2."""
@@ -367,14 +386,7 @@ def test_sd21_768_full_size_forward_vs_oracle_on_gpu():
     from conftest import _bind_hip
     _bind_hip()
     dev = torch.device("cuda:0")
-    ref = R.init_synthetic_(R.UNet2DConditionModel(R.sd21_config()), seed=77)
-    with torch.no_grad():
-        for p in ref.parameters():
-            p.copy_(p.to(bf).float())
-    m = UNet2DConditionModel(model_util.SYNTHETIC["sd21"]())
-    m.load_state_dict(ref.state_dict())
-    m = m.to(dev, bf)
-    ref = ref.to(dev)
+    ref, m = _device_models(R.sd21_config(), model_util.SYNTHETIC["sd21"](), dev, 77)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, 4, 96, 96, generator=g).to(bf).to(dev)
     ctx = torch.randn(2, 77, 1024, generator=g).to(bf).to(dev)
@@ -395,14 +407,7 @@ def test_sd15_full_size_forward_vs_oracle_on_gpu():
     from conftest import _bind_hip
     _bind_hip()
     dev = torch.device("cuda:0")
-    ref = R.init_synthetic_(R.UNet2DConditionModel(R.sd15_config()), seed=1234)
-    with torch.no_grad():
-        for p in ref.parameters():
-            p.copy_(p.to(bf).float())
-    m = UNet2DConditionModel()
-    m.load_state_dict(ref.state_dict())
-    m = m.to(dev, bf)
-    ref = ref.to(dev)
+    ref, m = _device_models(R.sd15_config(), None, dev, 1234)
     g = torch.Generator().manual_seed(0)
     x = torch.randn(2, 4, 64, 64, generator=g).to(bf).to(dev)
     ctx = torch.randn(2, 77, 768, generator=g).to(bf).to(dev)
