@@ -25,14 +25,16 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-F_FWD_SD15_512 = 0.8033e12   # FLOPs of one sample-pass
-ATTN_SHARE = 0.157
+# FLOPs of one sample-pass F_fwd and attention share a of the backward, at the resolution named
+F_FWD = {("sd15", 512): (0.8033e12, 0.157), ("sd21", 768): (2.149e12, 0.292), ("sdxl", 1024): (6.761e12, 0.116)}
+F_FWD_SD15_512, ATTN_SHARE = F_FWD[("sd15", 512)]
 PEAK_BF16 = 2.5e15           # dense bf16 MFMA, MI355X_MICROARCH.md
 
 
-def step_flops(bs: int, k: int) -> float:
+def step_flops(bs: int, k: int, arch: str = "sd15", res: int = 512) -> float:
     """Reference-faithful algorithmic work of one step: W_ref(k) = 2 bs F_fwd (k + 4 + 1 + a)."""
-    return 2 * bs * F_FWD_SD15_512 * (k + 5 + ATTN_SHARE)
+    f, a = F_FWD.get((arch, res), (F_FWD_SD15_512 * (res / 512.0) ** 2, ATTN_SHARE))
+    return 2 * bs * f * (k + 5 + a)
 
 
 def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 150.0):
@@ -233,6 +235,8 @@ def main():
     ap.add_argument("--bs", type=int, default=2)
     ap.add_argument("--res", type=int, default=512)
     ap.add_argument("--rank", type=int, default=4)
+    ap.add_argument("--c3lier", action="store_true", help="network.type c3lier (conv + time_emb_proj LoRA; BASELINE config 4)")
+    ap.add_argument("--v-pred", action="store_true", help="v-prediction scheduler (BASELINE config 3)")
     ap.add_argument("--dominant-only", action="store_true",
                     help="counter passes: build the plans, replay only the dominant kernel's launches of one step "
                          "(rocprofv3 --pmc ... -- python bench.py --dominant-only), print nothing else")
@@ -263,14 +267,20 @@ def main():
 
     import io
     import contextlib
-    tokenizer, text_encoder, unet, sched = model_util.load_models(f"synthetic:{args.arch}", "ddim")
+    xl = args.arch == "sdxl"
+    if xl:
+        tokenizers, text_encoders, unet, sched = model_util.load_models_xl("synthetic:sdxl", "ddim")
+    else:
+        tokenizer, text_encoder, unet, sched = model_util.load_models(f"synthetic:{args.arch}", "ddim", v_pred=args.v_pred)
     unet.to(dev, dtype=torch.bfloat16)
     unet.requires_grad_(False)
     unet.eval()
     unet.use_graphs = not args.no_graphs
     torch.manual_seed(1234)
+    from leco_amd.lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV
+    targets = list(DEFAULT_TARGET_REPLACE) + (list(UNET_TARGET_REPLACE_MODULE_CONV) if args.c3lier else [])
     with contextlib.redirect_stdout(io.StringIO()):
-        net = LoRANetwork(unet, rank=args.rank, multiplier=1.0, alpha=1.0).to(dev)
+        net = LoRANetwork(unet, rank=args.rank, multiplier=1.0, alpha=1.0, target_replace_modules=targets).to(dev)
     # lora_up starts at zero in the reference; give it a small value so the LoRA path does real work
     g = torch.Generator().manual_seed(99)
     with torch.no_grad():
@@ -279,7 +289,13 @@ def main():
     net.mark_updated()
     settings = prompt_util.PromptSettings(target="van gogh", positive="van gogh", unconditional="", neutral="",
                                           action="erase", guidance_scale=1.0, resolution=args.res, batch_size=args.bs)
-    emb = {p: text_encoder([p])[0] for p in ("van gogh", "")}
+    if xl:
+        emb = {p: prompt_util.PromptEmbedsXL(*train_util.encode_prompts_xl(tokenizers, text_encoders, [p], num_images_per_prompt=1))
+               for p in ("van gogh", "")}
+        add_time_ids = train_util.get_add_time_ids(args.res, args.res)
+    else:
+        emb = {p: text_encoder([p])[0] for p in ("van gogh", "")}
+        add_time_ids = None
     pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["van gogh"], emb["van gogh"], emb[""], emb[""], settings)
     fused = FusedStep(unet, net, sched, 50, lr=1e-4, world_size=world)
 
@@ -291,11 +307,12 @@ def main():
 
     def one(i):
         lat = train_util.get_initial_latents(sched, args.bs, args.res, args.res, 1, generator=noise_gen)
-        return fused.step(pair, ks[i], lat)
+        return fused.step(pair, ks[i], lat, add_time_ids=add_time_ids)
 
     if args.dominant_only:
         unet.use_graphs = False
-        fused.step(pair, 1, train_util.get_initial_latents(sched, args.bs, args.res, args.res, 1, generator=noise_gen))
+        fused.step(pair, 1, train_util.get_initial_latents(sched, args.bs, args.res, args.res, 1, generator=noise_gen),
+                   add_time_ids=add_time_ids)
         torch.cuda.synchronize()
         st = fused._state[(args.bs, args.res // 8, args.res // 8)]
         k_mean = sum(ks[args.warmup:]) / max(1, len(ks[args.warmup:]))
@@ -333,13 +350,17 @@ def main():
             sys.exit(f"rank {rank}: non-finite loss in the timed steps: {losses}")
         return
     timed_ks = ks[args.warmup:]
-    flops = sum(step_flops(args.bs, k) for k in timed_ks)
+    default_cfg = (args.arch, args.res, args.bs, args.rank, args.c3lier) == ("sd15", 512, 2, 4, False)
+    flops = sum(step_flops(args.bs, k, args.arch, args.res) for k in timed_ks)
     achieved = flops / dt_ev / 1e12
     out = {
-        "metric": "LECO train-steps/sec, SDv1.5 rank-4 512px bs=2", "value": world * args.steps / dt, "unit": "steps/s",
+        "metric": "LECO train-steps/sec, SDv1.5 rank-4 512px bs=2" if default_cfg else
+                  f"LECO train-steps/sec, {args.arch} rank-{args.rank}{' c3lier' if args.c3lier else ''} {args.res}px bs={args.bs}",
+        "value": world * args.steps / dt, "unit": "steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"SDv1.5 UNet (random init) LECO erase step, LoRA rank {args.rank} lierla, "
+        "config": {"workload": f"{'SDv1.5' if args.arch == 'sd15' else args.arch} UNet (random init) LECO erase step, LoRA rank {args.rank} "
+                               f"{'c3lier' if args.c3lier else 'lierla'}{', v-prediction' if args.v_pred else ''}, "
                                f"{args.res}x{args.res}, prompt batch {args.bs} (UNet batch {2 * args.bs}), DDIM 50, "
                                f"reference-faithful pass structure (k+3+1 fwd, 1 bwd)",
                    "global_batch": args.bs * world, "k_sequence_seed": 0 if args.k <= 0 else f"fixed k={args.k} (profiling run)", "k_mean": sum(timed_ks) / len(timed_ks),

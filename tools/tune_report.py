@@ -69,7 +69,7 @@ def main():
     print(f"# GEMM time per denoising pass: heuristic {tot_pass/1e3:.3f} ms -> tuned {(tot_pass-save_pass)/1e3:.3f} ms; "
           f"fixed part of a step (3 frozen + target fwd + bwd): {tot_fixed/1e3:.3f} -> {(tot_fixed-save_fixed)/1e3:.3f} ms")
     os.makedirs(os.path.dirname(args.out) or ".", exist_ok=True)
-    n = tune.save_table(args.out, merge=os.path.exists(args.out))
+    n = tune.save_table(args.out, merge=True)      # keep the committed entries of the other configurations
     print(f"# wrote {n} entries to {args.out}")
 
 
