@@ -46,6 +46,9 @@ constexpr int KT = 64;  // keys per tile
 #ifndef LECO_ATTN_OCC40
 #define LECO_ATTN_OCC40 4
 #endif
+#ifndef LECO_ATTN_OCC64    // d = 64 (SD2.x / SDXL): 3 caps the kernel at 168 VGPRs (182 without); d = 80 would spill at 3
+#define LECO_ATTN_OCC64 3
+#endif
 // MASKED: the key count is not a multiple of the 64-key tile (cross-attention, 77 keys): every tile applies the key
 // bound.  Self-attention (4096 / 1024 / 256 keys) runs the instantiation without a single compare or select.
 // The softmax is VALU-bound here (per 64-key x 32-query wave tile: 28 MFMAs = 448 cycles, but 34 quarter-rate v_exp +
@@ -55,7 +58,7 @@ constexpr int KT = 64;  // keys per tile
 //   * ONES (head dims whose padded width has a spare column, d = 40 -> 48): the spare V column holds 1.0, so the PV
 //     MFMA accumulates the softmax row sum l = sum P next to O -- no VALU adds, and l is rescaled with O for free.
 template <int D, int QF, bool MASKED>
-__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OCC40 : (D <= 80 ? 2 : 1)) void attn_fwd_kernel(AttnArgs p) {
+__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OCC40 : (D == 64 ? LECO_ATTN_OCC64 : (D <= 80 ? 2 : 1))) void attn_fwd_kernel(AttnArgs p) {
     constexpr int DK = (D + 31) / 32 * 32, DV = (D + 15) / 16 * 16;
     constexpr bool ONES = DV > D;
     constexpr int NKS = DK / 32, NFD = DV / 16, NDC = D / 8;

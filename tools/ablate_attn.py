@@ -23,7 +23,12 @@ def build_variant(v):
     out = os.path.join(d, f"libleco_attn_{v}.so")
     if os.path.exists(out) and os.path.getmtime(out) > os.path.getmtime(os.path.join(B.CSRC, "attention.hip")):
         return out
-    define = f"-DLECO_ATTN_OCC40={str(v)[3:]}" if str(v).startswith("occ") else f"-DLECO_ATTN_ABLATE={v}"
+    if str(v).startswith("occ64_"):
+        define = f"-DLECO_ATTN_OCC64={str(v)[6:]}"
+    elif str(v).startswith("occ"):
+        define = f"-DLECO_ATTN_OCC40={str(v)[3:]}"
+    else:
+        define = f"-DLECO_ATTN_ABLATE={v}"
     srcs = [os.path.join(B.CSRC, f) for f in sorted(os.listdir(B.CSRC)) if f.endswith((".hip", ".cpp"))]
     subprocess.run([B.HIPCC, *B.FLAGS, define, "-shared", "-x", "hip", *srcs, "-o", out], check=True)
     return out
@@ -60,7 +65,7 @@ if "--build-only" in sys.argv:
 for v in VARIANTS:
     hip._use_library(build_variant(v) if v != "0" else hip.LIB_PATH)
     for (Bq, H, Sq, Skv, D) in [(4, 8, 4096, 4096, 40), (12, 8, 4096, 4096, 40), (4, 8, 4096, 77, 40), (4, 8, 1024, 1024, 80),
-                                (4, 8, 256, 256, 160), (4, 5, 9216, 9216, 64)]:
+                                (4, 8, 256, 256, 160), (4, 5, 9216, 9216, 64), (2, 10, 4096, 4096, 64), (2, 20, 1024, 1024, 64)]:
         C = H * D
         q = torch.randn(Bq, Sq, C, device=dev).to(bf); k = torch.randn(Bq, Skv, C, device=dev).to(bf)
         vv = torch.randn(Bq, Skv, C, device=dev).to(bf); o = torch.empty_like(q); lse = torch.empty(Bq, H, Sq, device=dev)
