@@ -37,14 +37,15 @@ def step_flops(bs: int, k: int, arch: str = "sd15", res: int = 512) -> float:
     return 2 * bs * f * (k + 5 + a)
 
 
-def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 150.0):
+def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 210.0):
     """The reference loop on the host CPU (BASELINE.json configs[0]: SD1.5, rank 4, 512^2, prompt batch 1, fp32,
     DDIM, AdamW), as a port: `oracle/step_ref.leco_step` restates one iteration of train_lora.py:141-281 on the
     oracle UNet / DDIM / LoRA (the reference's own files need `diffusers` and do not exist on the GPU box), followed
     by `loss.backward()`, `optimizer.step()`, `lr_scheduler.step()` and the reference's per-step `flush()`
-    (train_lora.py:279-290).  FULL optimizer steps are timed, one per entry of `ks` (k denoising passes each); a step
-    costs a + b k, so two steps with different k give both coefficients, which are then evaluated at the k mean of
-    the GPU run and scaled by the prompt batch (2 x the samples -> 2 x the time; a CPU has no idle lanes to fill)."""
+    (train_lora.py:279-290).  FULL optimizer steps are timed, one per entry of `ks` (k denoising passes each) after an
+    untimed warm-up forward; the steady-state step is scaled with W_ref(k) to the k mean of the GPU run and by the
+    prompt batch (2 x the samples -> 2 x the time; a CPU has no idle lanes to fill).  The reference's OWN files driving
+    the same oracle UNet cost the same (oracle/time_reference_cpu.py, build container: 64 s / 50 s for k = 1 / 2)."""
     import gc
     from oracle import lora_ref, step_ref
     from oracle import unet_ref as R
@@ -65,6 +66,8 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 150.0):
     eg = torch.Generator().manual_seed(4321)
     emb = {n: torch.randn(1, 77, 768, generator=eg) for n in ("target", "neutral")}
     emb["positive"], emb["unconditional"] = emb["target"], emb["neutral"]       # 'van gogh' erase: 2 distinct prompts
+    with torch.no_grad():      # untimed warm-up pass (thread pool, allocator): the first forward of a process is ~1.6x slow
+        unet(torch.zeros(2, 4, 64, 64), torch.tensor(1), encoder_hidden_states=torch.zeros(2, 77, 768))
     times, losses = [], []
     t_all = time.perf_counter()
     for i, k in enumerate(ks):
@@ -81,14 +84,12 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 150.0):
         gc.collect()
         times.append(time.perf_counter() - t0)
         losses.append(None)
-    if len(times) >= 2 and ks[1] != ks[0]:
-        b = (times[1] - times[0]) / (ks[1] - ks[0])
-        a = times[0] - b * ks[0]
-        how = f"a + b k with a = {a:.1f} s, b = {b:.1f} s from the two steps"
-    else:   # one step only: W_ref(k) = 2 bs F_fwd (k + 5 + a_attn)
-        b = times[0] / (ks[0] + 5 + ATTN_SHARE)
-        a = b * (5 + ATTN_SHARE)
-        how = f"W_ref(k): {b:.1f} s per forward-equivalent from the one step"
+    # the LAST timed step is the steady-state one (the first still pays allocator / autograd warm-up: measured 64 s vs 50 s
+    # on the build container); its cost per forward-equivalent, W_ref(k) = 2 bs F_fwd (k + 5 + a_attn), is evaluated at
+    # the GPU run's k mean
+    b = times[-1] / (ks[len(times) - 1] + 5 + ATTN_SHARE)
+    a = b * (5 + ATTN_SHARE)
+    how = f"W_ref(k): {b:.1f} s per forward-equivalent from the last step"
     t_step = bs * (a + b * k_mean)
     return {"value": 1.0 / t_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{len(times)} full fp32 optimizer steps of the ported reference loop at prompt batch 1 with k = "
