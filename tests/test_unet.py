@@ -522,3 +522,30 @@ def test_plan_buckets_are_evicted_lru(dev):
     fs._bucket(1, 8, 16)                       # touch: becomes most recent
     fs._bucket(1, 8, 8)                        # evicts (1, 16, 8)
     assert list(fs._state) == [(1, 8, 16), (1, 8, 8)] and (2, 16, 8, True) not in eng.plans
+
+
+def test_infer_xl_script_samples_with_a_trained_lora(dev, tmp_path):
+    """examples/infer_xl.py (the counterpart of the reference's test/infer_xl.py up to the VAE): load_models_xl ->
+    encode_prompts_xl -> diffusion_xl with CFG through the HIP UNet, with and without a saved LoRA applied."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("infer_xl", os.path.join(os.path.dirname(os.path.dirname(__file__)),
+                                                                           "examples", "infer_xl.py"))
+    infer = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(infer)
+    _, _, unet, _ = model_util.load_models_xl("synthetic:tiny_xl", "ddim")
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(unet.to(dev, bf), rank=4, multiplier=1.0, alpha=1.0)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for l in net.unet_loras:
+            l.lora_up.weight.copy_(torch.randn(l.lora_up.weight.shape, generator=g) * 0.3)
+    net.mark_updated()
+    f = str(tmp_path / "x_last.safetensors")
+    net.save_weights(f, dtype=torch.float32)
+    common = ["--model", "synthetic:tiny_xl", "--height", "128", "--width", "128", "--steps", "3", "--device", str(dev)]
+    with contextlib.redirect_stdout(io.StringIO()):
+        base = infer.main(common + ["--out", str(tmp_path / "a.safetensors")])
+        lora = infer.main(common + ["--lora", f, "--out", str(tmp_path / "b.safetensors")])
+    assert base.shape == (1, 4, 16, 16) and torch.isfinite(base.float()).all() and torch.isfinite(lora.float()).all()
+    assert (tmp_path / "b.safetensors").exists()
+    assert rel_err(lora.cpu(), base.cpu()) > 1e-3          # the LoRA really is applied
