@@ -127,6 +127,22 @@ int leco_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, floa
                     int64_t g_sj, int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
                     float* part, int64_t part_bytes, leco_stream_t stream);
 
+/* All LoRA weight gradients of a backward in ONE launch (atomic accumulation, like leco_lora_wgrad with part == NULL):
+ * `problems` is a DEVICE array; problem i owns the blocks [block_start, block_start + blocks_x * ceil(m / 128)) with
+ * blocks_x = ceil(cols / 256); total_blocks = their sum; max_rank = largest r in the table (<= 16).  a_mode
+ * LECO_A_PLAIN: a leco_lora_wgrad problem; LECO_A_CONV3_S1/S2/UP2: a leco_lora_wgrad_conv problem (tap kh, kw). */
+typedef struct leco_wgrad_problem {
+    const void* p; int64_t ldp;
+    const void* q; int64_t ldq;
+    float* g; int64_t g_sj, g_sc;
+    int32_t m, r, cols;
+    float scale;
+    int32_t a_mode, h_out, w_out, h_in, w_in, kh, kw;
+    int32_t block_start, blocks_x;
+} leco_wgrad_problem;
+int leco_lora_wgrad_grouped(const leco_wgrad_problem* problems, int32_t nproblems, int32_t total_blocks,
+                            int32_t max_rank, leco_stream_t stream);
+
 /* same as leco_gemm with an explicit tile choice: 0 heuristic, 1 = 128x128 (wave shape by grid size), 2 = 128x160,
  * 3 = 64x64, 4 = 256x128, 5 = 128x128 as 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU
  * (tests / the launch-shape tuner leco_amd/tune.py). */

@@ -419,9 +419,9 @@ struct WgradConv {   // a_mode == LECO_A_PLAIN: Q row = m.  Otherwise Q row = so
     int a_mode, h_out, w_out, h_in, w_in, kh, kw;
 };
 template <int R>
-__global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_t ldp, const bf16_t* Q, int64_t ldq,
-                                                          float* G, int64_t g_sj, int64_t g_sc, int M, int r,
-                                                          int cols, float scale, WgradConv cv, float* part) {
+__device__ __forceinline__ void lora_wgrad_body(const bf16_t* P, int64_t ldp, const bf16_t* Q, int64_t ldq, float* G,
+                                                int64_t g_sj, int64_t g_sc, int M, int r, int cols, float scale,
+                                                WgradConv cv, float* part, int bx, int by) {
     // thread (vec = tid & 31, rl = tid >> 5): 8 adjacent columns (one 16-byte load per row) x every 8th row of
     // the slab; the 8 row lanes are then combined through LDS in a fixed order and one atomic per (j, column)
     // leaves the block.
@@ -430,9 +430,9 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_
     __shared__ f32x4 red[8 * 256];
     const int tid = (int)threadIdx.x;
     const int vec = tid & 31, rl = tid >> 5;
-    const int c0 = (int)blockIdx.x * 256;
+    const int c0 = bx * 256;
     const int c = c0 + vec * 8;
-    const int m0 = (int)blockIdx.y * WG_ROWS;
+    const int m0 = by * WG_ROWS;
     const int rows = min(WG_ROWS, M - m0);
     for (int e = tid; e < WG_ROWS * R; e += 256) {
         const int mm = e / R, j = e - mm * R;
@@ -506,12 +506,36 @@ __global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_
             for (int jj = 0; jj < 4; ++jj)
                 if (jb + jj < r) {
                     if (part)   // deterministic mode: this slab's contribution, summed in slab order by the reduce kernel
-                        part[((int64_t)blockIdx.y * r + jb + jj) * cols + c0 + tid] = t[jj] * scale;
+                        part[((int64_t)by * r + jb + jj) * cols + c0 + tid] = t[jj] * scale;
                     else
                         atomicAdd(&G[(jb + jj) * g_sj + (int64_t)(c0 + tid) * g_sc], t[jj] * scale);
                 }
         }
     }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void lora_wgrad_kernel(const bf16_t* P, int64_t ldp, const bf16_t* Q, int64_t ldq,
+                                                          float* G, int64_t g_sj, int64_t g_sc, int M, int r,
+                                                          int cols, float scale, WgradConv cv, float* part) {
+    lora_wgrad_body<R>(P, ldp, Q, ldq, G, g_sj, g_sc, M, r, cols, scale, cv, part, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// ALL LoRA weight gradients of a backward in one launch: block b finds its problem in the table (block_start is the
+// running sum of blocks_x * ceil(m / 128); binary search) -- 384 launches at their ~10 us floor become one.
+template <int R>
+__global__ __launch_bounds__(256) void lora_wgrad_grouped_kernel(const leco_wgrad_problem* probs, int n) {
+    const int b = (int)blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (probs[mid].block_start <= b) lo = mid; else hi = mid - 1;
+    }
+    const leco_wgrad_problem q = probs[lo];
+    const int local = b - q.block_start;
+    const int by = local / q.blocks_x, bx = local - by * q.blocks_x;
+    lora_wgrad_body<R>((const bf16_t*)q.p, q.ldp, (const bf16_t*)q.q, q.ldq, q.g, q.g_sj, q.g_sc, q.m, q.r, q.cols, q.scale,
+                       WgradConv{q.a_mode, q.h_out, q.w_out, q.h_in, q.w_in, q.kh, q.kw}, nullptr, bx, by);
 }
 
 // deterministic mode: G[j][c] += sum over the M slabs (in slab order) of part[slab][j][c]
@@ -691,6 +715,16 @@ extern "C" int leco_lora_wgrad_conv(const void* p, int64_t ldp, const void* q, i
     if (a_mode < LECO_A_CONV3_S1 || a_mode > LECO_A_CONV3_UP2) return fail(-EINVAL, "lora_wgrad_conv: bad a_mode %d", a_mode);
     return wgrad_launch(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, WgradConv{a_mode, h_out, w_out, h_in, w_in, kh, kw},
                         part, part_bytes, LECO_STREAM);
+}
+extern "C" int leco_lora_wgrad_grouped(const leco_wgrad_problem* problems, int32_t nproblems, int32_t total_blocks,
+                                       int32_t max_rank, leco_stream_t stream) {
+    if (nproblems <= 0 || total_blocks <= 0) return 0;
+    if (max_rank <= 0 || max_rank > 16) return fail(-EINVAL, "lora_wgrad_grouped: rank %d unsupported (1..16)", max_rank);
+    const dim3 grid((unsigned)total_blocks);
+    if (max_rank <= 4) hipLaunchKernelGGL((lora_wgrad_grouped_kernel<4>), grid, dim3(256), 0, LECO_STREAM, problems, nproblems);
+    else if (max_rank <= 8) hipLaunchKernelGGL((lora_wgrad_grouped_kernel<8>), grid, dim3(256), 0, LECO_STREAM, problems, nproblems);
+    else hipLaunchKernelGGL((lora_wgrad_grouped_kernel<16>), grid, dim3(256), 0, LECO_STREAM, problems, nproblems);
+    return check_launch("leco_lora_wgrad_grouped");
 }
 extern "C" int leco_rowgroup_sum(const void* x, int64_t ldx, float* out, int64_t ldo, int32_t groups,
                                  int32_t rows_per_group, int32_t cols, leco_stream_t stream) {

@@ -48,6 +48,16 @@ class LoraSite(C.Structure):
     ]
 
 
+class WgradProblem(C.Structure):     # mirrors `leco_wgrad_problem` in include/leco_hip.h
+    _fields_ = [
+        ("p", C.c_void_p), ("ldp", C.c_int64), ("q", C.c_void_p), ("ldq", C.c_int64),
+        ("g", C.c_void_p), ("g_sj", C.c_int64), ("g_sc", C.c_int64),
+        ("m", C.c_int32), ("r", C.c_int32), ("cols", C.c_int32), ("scale", C.c_float),
+        ("a_mode", C.c_int32), ("h_out", C.c_int32), ("w_out", C.c_int32), ("h_in", C.c_int32), ("w_in", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("block_start", C.c_int32), ("blocks_x", C.c_int32),
+    ]
+
+
 _lib: Optional[C.CDLL] = None
 _lib_path: Optional[str] = None
 

@@ -47,6 +47,7 @@ _SIGS = {
     "leco_lora_wgrad_conv": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32,
                              _i32, _i32, _vp, _i64, _vp],
     "leco_rowgroup_sum": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp],
+    "leco_lora_wgrad_grouped": [_vp, _i32, _i32, _i32, _vp],
     "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp],
 }
 _fn_cache = {}
@@ -227,6 +228,24 @@ def lora_wgrad(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, part: Optional[
     """p, q, g are raw device addresses (ints).  ``part``: fp32 scratch -> deterministic (atomic-free) accumulation."""
     return Op("leco_lora_wgrad", (p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols, scale, ptr(part),
                                   0 if part is None else part.numel() * part.element_size()), keep=(part,))
+
+
+def lora_wgrad_grouped(problems: list, device) -> Optional[Op]:
+    """ONE launch for a list of weight-gradient problems.  Each entry: dict(p, ldp, q, ldq, g, g_sj, g_sc, m, r, cols,
+    scale[, a_mode, h_out, w_out, h_in, w_in, kh, kw]) with raw device addresses, as for `lora_wgrad` /
+    leco_lora_wgrad_conv.  The problem table is built here and kept on the device."""
+    if not problems:
+        return None
+    tab = (hip.WgradProblem * len(problems))()
+    start = 0
+    for d, pr in zip(tab, problems):
+        for k, v in pr.items():
+            setattr(d, k, v)
+        d.blocks_x = -(-pr["cols"] // 256)
+        d.block_start = start
+        start += d.blocks_x * -(-pr["m"] // 128)
+    raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(device)
+    return Op("leco_lora_wgrad_grouped", (raw.data_ptr(), len(problems), start, max(pr["r"] for pr in problems)), keep=(raw,))
 
 
 def deterministic_default() -> bool:

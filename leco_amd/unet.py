@@ -542,6 +542,8 @@ class PlanBuilder:
         self.f_off: List[ops.Op] = self.plan.fwd[False]
         self.tape: List = []
         self.nbuf = 0
+        self.wgrad_problems: List[dict] = []     # LoRA weight gradients of the backward: one grouped launch at its end
+        self.wgrad_keep: List = []
 
     # ---- helpers -----------------------------------------------------------------------------
     def buf(self, name, shape, dtype=bf16, zero=False) -> torch.Tensor:
@@ -662,11 +664,28 @@ class PlanBuilder:
         return U
 
     def lora_wgrads(self, site: GemmSite, xs, dy: TRef, T: TRef, U: TRef, conv, amode, rows) -> None:
+        """The LoRA weight gradients of one site.  Default: recorded as problems of the ONE grouped launch that `build`
+        appends at the end of the backward (every operand buffer of a plan stays intact until then); deterministic mode:
+        one atomic-free launch pair per problem, in place."""
         out, lora, net = self.plan.bwd, site.lora, self.eng.network
         gn, r = site.group_n, lora.r
         cin_total = sum(t.cols for t in xs)
         det = self.eng.workspace if self.eng.deterministic else None   # atomic-free wgrad accumulation
         det_bytes = 0 if det is None else det.numel() * det.element_size()
+
+        def emit(p, ldp, q, ldq, g, g_sj, g_sc, cols, s, cv=None, keep=()):
+            if det is None:
+                pr = dict(p=p, ldp=ldp, q=q, ldq=ldq, g=g, g_sj=g_sj, g_sc=g_sc, m=rows, r=r, cols=cols, scale=s)
+                if cv is not None:
+                    pr.update(a_mode=cv[0], h_out=cv[1], w_out=cv[2], h_in=cv[3], w_in=cv[4], kh=cv[5], kw=cv[6])
+                self.wgrad_problems.append(pr)
+                self.wgrad_keep.append(keep)
+            elif cv is None:
+                out.append(ops.Op("leco_lora_wgrad", (p, ldp, q, ldq, g, g_sj, g_sc, rows, r, cols, s, ops.ptr(det), det_bytes),
+                                  keep=(keep, det)))
+            else:
+                out.append(ops.Op("leco_lora_wgrad_conv", (p, ldp, q, ldq, g, g_sj, g_sc, rows, r, cols, s, *cv,
+                                                           ops.ptr(det), det_bytes), keep=(keep, det)))
         for g, mod in enumerate(lora.mods):
             if mod is None:
                 continue
@@ -676,19 +695,17 @@ class PlanBuilder:
             for t in xs:
                 if amode == A_PLAIN:
                     # d lora_down[j][c_off + c] = s * sum_m U[m][g r + j] x[m][c]
-                    out.append(ops.lora_wgrad(U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * c_off, cin_total, 1, rows,
-                                              r, t.cols, s, det))
+                    emit(U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * c_off, cin_total, 1, t.cols, s, keep=(U, t))
                 else:
                     # conv lora_down [r][Cin][3][3]: one gathered product per tap
                     _, ho, wo, hi, wi = conv
                     for tap in range(9):
-                        out.append(ops.Op("leco_lora_wgrad_conv", (
-                            U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * (c_off * 9 + tap), cin_total * 9, 9, rows, r,
-                            t.cols, s, amode, ho, wo, hi, wi, tap // 3, tap % 3, ops.ptr(det), det_bytes), keep=(U, t, det)))
+                        emit(U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * (c_off * 9 + tap), cin_total * 9, 9, t.cols, s,
+                             cv=(amode, ho, wo, hi, wi, tap // 3, tap % 3), keep=(U, t))
                 c_off += t.cols
             # d lora_up[n][j] = s * sum_m dy[m][g gn + n] T[m][g r + j]
-            out.append(ops.lora_wgrad(T.ptr + 2 * g * r, T.ld, dy.ptr + 2 * g * gn, dy.ld,
-                                      net.grad.data_ptr() + 4 * mod.up_off, 1, r, rows, r, gn, s, det))
+            emit(T.ptr + 2 * g * r, T.ld, dy.ptr + 2 * g * gn, dy.ld, net.grad.data_ptr() + 4 * mod.up_off, 1, r, gn, s,
+                 keep=(T, dy))
 
     def gemm_bwd(self, site: GemmSite, xs, y: TRef, T: Optional[TRef], conv, amode, rows, residual):
         out = self.plan.bwd
@@ -1017,6 +1034,10 @@ class PlanBuilder:
             nout.gparts.append(dn)
             for fn in reversed(self.tape):
                 fn()
+            grouped = ops.lora_wgrad_grouped(self.wgrad_problems, self.dev)
+            if grouped is not None:
+                grouped.keep = (grouped.keep, self.wgrad_keep)
+                P.bwd.append(grouped)
         self.tape = []
         return P
 

@@ -475,6 +475,33 @@ def test_lora_pack_forward_wgrad(dev):
     assert rel_err(G.cpu(), 0.25 * dy[:, 64:128].float().cpu().T @ T[:, r:2 * r].float().cpu()) < 1e-5
 
 
+def test_lora_wgrad_grouped_launch_equals_single_launches(dev):
+    """leco_lora_wgrad_grouped: problems of different M / cols / rank / gather mode in one launch == one launch each."""
+    torch.manual_seed(18)
+    probs, singles, keep = [], [], []
+    for (M, r, cols, conv) in [(300, 4, 320, None), (70, 4, 64, None), (128, 8, 600, None), (2 * 6 * 6, 4, 64, (2, 6, 6, 6, 6))]:
+        P = torch.randn(M, 32).to(bf).to(dev)
+        Q = torch.randn(M if conv is None else conv[0] * conv[3] * conv[4], cols).to(bf).to(dev)
+        Ga = torch.zeros(r, cols, device=dev); Gb = torch.zeros(r, cols, device=dev)
+        keep += [P, Q, Ga, Gb]
+        pr = dict(p=P.data_ptr(), ldp=32, q=Q.data_ptr(), ldq=cols, g_sj=cols, g_sc=1, m=M, r=r, cols=cols, scale=0.5)
+        if conv is not None:
+            pr.update(a_mode=hip.A_CONV3_S1, h_out=conv[1], w_out=conv[2], h_in=conv[3], w_in=conv[4], kh=0, kw=2)
+        probs.append(dict(pr, g=Ga.data_ptr()))
+        if conv is None:
+            singles.append(ops.lora_wgrad(P.data_ptr(), 32, Q.data_ptr(), cols, Gb.data_ptr(), cols, 1, M, r, cols, 0.5))
+        else:
+            singles.append(ops.Op("leco_lora_wgrad_conv", (P.data_ptr(), 32, Q.data_ptr(), cols, Gb.data_ptr(), cols, 1, M, r,
+                                                           cols, 0.5, hip.A_CONV3_S1, conv[1], conv[2], conv[3], conv[4], 0, 2,
+                                                           None, 0)))
+    ops.lora_wgrad_grouped(probs, dev).run()
+    for op in singles:
+        op.run()
+    _sync(dev)
+    for i in range(4):
+        assert rel_err(keep[4 * i + 2].cpu(), keep[4 * i + 3].cpu()) < 1e-6 and keep[4 * i + 3].abs().sum().item() > 0
+
+
 def test_lora_wgrad_deterministic_mode(dev):
     """part != NULL: per-slab partials + an in-order reduce instead of fp32 atomics -- bitwise reproducible, and it
     ACCUMULATES into G like the atomic form."""
