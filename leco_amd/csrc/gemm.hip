@@ -401,8 +401,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         sched_fence();
     }
     lds_wait<0>();
-    landed(afA, wfA);      // (nothing is in flight here; the ties keep the compiler from re-using a fragment register
-    landed(afB, wfB);      //  ahead of the wait, which the path-insensitive ISA audit would flag)
 
     if (TF) {
         // ---- fused K-extension: T (this wave's fragments, fp32) -> bf16 into the A side of the extension tile's ring
@@ -642,19 +640,14 @@ void launch_one(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_
     if constexpr (BM == 64) {
         launch_ns<BM, BN, CONV, 4, 2>(a, rt, grid, s);
     } else {
-        // shape: 0 = by grid size, 1 = force the 4-wave / two-workgroups-per-CU form (64-row wave tiles, 2-deep ring),
-        // 2 = force the 8-wave form.  By grid size only plain 128x128 grids of >= 512 workgroups take the 4-wave form;
-        // every 128-row tile can be ASKED to (tile ids 5 / 7: the tuner's candidates).
-        bool w4 = shape == 1;
         if constexpr (BM == 128 && BN == 128 && !CONV) {
             static const long w4_min_blocks = [] {
                 const char* e = getenv("LECO_GEMM_W4_MIN_BLOCKS");
                 return e ? atol(e) : 512L;
             }();
-            if (shape == 0 && (long)grid.x * grid.y >= w4_min_blocks) w4 = true;
-        }
-        if constexpr (BM == 128) {
-            if (w4) return launch_ns<BM, BN, CONV, 2, 2>(a, rt, grid, s);
+            // shape: 0 = by grid size, 1 = force the 4-wave / two-workgroups-per-CU form, 2 = force the 8-wave form
+            if (shape == 1 || (shape == 0 && (long)grid.x * grid.y >= w4_min_blocks))
+                return launch_ns<BM, BN, CONV, 2, 2>(a, rt, grid, s);
         }
         launch_ns<BM, BN, CONV, 4, 4>(a, rt, grid, s);
     }
@@ -724,7 +717,7 @@ int validate(const leco_gemm_args& a) {
 }  // namespace leco
 
 // tile: 0 = heuristic, 1 = 128x128 (wave shape by grid size), 2 = 128x160, 3 = 64x64, 4 = 256x128, 5 = 128x128 as
-// 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU, 7 = 128x160 as 4-wave workgroups.  split_k: 0 = heuristic (needs a
+// 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU.  split_k: 0 = heuristic (needs a
 // workspace), 1 = none, >1 = that many K slices.  workspace: fp32 scratch for split-K partials.
 extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* workspace,
                             int64_t workspace_bytes, leco_stream_t stream) {
@@ -753,7 +746,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
             if (tile == 1 && workspace != nullptr && m >= 1024 && nk >= 64) tile = 4;
         }
     }
-    const int bm = tile == 3 ? 64 : (tile == 4 ? 256 : 128), bn = tile == 3 ? 64 : ((tile == 2 || tile == 7) ? 160 : 128);
+    const int bm = tile == 3 ? 64 : (tile == 4 ? 256 : 128), bn = tile == 3 ? 64 : (tile == 2 ? 160 : 128);   // 1, 5, 6: 128x128
     const long tiles = (long)cdiv(m, bm) * cdiv(n, bn);
     if (split_k == 0) {
         split_k = 1;
@@ -806,7 +799,6 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         case 4: return launch<256, 128>(*args, split_k, (float*)workspace, s);
         case 5: return launch<128, 128>(*args, split_k, (float*)workspace, s, 1);
         case 6: return launch<128, 128>(*args, split_k, (float*)workspace, s, 2);
-        case 7: return launch<128, 160>(*args, split_k, (float*)workspace, s, 1);
         default: return fail(-EINVAL, "leco_gemm: bad tile id %d", tile);
     }
 }

@@ -56,12 +56,12 @@ def candidates(g: GemmArgs, has_ws: bool):
     nk = g.k // 64
     plain = g.a_mode == 0
     geglu = g.act == hip.ACT_GEGLU
-    tiles = [1, 4, 5, 6] if geglu else [1, 2, 3, 4, 5, 7] + ([6] if plain else [])
+    tiles = [1, 4, 5, 6] if geglu else [1, 2, 3, 4] + ([5, 6] if plain else [])
     out = [(0, 0)]                                   # the C heuristic itself
     for t in tiles:
-        bm, bn = {1: (128, 128), 2: (128, 160), 3: (64, 64), 4: (256, 128), 5: (128, 128), 6: (128, 128), 7: (128, 160)}[t]
+        bm, bn = {1: (128, 128), 2: (128, 160), 3: (64, 64), 4: (256, 128), 5: (128, 128), 6: (128, 128)}[t]
         blocks = -(-g.m // bm) * -(-g.n // bn)
-        if t in (2, 7) and g.n % 160 and g.n > 160:
+        if t == 2 and g.n % 160 and g.n > 160:
             continue
         out.append((t, 1))
         if has_ws and not geglu and nk >= 16 and blocks <= 192:
