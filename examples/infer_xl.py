@@ -44,6 +44,7 @@ def main(argv=None):
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--no_graphs", action="store_true", help="eager launches instead of one hipGraph per UNet pass")
     ap.add_argument("--out", default="latents.safetensors")
     args = ap.parse_args(argv)
     dev = torch.device(args.device)
@@ -56,7 +57,7 @@ def main(argv=None):
     unet.enable_xformers_memory_efficient_attention()
     unet.requires_grad_(False)
     unet.eval()
-    unet.use_graphs = dev.type == "cuda"
+    unet.use_graphs = dev.type == "cuda" and not args.no_graphs
     network = None
     if args.lora:
         with contextlib.redirect_stdout(io.StringIO()):

@@ -542,7 +542,10 @@ def test_infer_xl_script_samples_with_a_trained_lora(dev, tmp_path):
     net.mark_updated()
     f = str(tmp_path / "x_last.safetensors")
     net.save_weights(f, dtype=torch.float32)
-    common = ["--model", "synthetic:tiny_xl", "--height", "128", "--width", "128", "--steps", "3", "--device", str(dev)]
+    # (eager launches: graph capture for a further model in a process that has captured a multi-GB one -- the full-size
+    #  test above -- segfaults inside hipStreamBeginCapture on ROCm 7.2)
+    common = ["--model", "synthetic:tiny_xl", "--height", "128", "--width", "128", "--steps", "3", "--device", str(dev),
+              "--no_graphs"]
     with contextlib.redirect_stdout(io.StringIO()):
         base = infer.main(common + ["--out", str(tmp_path / "a.safetensors")])
         lora = infer.main(common + ["--lora", f, "--out", str(tmp_path / "b.safetensors")])
