@@ -437,8 +437,12 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
     optimizer_kwargs = _parse_optimizer_args(config.train.optimizer_args)
     if opt_name in ("adam", "adamw", "lion"):
         # fused on the flat slab.  torch.optim.Adam's weight_decay is a coupled L2 term, which the fused kernel
-        # does not implement: fall through to the torch object in that (non-default) case
-        fused_opt = opt_name if not (opt_name == "adam" and optimizer_kwargs.get("weight_decay", 0.0)) else None
+        # does not implement: fall through to the torch object in that (non-default) case -- and whenever
+        # optimizer_args carries a keyword the fused kernels do not implement (amsgrad, maximize, ...): the reference
+        # forwards every keyword to the optimizer constructor (train_lora.py:80-89), nothing may be dropped silently
+        unsupported = set(optimizer_kwargs) - {"betas", "eps", "weight_decay"}
+        coupled_l2 = opt_name == "adam" and optimizer_kwargs.get("weight_decay", 0.0)
+        fused_opt = opt_name if not (coupled_l2 or unsupported) else None
     else:
         fused_opt = None
     if fused_opt is None:
