@@ -98,7 +98,7 @@ int leco_gemm(const leco_gemm_args* args, leco_stream_t stream);
  *   up_p [N][Rp]   = scale * lora_up, block-diagonal over groups            fwd K-extension
  *   up_t [R16][N]  = lora_up^T, block-diagonal                              bwd: U = dy up_t^T
  *   dn_p [K][Rp]   = scale * lora_down^T                                    bwd K-extension
- * R = groups*r, R16 = roundup(R,16), Rp = roundup(R,32); group g owns output columns
+ * R = groups*r, R16 = roundup(R,16), Rp = roundup(R,32) unless `rp` overrides it; group g owns output columns
  * [g*N/groups, (g+1)*N/groups).  down[g] is [r][K], up[g] is [N/groups][r] (lora.py:65-66).
  * `sites` is a DEVICE array of descriptors; one launch covers all of them. */
 typedef struct leco_lora_site {
@@ -113,6 +113,8 @@ typedef struct leco_lora_site {
     void* up_t;
     void* dn_p;
     void* up_pg;         /* optional: a second copy of up_p with the LECO_ACT_GEGLU row interleave (or NULL) */
+    int32_t rp;          /* 0: Rp = roundup(R, 32) (64 for conv sites); else the column count of up_p / dn_p (a multiple
+                            of 64 for R > 64: ranks whose stacked columns need several 64-wide K-extension steps) */
 } leco_lora_site;
 
 int leco_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_stream_t stream);

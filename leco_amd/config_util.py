@@ -8,7 +8,7 @@ from typing import Literal, Optional
 
 import torch
 import yaml
-from pydantic import BaseModel, field_validator
+from pydantic import BaseModel, model_validator
 
 from .lora import TRAINING_METHODS
 
@@ -23,7 +23,8 @@ class PretrainedModelConfig(BaseModel):
     clip_skip: Optional[int] = None
 
 
-MAX_LORA_RANK = 16   # leco_lora_wgrad keeps <= 16 rank columns in registers; q|k|v share one 64-wide K-extension tile
+MAX_LORA_RANK = 128        # lierla: stacked q|k|v columns run as chained 64-wide K-extension steps above 64
+MAX_LORA_RANK_C3LIER = 64  # conv LoRA: the low-rank image is one 64-channel tensor
 
 
 class NetworkConfig(BaseModel):
@@ -32,14 +33,13 @@ class NetworkConfig(BaseModel):
     alpha: float = 1.0
     training_method: TRAINING_METHODS = "full"
 
-    @field_validator("rank")
-    @classmethod
-    def _rank_fits_the_fused_lora_tile(cls, rank: int) -> int:
-        # the reference accepts any rank; the MI355X path fuses the low-rank product into the weight GEMM as one
-        # K-extension tile, which bounds it (README "Limits").  Fail at config time, not after the model has loaded.
-        if not 1 <= rank <= MAX_LORA_RANK:
-            raise ValueError(f"network.rank={rank}: the fused LoRA kernels support ranks 1..{MAX_LORA_RANK}")
-        return rank
+    @model_validator(mode="after")
+    def _rank_fits_the_lora_kernels(self):
+        # the reference accepts any rank; fail at config time, not after the model has loaded (README "Limits")
+        cap = MAX_LORA_RANK_C3LIER if self.type == "c3lier" else MAX_LORA_RANK
+        if not 1 <= self.rank <= cap:
+            raise ValueError(f"network.rank={self.rank}: network.type {self.type} supports ranks 1..{cap}")
+        return self
 
 
 class TrainConfig(BaseModel):

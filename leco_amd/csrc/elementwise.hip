@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* x, bf16
 __global__ __launch_bounds__(256) void lora_pack_kernel(const leco_lora_site* sites) {
     const leco_lora_site s = sites[blockIdx.y];
     const bool conv = s.taps == 9;     // 3x3 conv LoRA: lora_down is [r][Cin][3][3] (lora.py:72-81)
-    const int R = s.groups * s.r, R16 = (R + 15) / 16 * 16, Rp = conv ? 64 : (R + 31) / 32 * 32;
+    const int R = s.groups * s.r, R16 = (R + 15) / 16 * 16, Rp = s.rp ? s.rp : (conv ? 64 : (R + 31) / 32 * 32);
     const int gn = s.n / s.groups, cin = conv ? s.k / 9 : s.k;
     const int rows_s = conv ? Rp : R16;   // conv sites use dn_s / up_t as GEMM weight operands of Rp rows
     const int64_t n0 = (int64_t)rows_s * s.k, n1 = (int64_t)s.n * Rp, n2 = (int64_t)rows_s * s.n, n3 = (int64_t)s.k * Rp;

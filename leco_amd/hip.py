@@ -44,7 +44,7 @@ class LoraSite(C.Structure):
         ("groups", C.c_int32), ("r", C.c_int32), ("k", C.c_int32), ("n", C.c_int32),
         ("scale", C.c_float), ("taps", C.c_int32),
         ("dn_s", C.c_void_p), ("up_p", C.c_void_p), ("up_t", C.c_void_p), ("dn_p", C.c_void_p),
-        ("up_pg", C.c_void_p),
+        ("up_pg", C.c_void_p), ("rp", C.c_int32),
     ]
 
 

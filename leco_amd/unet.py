@@ -266,10 +266,14 @@ class LoraSiteState:
         g = len(mods)
         self.R = g * r
         self.R16 = (self.R + 15) // 16 * 16
-        self.Rp = 64 if site.conv3 else (self.R + 31) // 32 * 32
-        if self.Rp > 64:
-            raise ValueError(f"LoRA rank {r} x {g} fused projections exceeds the 64-wide K-extension tile "
-                             f"(network.rank <= 16 is supported, config_util.MAX_LORA_RANK)")
+        # columns of the packed up / down images: one 32- or 64-wide K-extension step, or (ranks whose stacked
+        # columns exceed 64) several 64-wide steps, the first riding in the main GEMM, the rest chained behind it
+        if site.conv3:
+            self.Rp = 64
+            if self.R > 64:
+                raise ValueError(f"conv LoRA rank {r} exceeds the 64-channel low-rank image of the c3lier path")
+        else:
+            self.Rp = (self.R + 31) // 32 * 32 if self.R <= 64 else (self.R + 63) // 64 * 64
         K, N = site.lora_k, site.n
         # dn_s / up_t get Rp rows (rows beyond R16 stay zero) so they can be GEMM weight operands
         self.dn_s = torch.zeros(self.Rp, K, dtype=bf16, device=dev)
@@ -483,6 +487,7 @@ class Engine:
             d.taps = 9 if site.conv3 else 1
             d.dn_s, d.up_p, d.up_t, d.dn_p = st.dn_s.data_ptr(), st.up_p.data_ptr(), st.up_t.data_ptr(), st.dn_p.data_ptr()
             d.up_pg = st.up_pg.data_ptr() if st.up_pg is not None else None
+            d.rp = st.Rp
         self._pack_host = sites
         self._pack_dev = torch.zeros(C.sizeof(sites), dtype=torch.uint8, device=self.device)
         self._pack_scale = None
@@ -620,9 +625,15 @@ class PlanBuilder:
                     kw.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
                 g_t = gemm_args(a0, lora.dn_s, T.ptr, lda=lda0, ldc=T.ld, **kw)
                 self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T), ws=self.eng.workspace))
-                g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, a_ext=T.ptr, w_ext=lora.up_p, ext_k=lora.Rp,
+                e0 = min(lora.Rp, 64)
+                g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, a_ext=T.ptr, w_ext=lora.up_p, ext_k=e0,
                                  ld_aext=T.ld, ld_wext=lora.Rp, **common)
                 self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y), ws=self.eng.workspace))
+                for c in range(64, lora.Rp, 64):   # further 64-column slices of T . (scale up)^T, accumulated into y
+                    assert y is not None and act == ACT_NONE
+                    g_c = gemm_args(T.ptr + 2 * c, lora.up_p.data_ptr() + 2 * c, y.ptr, m=rows, n=site.n, k=64, lda=T.ld,
+                                    ldw=lora.Rp, ldc=y.ld, residual=y.ptr, ldr=y.ld)
+                    self.f_on.append(ops.gemm(g_c, keep=(lora, T, y), ws=self.eng.workspace))
         else:
             self.f_on.append(ops.gemm(g_off, ws=self.eng.workspace))
         if y is not None:
@@ -673,7 +684,11 @@ class PlanBuilder:
         det = self.eng.workspace if self.eng.deterministic else None   # atomic-free wgrad accumulation
         det_bytes = 0 if det is None else det.numel() * det.element_size()
 
-        def emit(p, ldp, q, ldq, g, g_sj, g_sc, cols, s, cv=None, keep=()):
+        def emit(p, ldp, q, ldq, g, g_sj, g_sc, cols, s, cv=None, keep=(), r=r):
+            if r > 16:   # the wgrad kernel keeps <= 16 rank columns in registers: one problem per 16-column slice
+                for j0 in range(0, r, 16):
+                    emit(p + 2 * j0, ldp, q, ldq, g + 4 * j0 * g_sj, g_sj, g_sc, cols, s, cv, keep, min(16, r - j0))
+                return
             if det is None:
                 pr = dict(p=p, ldp=ldp, q=q, ldq=ldq, g=g, g_sj=g_sj, g_sc=g_sc, m=rows, r=r, cols=cols, scale=s)
                 if cv is not None:
@@ -733,9 +748,13 @@ class PlanBuilder:
             else:
                 g = gemm_args(dy.ptr, site.wt, dx.ptr, m=rows, n=kin, k=site.n, lda=dy.ld, ldc=dx.ld,
                               a_ext=U.ptr if U is not None else None, w_ext=lora.dn_p if lora is not None else None,
-                              ext_k=lora.Rp if lora is not None else 0, ld_aext=U.ld if U is not None else 0,
+                              ext_k=min(lora.Rp, 64) if lora is not None else 0, ld_aext=U.ld if U is not None else 0,
                               ld_wext=lora.Rp if lora is not None else 0)
                 out.append(ops.gemm(g, keep=(site, dy, dx, U), ws=self.eng.workspace))
+                for c in range(64, lora.Rp if lora is not None else 0, 64):   # further slices of U . (scale down)
+                    g_c = gemm_args(U.ptr + 2 * c, lora.dn_p.data_ptr() + 2 * c, dx.ptr, m=rows, n=kin, k=64, lda=U.ld,
+                                    ldw=lora.Rp, ldc=dx.ld, residual=dx.ptr, ldr=dx.ld)
+                    out.append(ops.gemm(g_c, keep=(lora, U, dx), ws=self.eng.workspace))
         else:
             B, ho, wo, hi, wi = conv
             if amode == A_CONV3_S1:

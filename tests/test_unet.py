@@ -552,3 +552,35 @@ def test_infer_xl_script_samples_with_a_trained_lora(dev, tmp_path):
     assert base.shape == (1, 4, 16, 16) and torch.isfinite(base.float()).all() and torch.isfinite(lora.float()).all()
     assert (tmp_path / "b.safetensors").exists()
     assert rel_err(lora.cpu(), base.cpu()) > 1e-3          # the LoRA really is applied
+
+
+@pytest.mark.parametrize("rank,c3lier", [(24, False), (32, True)])
+def test_lora_ranks_above_16_forward_backward(dev, rank, c3lier):
+    """Ranks whose stacked columns exceed one K-extension tile (q|k|v: 3 x 24 = 72, 3 x 32 = 96 columns): the low-rank
+    product runs as chained 64-wide extension steps, the weight gradients in 16-column slices -- vs the oracle LoRA."""
+    from leco_amd.lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV
+    ref = oracle_unet()
+    m = hip_unet(dev)
+    targets = list(DEFAULT_TARGET_REPLACE) + (list(UNET_TARGET_REPLACE_MODULE_CONV) if c3lier else [])
+    with contextlib.redirect_stdout(io.StringIO()):
+        rnet = lora_ref.LoRANetworkRef(ref, rank=rank, targets=targets)
+        net = LoRANetwork(m, rank=rank, target_replace_modules=targets)
+    g = torch.Generator().manual_seed(23)
+    with torch.no_grad():
+        for rl, l in zip(rnet.unet_loras, net.unet_loras):
+            d = (torch.randn(rl.lora_down.weight.shape, generator=g) * 0.05).to(bf).float()
+            u = (torch.randn(rl.lora_up.weight.shape, generator=g) * 0.05).to(bf).float()
+            rl.lora_down.weight.copy_(d); rl.lora_up.weight.copy_(u)
+            l.lora_down.weight.copy_(d); l.lora_up.weight.copy_(u)
+    net.mark_updated()
+    x = torch.randn(2, 4, 16, 16, generator=g).to(bf); ctx = torch.randn(2, 77, 64, generator=g).to(bf)
+    tgt = torch.randn(2, 4, 16, 16, generator=g)
+    with net:
+        y = m(x.to(dev), torch.tensor(500), encoder_hidden_states=ctx.to(dev)).sample
+    ((y.float() - tgt.to(dev)) ** 2).mean().backward()
+    with rnet:
+        yr = ref(x.float(), torch.tensor(500), encoder_hidden_states=ctx.float()).sample
+    ((yr - tgt) ** 2).mean().backward()
+    assert rel_err(y.float().cpu(), yr.detach()) < 3e-2
+    gr = torch.cat([p.grad.reshape(-1) for l in rnet.unet_loras for p in (l.lora_down.weight, l.lora_up.weight)])
+    assert rel_err(flat(net, "grad"), gr) < 6e-2
