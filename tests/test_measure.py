@@ -1,0 +1,64 @@
+"""Measurement plumbing on CPU: the launch-shape tuner's table / keys / candidates, `leco_gemm_describe` (dry run of the
+dispatcher: no device needed) and bench.py's attribution of plan launches to kernel-trace rows."""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from leco_amd import hip, tune  # noqa: E402
+
+bf = torch.bfloat16
+
+
+def _args(m, n, k, **kw):
+    x = torch.zeros(8, 8, dtype=bf)       # addresses only: describe / keys never touch the memory
+    return hip.gemm_args(x, x, x, m=m, n=n, k=k, **kw)
+
+
+def test_describe_names_the_instantiation_the_dispatcher_would_launch():
+    hip._use_library(hip.LIB_PATH) if os.path.exists(hip.LIB_PATH) else None
+    ws = torch.zeros(32 * 1024 * 1024 // 4)
+    wsp, wsb = ws.data_ptr(), ws.numel() * 4
+    assert hip.gemm_describe(_args(16384, 320, 2880, a_mode=hip.A_CONV3_S1, conv=(4, 64, 64, 64, 64)), 0, 0, wsp, wsb) \
+        .startswith("gemm_kernel<128, 160, true, 4, 4, 0> grid=256 split=1")
+    # deep K, small M: 256x128 tile, split over K so that one round fills the chip
+    d = hip.gemm_describe(_args(1024, 1280, 11520, a_mode=hip.A_CONV3_S1, conv=(4, 16, 16, 16, 16)), 0, 0, wsp, wsb)
+    assert d.startswith("gemm_kernel<256, 128, true, 3, 4, 0>") and "split=6" in d
+    # large plain 128x128 grids run as 4-wave workgroups (two per CU); explicit tile ids pin either form
+    g = _args(16384, 2560, 320)
+    assert "gemm_kernel<128, 128, false, 2, 2, 0>" in hip.gemm_describe(g, 0, 0, wsp, wsb)
+    assert "gemm_kernel<128, 128, false, 4, 4, 0>" in hip.gemm_describe(g, 6, 1)
+    assert "gemm_kernel<128, 128, false, 2, 2, 0>" in hip.gemm_describe(g, 5, 1)
+    # fused LoRA down-projection on a deep-K small-M shape: the unsplit 64x64 grid keeps it fused (one kernel)
+    x = torch.zeros(8, 8, dtype=bf)
+    g = _args(1024, 1280, 5120, w_ext=x, ext_k=32, t_w=x, t_rows=16, t_out=x)
+    assert hip.gemm_describe(g, 0, 0, wsp, wsb) == "gemm_kernel<64, 64, false, 4, 2, 1> grid=320 split=1"
+
+
+def test_tuner_keys_candidates_and_table():
+    g = _args(4096, 640, 5760, a_mode=hip.A_CONV3_S1, conv=(4, 32, 32, 32, 32), residual=torch.zeros(8, dtype=bf),
+              bias=torch.zeros(8))
+    key = tune.shape_key(g)
+    assert key == "m4096n640k5760a1c4x32x32<32x32e0rbA0"
+    cands = tune.candidates(g, has_ws=True)
+    assert (0, 0) in cands and (2, 2) in cands and (4, 1) in cands and all(t != 6 for t, _ in cands)   # 6: plain only
+    geglu = _args(16384, 2560, 320, act=hip.ACT_GEGLU)
+    assert {t for t, _ in tune.candidates(geglu, has_ws=True)} == {0, 1, 4, 5, 6}                     # 128-column tiles
+    tab = json.load(open(tune.TABLE_PATH))
+    assert tab[key] in ([2, 2], [2, 4], [2, 1]) and len(tab) > 100
+    # without a GPU (or on the emulator) the tuner never measures and defers to the C heuristic
+    assert tune.choose(g, None) == (0, 0)
+
+
+def test_bench_attributes_launches_to_kernel_trace_rows(tmp_path, monkeypatch):
+    import bench
+    top = bench._profile_top_row()
+    assert top and top["name"].startswith("gemm_kernel<") and top["share_pct"] > 5
+    # counter summaries: kernel names contain commas; the row is found by its full name
+    row = bench._pmc_row(bench.PMC_MFMA, top["name"])
+    assert row and row["calls"] > 0 and 0.05 < row["SQ_VALU_MFMA_BUSY_CYCLES"] / (row["GRBM_GUI_ACTIVE"] / 8 * 1024) < 1
+    assert bench._pmc_row(bench.PMC_FETCH, top["name"])["FETCH_SIZE"] > 0
+    assert bench.step_flops(2, 25) == 2 * 2 * 0.8033e12 * (25 + 5 + 0.157)
