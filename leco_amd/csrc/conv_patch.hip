@@ -1,0 +1,423 @@
+// Patch-staged 3x3 / stride-1 convolution for gfx950 (wave64, v_mfma_f32_16x16x32_bf16).
+//
+//   C[m][n] = epilogue( sum_{tap, c} X[pixel(m) + tap][c] * W[n][tap][c] ),   m = (b, y, x), K = 9 Cin
+//
+// Replaces the 3x3 convolutions of diffusers' ResnetBlock2D (conv1 / conv2; call site train_util.py:156-160)
+// and, with the flipped / transposed weight image, their dgrad (train_lora.py:279).  Same operands and
+// epilogue as `gemm_kernel<..., CONV = true>` (gemm.hip); what differs is how the activation operand reaches
+// the MFMAs.  The implicit-GEMM kernel re-DMAs a BM x 64 activation tile for each of the 9 taps (every input
+// pixel travels L2 -> LDS nine times: round 2 measured that path, not the MFMAs, as the bound -- 37.5 of
+// 41.7 us on the level-0 conv).  Here a workgroup owns a TH x TW block of output pixels and stages the
+// (TH + halo) x (TW + 2) x 64-channel INPUT PATCH once per channel chunk; the nine taps are served from that
+// one LDS image by shifted fragment reads:
+//
+//   * tile = TH x TW output pixels, TH rows of the "global row" space g = b * H + y (a tile may span images),
+//     TW in {8, 16}; BM = TH * TW in {128, 256}; BN in {128, 160} output channels.
+//   * patch rows live in a VIRTUAL row space v = g + g / H: every image is followed by one all-zero
+//     separator row, which is at once the bottom halo of image b and the top halo of image b + 1.  The patch
+//     is the contiguous range v0 - 1 .. v_last + 1 with TW + 2 columns (left / right halo); halo and
+//     separator entries are out-of-range lanes of the buffer-descriptor DMA (zeros, no traffic).  Tap (kh, kw) of output pixel (ty, tx) is patch entry
+//     (v(ty) - v0 + kh) * PW + tx + kw: one scalar offset per tap, no validity masks, no branches.
+//   * a patch entry is one pixel's 64 channels = 128 B = 8 x 16-byte slots, XOR-swizzled by (entry & 7) on
+//     the DMA source side (the LDS destination of an LDS-DMA is lane-linear); 16 consecutive entries
+//     -- an MFMA fragment's 16 pixels of one tile row -- read conflict-free at any start offset.
+//   * LDS: two patch buffers (chunk c is consumed while c + 1 lands, spread over the first taps of chunk c)
+//     + an NSW-deep ring of BN x 64 weight tiles, one tile per tap step.  Per step a wave issues
+//     ceil(BN / 64) weight pieces and (first APW taps only) one patch piece: at 256 x 128 that is 2.7 DMA
+//     instructions per wave and step against 6 for the implicit-GEMM tile, 198 KB per chunk against 442 KB.
+//   * the 9 taps of a chunk are unrolled, so every s_waitcnt immediate, tap offset and ring slot rotation is a
+//     compile-time constant; DMAs past the end of the K range are issued out of range (zeros) so that the
+//     counts stay uniform (no drain loop, one loop body).
+//   * no asynchronous fragment read crosses the loop back edge (tools/audit_async_lds.py).
+#include <errno.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include <hip/hip_runtime.h>
+#include <leco_prims.h>
+
+#include "common.h"
+
+namespace leco {
+namespace {
+
+constexpr int BK = 64;
+
+struct PatchRt {
+    int tiles_n, tiles_x, tiles_g;   // grid.x = tiles_g * tiles_x * tiles_n
+    int split_k;                     // > 1: raw fp32 partials to ws[split][M][N], epilogue by splitk_finish
+    int tw_log2;                     // TW = 8 or 16
+    unsigned a0_bytes, a1_bytes, w_bytes;   // operand extents (buffer descriptors; < 2^31)
+    float* ws;
+};
+
+template <int BM, int BN, int NSW>
+struct PatchCfg {
+    static constexpr int NW = 8;
+    static constexpr int APW = BM == 256 ? 6 : 4;          // patch pieces (8 entries each) per wave and chunk
+    static constexpr int PCAP = APW * NW * 8;              // patch capacity in entries (pixels)
+    static constexpr int GWT = BN / 8, GW = (GWT + NW - 1) / NW;
+    static constexpr bool RAGW = (GWT % NW) != 0;          // the last weight piece exists only for the low waves
+    static constexpr int WTILE = BN * BK * 2;              // bytes per weight ring slot
+    static constexpr int PBUF = PCAP * BK * 2;             // bytes per patch buffer
+    static constexpr int OFF_A = NSW * WTILE, OFF_DUMP = OFF_A + 2 * PBUF;
+    static constexpr int LDS_BYTES = OFF_DUMP + (RAGW ? 1024 : 0);
+    static constexpr int SROW = BN + 4;                    // epilogue staging row (fp32)
+    static_assert(APW <= 10 - NSW, "the next chunk's patch must be covered by the wait of tap 8");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS layout does not fit");
+    static_assert(64 * SROW * 4 <= LDS_BYTES, "epilogue staging does not fit");
+};
+
+template <int BM, int BN, int NSW>
+__global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p, const PatchRt rt) {
+    using Cf = PatchCfg<BM, BN, NSW>;
+    constexpr int NW = Cf::NW, NT = NW * 64;
+    constexpr int WM = BM / 4, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int APW = Cf::APW, GW = Cf::GW, GWT = Cf::GWT;
+    constexpr bool RAGW = Cf::RAGW;
+    constexpr int WTILE = Cf::WTILE, PBUF = Cf::PBUF, OFF_A = Cf::OFF_A, OFF_DUMP = Cf::OFF_DUMP;
+    unsigned char* lds = dyn_lds();
+
+    // ---- work decomposition: XCD-aware bijective remap (hardware places linear workgroup id b on XCD b % 8), split
+    // major; inside a split the LARGER operand is what an XCD keeps to itself (N > M: m-fastest walk, an XCD owns a
+    // slice of W's rows; otherwise n-fastest: an XCD owns a slice of the activations) -- as gemm.hip
+    const int tiles_m = rt.tiles_g * rt.tiles_x;
+    const int tiles = (int)gridDim.x;
+    const int nwg = tiles * (int)gridDim.y, bid = (int)blockIdx.x + (int)blockIdx.y * tiles;
+    const int q8 = nwg >> 3, r8 = nwg & 7, xcd = bid & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    const int split = wg / tiles, t_in = wg - split * tiles;
+    int tile_m, tile_n;
+    if (p.n > p.m) { tile_n = t_in / tiles_m; tile_m = t_in - tile_n * tiles_m; }
+    else { tile_m = t_in / rt.tiles_n; tile_n = t_in - tile_m * rt.tiles_n; }
+    const int tile_g = tile_m / rt.tiles_x, tile_x = tile_m - tile_g * rt.tiles_x;
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+    const int st_row = lane >> 3, st_pos = lane & 7;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int TWl = rt.tw_log2, TW = 1 << TWl, TH = BM >> TWl, PW = TW + 2;
+    const int H = p.h_out, W = p.w_out, GROWS = p.batch * H;
+    const int g0 = tile_g * TH, x0 = tile_x * TW, n0 = tile_n * BN;
+    const int v0 = g0 + g0 / H;                                  // virtual row of the tile's first output row
+    const int g_last = (g0 + TH < GROWS ? g0 + TH : GROWS) - 1;
+    const int PR = (g_last + g_last / H) - v0 + 3;               // patch rows: v0 - 1 .. v(g_last) + 1
+    const int M = p.m, N = p.n;
+    const int cin = p.k / 9, nchunks = cin / BK;
+    const int chunk_begin = (int)(((int64_t)nchunks * split) / rt.split_k);
+    const int chunk_end = (int)(((int64_t)nchunks * (split + 1)) / rt.split_k);
+    const int k_split = p.a1 ? p.k_split : 0x7fffffff;
+
+    // operands through buffer descriptors: 32-bit per-lane offsets, and an out-of-range offset (DMA_OOB) reads zeros --
+    // halo / separator entries, rows n >= N, the padding piece of a ragged weight tile and every DMA issued past the end
+    // of the K range cost no memory traffic and need no zero page or select
+    const buf_rsrc ra0 = make_rsrc(p.a0, rt.a0_bytes);
+    const buf_rsrc ra1 = make_rsrc(p.a1 ? p.a1 : p.a0, p.a1 ? rt.a1_bytes : rt.a0_bytes);
+    const buf_rsrc rw = make_rsrc(p.w, rt.w_bytes);
+    const unsigned cpos = (unsigned)((st_pos ^ st_row) * 16);   // swizzled 16-byte slot this lane fills: entry & 7 == st_row
+
+    // ---- patch loader state: the APW entries this lane stages per chunk, built once: pixel index in bits 0..23
+    // (v_mul_u32_u24 ignores the rest), bit 31 set = halo / separator / beyond the patch: the DMA offset gets that bit
+    // OR-ed in, which puts it out of the descriptor's range
+    unsigned ppix[APW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int q = (wave + NW * j) * 8 + st_row;
+        const int srow = q / PW, scol = q - srow * PW;
+        const int v = v0 - 1 + srow;
+        const int vb = v >= 0 ? v / (H + 1) : 0, vy = v - vb * (H + 1);
+        const int xx = x0 - 1 + scol;
+        const bool ok = (srow < PR) & (v >= 0) & (vy < H) & (vb < p.batch) & (xx >= 0) & (xx < W);
+        ppix[j] = ok ? (unsigned)((vb * H + vy) * W + xx) : DMA_OOB;
+    }
+    // weight rows of this lane: byte offset of (row, swizzled slot), loop invariant
+    unsigned wvoff[GW];
+#pragma unroll
+    for (int i = 0; i < GW; ++i) {
+        const int rl = (wave + NW * i) * 8 + st_row;
+        const int n = n0 + rl;
+        wvoff[i] = (rl < BN && n < N) ? (unsigned)n * (unsigned)p.ldw * 2u + cpos : DMA_OOB;
+    }
+    // patch piece j of chunk `cabs` (absolute channel chunk; chunks >= chunk_end: zeros) into patch buffer `pb`
+    auto issue_a = [&](int j, int cabs, int pb) {
+        const int cch = cabs * BK;
+        const bool first = cch < k_split;
+        const unsigned ld = first ? (unsigned)p.lda0 : (unsigned)p.lda1;
+        const unsigned soff = (unsigned)(first ? cch : cch - k_split) * 2u;
+        const unsigned dead = cabs < chunk_end ? 0u : DMA_OOB;
+        const unsigned voff = (mul24(ppix[j], ld) * 2u + cpos) | (ppix[j] & DMA_OOB) | dead;
+        glds16_buf(first ? ra0 : ra1, voff, soff, lds + OFF_A + pb * PBUF + (wave + NW * j) * (8 * BK * 2));
+    };
+    // weight tile of (chunk cabs, tap) into ring slot `slot`
+    auto issue_w = [&](int cabs, int tap, int slot) {
+        const bool live = cabs < chunk_end;
+        const unsigned soff = live ? (unsigned)(tap * cin + cabs * BK) * 2u : 0u;
+        const unsigned dead = live ? 0u : DMA_OOB;
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            const bool real = !RAGW || i < GW - 1 || (wave + NW * i) < GWT;     // wave-uniform
+            unsigned char* dst = real ? lds + slot * WTILE + (wave + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
+            glds16_buf(rw, wvoff[i] | dead | (real ? 0u : DMA_OOB), soff, dst);
+        }
+    };
+
+    // ---- fragment addressing.  Activation fragment i of this wave = tile rows r = wave_m * WM + 16 i + fr; its tap
+    // (0, 0) patch entry is abase[i]; tap (kh, kw) adds kh * PW + kw.  Weight fragment j = tile rows wave_n * WN + 16 j + fr.
+    int abase[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int r = wave_m * WM + i * 16 + fr;
+        const int ty = r >> TWl, tx = r & (TW - 1);
+        const int g = g0 + ty;
+        abase[i] = g < GROWS ? ((g + g / H) - v0) * PW + tx : 0;
+    }
+    const int wl0 = (wave_n * WN + fr) * (BK * 2) + ((fg ^ (fr & 7)) << 4);       // ks = 0; ks = 1 flips bit 6
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 afA[FM], wfA[FN], afB[FM], wfB[FN];
+    int aoff[FM];                                   // byte offset of the ks = 0 read of the current step (ks = 1: ^ 64)
+    auto read_a0 = [&](int pb, int dtap, bf16x8 (&af)[FM]) {
+        const unsigned char* base = lds + OFF_A + pb * PBUF;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int P = abase[i] + dtap;
+            aoff[i] = (P << 7) + ((fg ^ (P & 7)) << 4);
+            af[i] = lds_read16_async(base + aoff[i]);
+        }
+    };
+    auto read_a1 = [&](int pb, bf16x8 (&af)[FM]) {
+        const unsigned char* base = lds + OFF_A + pb * PBUF;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = lds_read16_async(base + (aoff[i] ^ 64));
+    };
+    auto read_w = [&](int slot, int ks, bf16x8 (&wf)[FN]) {
+        const unsigned char* base = lds + slot * WTILE + (wl0 ^ (ks << 6));
+#pragma unroll
+        for (int j = 0; j < FN; ++j) wf[j] = lds_read16_async(base + j * (16 * BK * 2));
+    };
+    auto landed = [&](bf16x8 (&af)[FM], bf16x8 (&wf)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) lds_tie(af[i]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) lds_tie(wf[j]);
+    };
+    auto mma = [&](const bf16x8 (&af)[FM], const bf16x8 (&wf)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
+    };
+
+    // ---- prologue: patch of the first chunk, weight tiles of steps 0 .. NSW - 1
+    if (chunk_begin < chunk_end) {
+#pragma unroll
+        for (int j = 0; j < APW; ++j) issue_a(j, chunk_begin, 0);
+#pragma unroll
+        for (int s = 0; s < NSW; ++s) issue_w(chunk_begin, s, s);
+        wait_vmcnt<(NSW - 1) * GW>();
+        barrier_keep_dma();
+        read_a0(0, 0, afA);
+        read_w(0, 0, wfA);
+        lds_wait<0>();
+        landed(afA, wfA);
+    }
+    int slot = 0, pb = 0;
+    for (int c = chunk_begin; c < chunk_end; ++c) {
+        // the tap offsets are loop invariant: without this the compiler hoists the fragment addresses of all 9 taps x FM
+        // fragments (x 2 patch buffers) out of the loop and spills; recomputing them costs 5 VALU per read beside 2 FN MFMAs
+#pragma unroll
+        for (int i = 0; i < FM; ++i) opaque(abase[i]);
+        // one tap step; everything that depends on `tap` is a compile-time constant
+        auto step = [&](auto tap_c) {
+            constexpr int tap = decltype(tap_c)::value;
+            constexpr int tn = (tap + NSW) % 9, cn = (tap + NSW) / 9;            // the weight tile this step refills with
+            // DMAs younger than weight tile t + 1 at this step's wait: everything issued in steps t - (NSW - 2) .. t - 1
+            constexpr int younger = [] {
+                int n = 0;
+                for (int d = 1; d <= NSW - 2; ++d) n += GW + ((((tap - d) % 9 + 9) % 9) < APW ? 1 : 0);
+                return n;
+            }();
+            const int dnext = ((tap + 1) % 9 / 3) * PW + (tap + 1) % 9 % 3;      // patch offset of the next step's tap
+            read_a1(pb, afB);
+            read_w(slot, 1, wfB);
+            lds_wait<FM + FN>();
+            landed(afA, wfA);
+            mma(afA, wfA);
+            sched_fence();
+            wait_vmcnt<younger>();            // weight tile t + 1 (and, at tap 8, the next chunk's patch) landed
+            barrier_keep_dma();               // ... for every wave; all waves are done with slot `slot` (completes set B)
+            landed(afB, wfB);
+            if constexpr (tap < APW) issue_a(tap, c + 1, pb ^ 1);
+            issue_w(c + cn, tn, slot);
+            const int snext = slot + 1 == NSW ? 0 : slot + 1;
+            read_a0(tap == 8 ? pb ^ 1 : pb, dnext, afA);
+            read_w(snext, 0, wfA);
+            mma(afB, wfB);
+            sched_fence();
+            slot = snext;
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
+        pb ^= 1;
+        lds_wait<0>();                        // set A complete before the back edge / the loop exit
+        landed(afA, wfA);
+    }
+    wait_vmcnt<0>();                          // the out-of-range DMAs issued past the end of the K range
+
+    // ---- epilogue through LDS: accumulators (lane = one pixel x 4 consecutive n) staged as fp32, 64 tile rows at a
+    // time, so bias / residual reads and the bf16 (or fp32 partial) stores move whole 16-byte row segments
+    constexpr int SROW = Cf::SROW, NC8 = BN / 8;
+    float* stg = (float*)lds;
+    bf16_t* cp = (bf16_t*)p.c;
+    const bf16_t* res = (const bf16_t*)p.residual;
+    float* wsp = rt.split_k > 1 ? rt.ws + (int64_t)split * M * N : nullptr;
+#pragma unroll
+    for (int h = 0; h < BM / 64; ++h) {
+        barrier_keep_dma();
+        if ((wave_m * WM) / 64 == h) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int rl = (wave_m * WM) % 64 + i * 16 + fr;
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    *(f32x4*)(stg + rl * SROW + wave_n * WN + j * 16 + 4 * fg) = acc[i][j];
+            }
+        }
+        barrier_keep_dma();
+        for (int e = tid; e < 64 * NC8; e += NT) {
+            const int rl = e / NC8, cc = e - rl * NC8;
+            const int r = h * 64 + rl;
+            const int g = g0 + (r >> TWl), xx = x0 + (r & (TW - 1));
+            const int n = n0 + cc * 8;
+            if (g >= GROWS || xx >= W || n >= N) continue;
+            const int m = g * W + xx;
+            const f32x4 v0_ = *(const f32x4*)(stg + rl * SROW + cc * 8);
+            const f32x4 v1_ = *(const f32x4*)(stg + rl * SROW + cc * 8 + 4);
+            float v[8] = {v0_[0], v0_[1], v0_[2], v0_[3], v1_[0], v1_[1], v1_[2], v1_[3]};
+            if (wsp) {
+                *(f32x4*)(wsp + (int64_t)m * N + n) = v0_;
+                *(f32x4*)(wsp + (int64_t)m * N + n + 4) = v1_;
+                continue;
+            }
+            if (p.bias) {
+                const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
+            }
+            if (p.rowbias) {
+                const float* rb = p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias + n;
+                const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
+            }
+            if (res) {
+                const u32x4 rr = *(const u32x4*)(res + (int64_t)m * p.ldr + n);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[2 * q] += bf2f((bf16_t)(rr[q] & 0xffffu));
+                    v[2 * q + 1] += bf2f((bf16_t)(rr[q] >> 16));
+                }
+            }
+            if (p.act == LECO_ACT_SILU) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = v[q] / (1.f + __expf(-v[q]));
+            }
+            if (cp) {
+                const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
+                *(u32x4*)(cp + (int64_t)m * p.ldc + n) = o;
+            }
+            if (p.c_f32) {
+                const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+                *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n) = o0;
+                *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n + 4) = o1;
+            }
+        }
+    }
+}
+
+// tile geometry of one (BM, problem): TW, tile counts, and whether every tile's patch fits the capacity
+struct PatchGeom { int tw_log2, tiles_g, tiles_x; bool fits; };
+
+PatchGeom patch_geometry(const leco_gemm_args& a, int bm, int pcap) {
+    const int H = a.h_out, W = a.w_out, grows = a.batch * H;
+    // TW: the candidate that wastes fewer output columns; ties go to 16 (fragment rows = 16 consecutive patch
+    // entries: conflict-free reads, smaller halo)
+    auto cols = [&](int tw) { return cdiv(W, tw) * tw; };
+    const int tw = cols(16) <= cols(8) ? 16 : 8;
+    PatchGeom g{tw == 16 ? 4 : 3, 0, cdiv(W, tw), true};
+    const int th = bm / tw, pw = tw + 2;
+    g.tiles_g = cdiv(grows, th);
+    for (int t = 0; t < g.tiles_g; ++t) {
+        const int g0 = t * th, gl = (g0 + th < grows ? g0 + th : grows) - 1;
+        const int pr = (gl + gl / H) - (g0 + g0 / H) + 3;
+        if (pr * pw > pcap) g.fits = false;
+    }
+    return g;
+}
+
+template <int BM, int BN, int NSW>
+int launch_patch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, char* describe, int describe_len) {
+    using Cf = PatchCfg<BM, BN, NSW>;
+    const PatchGeom g = patch_geometry(a, BM, Cf::PCAP);
+    if (!g.fits) return 1;
+    const int tn = cdiv(a.n, BN);
+    // operand extents in bytes (the descriptors' range check makes DMA_OOB lanes read zeros): < 2^31 or no patch path
+    const int cin = a.k / 9;
+    const int64_t pixels = (int64_t)a.batch * a.h_in * a.w_in;
+    const int c0 = a.a1 ? a.k_split : cin, c1 = cin - c0;
+    const int64_t e0 = ((pixels - 1) * a.lda0 + c0) * 2, e1 = a.a1 ? ((pixels - 1) * a.lda1 + c1) * 2 : 0;
+    const int64_t ew = ((int64_t)(a.n - 1) * a.ldw + a.k) * 2;
+    if (e0 >= (1ll << 31) || e1 >= (1ll << 31) || ew >= (1ll << 31)) return 1;
+    PatchRt rt{tn, g.tiles_x, g.tiles_g, split_k, g.tw_log2, (unsigned)e0, (unsigned)e1, (unsigned)ew, ws};
+    dim3 grid((unsigned)(g.tiles_g * g.tiles_x * tn), (unsigned)split_k);
+    if (describe) {
+        const int used = (int)strlen(describe);
+        snprintf(describe + used, describe_len - used, "%sconv_patch_kernel<%d, %d, %d> grid=%u split=%d", used ? " ; " : "",
+                 BM, BN, NSW, grid.x, split_k);
+        return 0;
+    }
+    static bool attr_set[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<BM, BN, NSW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
+    }
+    hipLaunchKernelGGL((conv_patch_kernel<BM, BN, NSW>), grid, dim3(512), Cf::LDS_BYTES, s, a, rt);
+    return 0;
+}
+}  // namespace
+
+// 0: launched (or described); 1: this problem / variant cannot take the patch path (the caller falls back to the
+// implicit-GEMM kernel); < 0: error.  variant: 7 = 256 x 128, 8 = 128 x 160, 9 = 128 x 128, 10 = 256 x 160.
+int conv_patch_try(const leco_gemm_args& a, int variant, int split_k, float* ws, hipStream_t s, char* describe,
+                   int describe_len) {
+    if (a.a_mode != LECO_A_CONV3_S1 || a.a_ext || a.t_w || a.act == LECO_ACT_GEGLU) return 1;
+    if (a.h_in != a.h_out || a.w_in != a.w_out) return 1;
+    const int nchunks = a.k / 9 / BK;
+    if (split_k > nchunks) split_k = nchunks;
+    if (split_k < 1) split_k = 1;
+    switch (variant) {
+        case 7: return launch_patch<256, 128, 4>(a, split_k, ws, s, describe, describe_len);
+        case 8: return launch_patch<128, 160, 4>(a, split_k, ws, s, describe, describe_len);
+        case 9: return launch_patch<128, 128, 4>(a, split_k, ws, s, describe, describe_len);
+        case 10: return launch_patch<256, 160, 3>(a, split_k, ws, s, describe, describe_len);
+        default: return 1;
+    }
+}
+}  // namespace leco

@@ -665,11 +665,7 @@ int launch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, int s
         if (a.a_mode == LECO_A_PLAIN) launch_one<BM, BN, false>(a, rt, grid, s, shape);
         else launch_one<BM, BN, true>(a, rt, grid, s, shape);
     }
-    if (split_k > 1 && !tl_describe) {
-        const int64_t quads = (int64_t)a.m * a.n / 4;
-        const int g = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3(g), dim3(256), 0, s, a, (const float*)ws, split_k);
-    }
+    if (split_k > 1 && !tl_describe) splitk_finish_launch(a, ws, split_k, s);
     if (tl_describe) return 0;
     return check_launch("leco_gemm");
 }
@@ -714,10 +710,18 @@ int validate(const leco_gemm_args& a) {
     return 0;
 }
 }  // namespace
+
+void splitk_finish_launch(const leco_gemm_args& a, const float* ws, int splits, hipStream_t s) {
+    const int64_t quads = (int64_t)a.m * a.n / 4;
+    const int g = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3(g), dim3(256), 0, s, a, ws, splits);
+}
 }  // namespace leco
 
 // tile: 0 = heuristic, 1 = 128x128 (wave shape by grid size), 2 = 128x160, 3 = 64x64, 4 = 256x128, 5 = 128x128 as
-// 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU.  split_k: 0 = heuristic (needs a
+// 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU; 7..10 = the patch-staged 3x3 / stride-1
+// convolution (conv_patch.hip) on 256x128 / 128x160 / 128x128 / 256x160 tiles -- problems it does not cover (other
+// gathers, a LoRA K-extension, a patch that does not fit) fall back to the heuristic.  split_k: 0 = heuristic (needs a
 // workspace), 1 = none, >1 = that many K slices.  workspace: fp32 scratch for split-K partials.
 extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, void* workspace,
                             int64_t workspace_bytes, leco_stream_t stream) {
@@ -746,7 +750,8 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
             if (tile == 1 && workspace != nullptr && m >= 1024 && nk >= 64) tile = 4;
         }
     }
-    const int bm = tile == 3 ? 64 : (tile == 4 ? 256 : 128), bn = tile == 3 ? 64 : (tile == 2 ? 160 : 128);   // 1, 5, 6: 128x128
+    const int bm = tile == 3 ? 64 : ((tile == 4 || tile == 7 || tile == 10) ? 256 : 128);
+    const int bn = tile == 3 ? 64 : ((tile == 2 || tile == 8 || tile == 10) ? 160 : 128);   // 1, 5, 6, 9: 128x128
     const long tiles = (long)cdiv(m, bm) * cdiv(n, bn);
     if (split_k == 0) {
         split_k = 1;
@@ -791,6 +796,14 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
             main_args.ld_aext = args->ld_tout;
             return leco_gemm_ex(&main_args, tile, split_k, workspace, workspace_bytes, stream);
         }
+    }
+    if (tile >= 7 && tile <= 10) {
+        rc = conv_patch_try(*args, tile, split_k, (float*)workspace, s, tl_describe, tl_describe_len);
+        if (rc == 1) return leco_gemm_ex(args, 0, 0, workspace, workspace_bytes, stream);
+        if (rc < 0 || tl_describe) return rc;
+        const int nchunks = args->k / 9 / BK;
+        if (split_k > 1) splitk_finish_launch(*args, (const float*)workspace, split_k < nchunks ? split_k : nchunks, s);
+        return check_launch("leco_gemm");
     }
     switch (tile) {
         case 1: return launch<128, 128>(*args, split_k, (float*)workspace, s);

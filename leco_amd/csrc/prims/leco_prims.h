@@ -41,6 +41,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
+// The same DMA through a buffer resource descriptor (buffer_load_dwordx4 ... offen lds): the source is
+// base + voff (per lane, bytes) + soff (wave-uniform, bytes) -- 32-bit offsets, no 64-bit per-lane pointer math -- and a
+// lane whose voff lies beyond the descriptor's extent reads ZEROS (hardware range check): conv halos / padding rows need
+// neither a zero page nor a select.  `bytes` < 2^31 so that DMA_OOB is out of range for every soff.
+typedef __amdgpu_buffer_rsrc_t buf_rsrc;
+constexpr unsigned DMA_OOB = 0x80000000u;
+__device__ __forceinline__ buf_rsrc make_rsrc(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void glds16_buf(buf_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
+}
 // Counted wait on this wave's outstanding global/LDS-DMA operations (s_waitcnt vmcnt(N)): the N most
 // recently issued may still be in flight.  Lets several tile DMAs span a barrier.
 template <int N>
@@ -77,6 +89,9 @@ __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
 __device__ __forceinline__ void lds_tie(bf16x8& v) { asm volatile("" : "+v"(v)); }
+// makes a value opaque to the optimiser at this point (no instruction is emitted): stops loop-invariant code motion
+// from hoisting -- and spilling -- whole tables of addresses derived from it
+__device__ __forceinline__ void opaque(int& v) { asm volatile("" : "+v"(v)); }
 // scheduling fence: the compiler moves no instruction across it
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 // Occupancy floor for a kernel (waves per SIMD).  Besides capping the register budget it makes the compiler

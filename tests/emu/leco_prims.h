@@ -84,6 +84,16 @@ static inline void glds16(const void* gsrc, void* lds_wave_base) {
     Q.q[(Q.head + Q.count) & 63] = emu_dma::Pending{gsrc, dst};
     ++Q.count;
 }
+// buffer-descriptor form: 32-bit offsets, out-of-range lanes read zeros
+struct buf_rsrc { const unsigned char* base; unsigned bytes; };
+constexpr unsigned DMA_OOB = 0x80000000u;
+static inline buf_rsrc make_rsrc(const void* base, unsigned bytes) { return buf_rsrc{(const unsigned char*)base, bytes}; }
+static inline void glds16_buf(buf_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
+    static const unsigned char zeros[16] = {0};
+    // range check on the per-lane offset alone (gfx9 raw buffers: buffer_offset >= num_records - soffset is out of range)
+    const bool oob = voff >= r.bytes || (unsigned long long)voff + soff + 16 > r.bytes;
+    glds16(oob ? (const void*)zeros : (const void*)(r.base + voff + soff), lds_wave_base);
+}
 template <int N>
 static inline void wait_vmcnt() { if (emu_dma::late()) emu_dma::complete_all_but(N); }
 #undef __syncthreads
@@ -105,6 +115,7 @@ static inline u32x2 lds_read_tr16(const void* lds_ptr) {
 template <int N>
 static inline void lds_wait() {}
 static inline void lds_tie(bf16x8&) {}
+static inline void opaque(int&) {}
 static inline void sched_fence() {}
 static inline void barrier_keep_dma() { emu::sync_block(); }
 static inline unsigned char* dyn_lds() {

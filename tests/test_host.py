@@ -46,6 +46,9 @@ def test_async_lds_reads_are_never_touched_in_flight():
     import audit_async_lds
     report = audit_async_lds.audit_source(os.path.join(ROOT, "leco_amd", "csrc", "gemm.hip"))
     assert len(report) >= 15
+    patch = audit_async_lds.audit_source(os.path.join(ROOT, "leco_amd", "csrc", "conv_patch.hip"))
+    assert len(patch) >= 4
+    report = report + patch
     bad = {audit_async_lds.pretty(name): list(v.items())[:3] for name, _, v in report if v}
     assert not bad, bad
 

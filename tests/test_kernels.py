@@ -237,6 +237,64 @@ def test_conv3x3_modes(dev, mode):
     assert rel_err(got, ref) < TOL32
 
 
+# (tile id, B, H, W, Cin, Cout, two-source split, split_k): TW = 16 and TW = 8 geometries, tiles that span several
+# images (the zero separator rows of the virtual row space), ragged rows / columns / output channels, the padding piece
+# of the 160-column weight tile, a channel range from two tensors, K slices
+PATCH_CASES = [
+    (7, 1, 16, 16, 64, 128, 0, 1),      # one 16x16 tile = one image
+    (7, 3, 8, 8, 128, 136, 0, 1),       # TW = 8: a 32-row tile over three 8x8 images (+ ragged rows, ragged n)
+    (7, 2, 24, 24, 64, 64, 0, 1),       # W % 16 != 0 -> TW = 8; tiles cross the image boundary mid-tile
+    (8, 2, 6, 10, 64, 320, 0, 1),       # 128x160: ragged columns (W = 10 in 16-wide tiles), 8-row tiles over 2 images
+    (8, 1, 32, 32, 192, 160, 64, 1),    # two-source channel range (64 + 128), three chunks
+    (9, 2, 12, 20, 128, 64, 0, 2),      # 128x128, split-K over the two chunks
+    (10, 1, 20, 16, 256, 200, 128, 2),  # 256x160 (3-slot ring), two sources, split-K, ragged n
+    (7, 4, 5, 7, 64, 64, 0, 1),         # odd sizes: many tiny images per tile
+]
+
+
+@pytest.mark.parametrize("tile,B,H,W_,Ci,Co,ks,split", PATCH_CASES)
+def test_conv3x3_patch_staged(dev, tile, B, H, W_, Ci, Co, ks, split):
+    """conv_patch.hip (tile ids 7..10 of leco_gemm_ex) vs F.conv2d on the same bf16-rounded operands, with the full
+    epilogue (bias + per-sample row bias + residual + SiLU, bf16 and fp32 outputs)."""
+    torch.manual_seed(tile * 100 + H)
+    x = torch.randn(B, Ci, H, W_).to(bf)
+    wt = (torch.randn(Co, Ci, 3, 3) / (9 * Ci) ** 0.5).to(bf)
+    bias, rowb = torch.randn(Co), torch.randn(B, Co)
+    res = torch.randn(B, Co, H, W_).to(bf)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wh = wt.permute(0, 2, 3, 1).contiguous().reshape(Co, 9 * Ci).to(dev)
+    resh = res.permute(0, 2, 3, 1).contiguous().reshape(B * H * W_, Co).to(dev)
+    M = B * H * W_
+    out = torch.zeros(M, Co, dtype=bf, device=dev)
+    o32 = torch.zeros(M, Co, device=dev)
+    kw = {}
+    if ks:       # channels [0, ks) from one tensor, the rest from another (skip-connection concat)
+        x0h = x[:, :ks].permute(0, 2, 3, 1).contiguous().to(dev)
+        x1h = x[:, ks:].permute(0, 2, 3, 1).contiguous().to(dev)
+        kw = dict(lda=ks, a1=x1h, lda1=Ci - ks, k_split=ks)
+        xh = x0h
+    g = hip.gemm_args(xh, wh, out, m=M, n=Co, k=9 * Ci, a_mode=hip.A_CONV3_S1, conv=(B, H, W_, H, W_), out_f32=o32,
+                      bias=bias.to(dev), rowbias=rowb.to(dev), rows_per_group=H * W_, residual=resh, act=hip.ACT_SILU,
+                      **{"lda": Ci, **kw})
+    desc = hip.gemm_describe(g, tile, split, None, 0)
+    assert "conv_patch_kernel" in desc, desc
+    ws = torch.zeros(split * M * Co, device=dev) if split > 1 else None
+    hip.gemm(g, ops.default_stream(), tile=tile, split_k=split, ws=ws)
+    _sync(dev)
+    ref = F.conv2d(x.float(), wt.float(), padding=1) + bias[None, :, None, None] + rowb[:, :, None, None] + res.float()
+    ref = F.silu(ref).permute(0, 2, 3, 1).reshape(M, Co)
+    assert rel_err(o32.cpu(), ref) < TOL32
+    assert rel_err(out.cpu(), ref) < TOLBF
+
+
+def test_conv3x3_patch_falls_back_when_not_applicable(dev):
+    """Tile ids 7..10 on a problem the patch kernel does not cover (stride 2) run the implicit-GEMM kernel instead."""
+    g = hip.gemm_args(torch.zeros(2 * 8 * 8, 64, dtype=bf, device=dev), torch.zeros(64, 576, dtype=bf, device=dev),
+                      torch.zeros(2 * 4 * 4, 64, dtype=bf, device=dev), m=32, n=64, k=576, lda=64, a_mode=hip.A_CONV3_S2,
+                      conv=(2, 4, 4, 8, 8))
+    assert "gemm_kernel" in hip.gemm_describe(g, 7, 1, None, 0)
+
+
 @pytest.mark.parametrize("act,B,HW,C0,C1,G", [
     (0, 2, 37, 64, 128, 32),      # cg = 6 -> 4 groups per block, two-source
     (1, 2, 37, 64, 128, 32),
