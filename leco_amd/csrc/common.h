@@ -19,4 +19,6 @@ void splitk_finish_launch(const leco_gemm_args& a, const float* ws, int splits, 
 // applicable (caller falls back to the implicit-GEMM kernel), < 0 = error.
 int conv_patch_try(const leco_gemm_args& a, int variant, int split_k, float* ws, hipStream_t s, char* describe,
                    int describe_len);
+// conv_patch.hip: the patch variant (tile id 7..10) and split_k its cost model picks for `a`; 0 = not applicable
+int conv_patch_choose(const leco_gemm_args& a, int64_t ws_bytes, int split_in, int* split);
 }  // namespace leco

@@ -118,20 +118,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     const buf_rsrc rw = make_rsrc(p.w, rt.w_bytes);
     const unsigned cpos = (unsigned)((st_pos ^ st_row) * 16);   // swizzled 16-byte slot this lane fills: entry & 7 == st_row
 
-    // ---- patch loader state: the APW entries this lane stages per chunk, built once: pixel index in bits 0..23
-    // (v_mul_u32_u24 ignores the rest), bit 31 set = halo / separator / beyond the patch: the DMA offset gets that bit
-    // OR-ed in, which puts it out of the descriptor's range
+    // ---- patch loader state: the APW entries this lane stages per chunk: pixel index in bits 0..23 (v_mul_u32_u24
+    // ignores the rest), bit 31 set = halo / separator / beyond the patch: the DMA offset gets that bit OR-ed in, which
+    // puts it out of the descriptor's range.  Filled in the prologue, behind the first weight DMAs.
     unsigned ppix[APW];
-#pragma unroll
-    for (int j = 0; j < APW; ++j) {
-        const int q = (wave + NW * j) * 8 + st_row;
-        const int srow = q / PW, scol = q - srow * PW;
-        const int v = v0 - 1 + srow;
-        const int vb = v >= 0 ? v / (H + 1) : 0, vy = v - vb * (H + 1);
-        const int xx = x0 - 1 + scol;
-        const bool ok = (srow < PR) & (v >= 0) & (vy < H) & (vb < p.batch) & (xx >= 0) & (xx < W);
-        ppix[j] = ok ? (unsigned)((vb * H + vy) * W + xx) : DMA_OOB;
-    }
     // weight rows of this lane: byte offset of (row, swizzled slot), loop invariant
     unsigned wvoff[GW];
 #pragma unroll
@@ -163,6 +153,14 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
         }
     };
 
+    auto issue_w1 = [&](int cabs, int tap, int slot, int i) {      // piece i of that tile
+        const bool live = cabs < chunk_end;
+        const unsigned soff = live ? (unsigned)(tap * cin + cabs * BK) * 2u : 0u;
+        const bool real = !RAGW || i < GW - 1 || (wave + NW * i) < GWT;         // wave-uniform
+        unsigned char* dst = real ? lds + slot * WTILE + (wave + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
+        glds16_buf(rw, wvoff[i] | (live ? 0u : DMA_OOB) | (real ? 0u : DMA_OOB), soff, dst);
+    };
+
     // ---- fragment addressing.  Activation fragment i of this wave = tile rows r = wave_m * WM + 16 i + fr; its tap
     // (0, 0) patch entry is abase[i]; tap (kh, kw) adds kh * PW + kw.  Weight fragment j = tile rows wave_n * WN + 16 j + fr.
     int abase[FM];
@@ -171,7 +169,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
         const int r = wave_m * WM + i * 16 + fr;
         const int ty = r >> TWl, tx = r & (TW - 1);
         const int g = g0 + ty;
-        abase[i] = g < GROWS ? ((g + g / H) - v0) * PW + tx : 0;
+        abase[i] = g < GROWS ? ((g + (int)(((float)g + 0.5f) * (1.0f / (float)H))) - v0) * PW + tx : 0;
     }
     const int wl0 = (wave_n * WN + fr) * (BK * 2) + ((fg ^ (fr & 7)) << 4);       // ks = 0; ks = 1 flips bit 6
 
@@ -215,13 +213,37 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
     };
 
-    // ---- prologue: patch of the first chunk, weight tiles of steps 0 .. NSW - 1
+    // ---- prologue: weight tiles of steps 0 .. NSW - 1 first (their addresses are cheap), then -- while those fly --
+    // the patch loader table, then the patch of the first chunk.  Small-operand integer divisions go through an exact
+    // float reciprocal (operands < 2^18, validated on the host): a 32-bit division is ~40 instructions, and the table
+    // needs 2 APW of them per lane.
+    auto divf = [](int a, float rcp) { return (int)(((float)a + 0.5f) * rcp); };
     if (chunk_begin < chunk_end) {
 #pragma unroll
-        for (int j = 0; j < APW; ++j) issue_a(j, chunk_begin, 0);
+        for (int s_ = 0; s_ < NSW; ++s_) issue_w(chunk_begin, s_, s_);
+        const float rpw = 1.0f / (float)PW, rh1 = 1.0f / (float)(H + 1);
 #pragma unroll
-        for (int s = 0; s < NSW; ++s) issue_w(chunk_begin, s, s);
-        wait_vmcnt<(NSW - 1) * GW>();
+        for (int j = 0; j < APW; ++j) {
+            const int q = (wave + NW * j) * 8 + st_row;
+            const int srow = divf(q, rpw), scol = q - srow * PW;
+            const int v = v0 - 1 + srow;
+            const int vb = v >= 0 ? divf(v, rh1) : 0, vy = v - vb * (H + 1);
+            const int xx = x0 - 1 + scol;
+            const bool ok = (srow < PR) & (v >= 0) & (vy < H) & (vb < p.batch) & (xx >= 0) & (xx < W);
+            ppix[j] = ok ? (unsigned)((vb * H + vy) * W + xx) : DMA_OOB;
+            // The halo / separator entries are the same LDS slots for every chunk and each 16-byte slot is only ever
+            // written by its own lane: zero them once, so the halo does not depend on whether the hardware writes zeros
+            // for an out-of-range LDS-DMA lane or skips the lane
+            if (!ok) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+                unsigned char* d = lds + OFF_A + (wave + NW * j) * (8 * BK * 2) + lane * 16;
+                *(u32x4*)d = z;
+                *(u32x4*)(d + PBUF) = z;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < APW; ++j) issue_a(j, chunk_begin, 0);
+        wait_vmcnt<0>();
         barrier_keep_dma();
         read_a0(0, 0, afA);
         read_w(0, 0, wfA);
@@ -247,6 +269,13 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             const int dnext = ((tap + 1) % 9 / 3) * PW + (tap + 1) % 9 % 3;      // patch offset of the next step's tap
             read_a1(pb, afB);
             read_w(slot, 1, wfB);
+            // byte offsets of the NEXT step's activation fragments: VALU work placed beside the MFMAs of set A, so the reads
+            // themselves can go out right behind the barrier
+#pragma unroll
+            for (int q = 0; q < FM; ++q) {
+                const int Pq = abase[q] + dnext;
+                aoff[q] = (Pq << 7) + ((fg ^ (Pq & 7)) << 4);
+            }
             lds_wait<FM + FN>();
             landed(afA, wfA);
             mma(afA, wfA);
@@ -254,12 +283,38 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             wait_vmcnt<younger>();            // weight tile t + 1 (and, at tap 8, the next chunk's patch) landed
             barrier_keep_dma();               // ... for every wave; all waves are done with slot `slot` (completes set B)
             landed(afB, wfB);
-            if constexpr (tap < APW) issue_a(tap, c + 1, pb ^ 1);
-            issue_w(c + cn, tn, slot);
+            // second half step: the MFMAs of set B with this step's DMA pieces and the next step's first fragment reads
+            // PINNED between them -- after the barrier both waves of a SIMD are at the same point, and three back-to-back
+            // DMA issues (~60-100 cycles each) ahead of the first MFMA leave the matrix pipe idle for both
             const int snext = slot + 1 == NSW ? 0 : slot + 1;
-            read_a0(tap == 8 ? pb ^ 1 : pb, dnext, afA);
-            read_w(snext, 0, wfA);
-            mma(afB, wfB);
+            const int pbn = tap == 8 ? pb ^ 1 : pb;
+            constexpr int ND = GW + (tap < APW ? 1 : 0), NACT = ND + 2, P = FM * FN;
+            constexpr int SP = P / (NACT + 1) > 0 ? P / (NACT + 1) : 1;
+            const unsigned char* abuf = lds + OFF_A + pbn * PBUF;
+            const unsigned char* wbuf = lds + snext * WTILE + wl0;
+#pragma unroll
+            for (int m = 0; m < P; ++m) {
+                const int i = m / FN, j = m % FN;
+                acc[i][j] = mfma16(wfB[j], afB[i], acc[i][j]);
+                if ((m + 1) % SP == 0 && (m + 1) / SP <= NACT) {
+                    const int a = (m + 1) / SP - 1;          // action index: R0 R1 D0 D1 [D2 ..]: reads as early as possible
+                    sched_fence();
+                    if (a == 0) {                            // activation fragments of the next step (ks = 0)
+#pragma unroll
+                        for (int q = 0; q < FM; ++q) afA[q] = lds_read16_async(abuf + aoff[q]);
+                    } else if (a == 1) {                     // weight fragments of the next step (ks = 0)
+#pragma unroll
+                        for (int q = 0; q < FN; ++q) wfA[q] = lds_read16_async(wbuf + q * (16 * BK * 2));
+                    } else {
+                        const int d = a - 2;                 // DMA piece
+                        if (d < ND) {
+                            if (tap < APW && d == 0) issue_a(tap, c + 1, pb ^ 1);
+                            else issue_w1(c + cn, tn, slot, d - (tap < APW ? 1 : 0));
+                        }
+                    }
+                    sched_fence();
+                }
+            }
             sched_fence();
             slot = snext;
         };
@@ -278,33 +333,50 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     }
     wait_vmcnt<0>();                          // the out-of-range DMAs issued past the end of the K range
 
-    // ---- epilogue through LDS: accumulators (lane = one pixel x 4 consecutive n) staged as fp32, 64 tile rows at a
-    // time, so bias / residual reads and the bf16 (or fp32 partial) stores move whole 16-byte row segments
+    // ---- epilogue through LDS: accumulators (lane = one pixel x 4 consecutive n) staged as fp32 -- the whole tile at
+    // once where it fits (RR rows per round) -- so bias / residual reads and the bf16 (or fp32 partial) stores move whole
+    // 16-byte row segments.  Every thread owns ITEMS (row, 8-column) items of a round; their residual loads are all
+    // issued before the first is used (one exposed global latency per round, not one per item).
     constexpr int SROW = Cf::SROW, NC8 = BN / 8;
+    constexpr int RR = BM * SROW * 4 <= Cf::LDS_BYTES ? BM : ((BM / 2) * SROW * 4 <= Cf::LDS_BYTES ? BM / 2 : 64);
+    constexpr int ITEMS = RR * NC8 / NT;
+    static_assert(RR * NC8 % NT == 0 && RR % WM == 0, "epilogue items must divide evenly over the threads");
     float* stg = (float*)lds;
     bf16_t* cp = (bf16_t*)p.c;
     const bf16_t* res = (const bf16_t*)p.residual;
     float* wsp = rt.split_k > 1 ? rt.ws + (int64_t)split * M * N : nullptr;
 #pragma unroll
-    for (int h = 0; h < BM / 64; ++h) {
+    for (int h = 0; h < BM / RR; ++h) {
         barrier_keep_dma();
-        if ((wave_m * WM) / 64 == h) {
+        if ((wave_m * WM) / RR == h) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int rl = (wave_m * WM) % 64 + i * 16 + fr;
+                const int rl = (wave_m * WM) % RR + i * 16 + fr;
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     *(f32x4*)(stg + rl * SROW + wave_n * WN + j * 16 + 4 * fg) = acc[i][j];
             }
         }
         barrier_keep_dma();
-        for (int e = tid; e < 64 * NC8; e += NT) {
+        int mrow[ITEMS];             // output row m of item `it`, or -1
+        u32x4 rres[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int e = tid + it * NT;
             const int rl = e / NC8, cc = e - rl * NC8;
-            const int r = h * 64 + rl;
+            const int r = h * RR + rl;
             const int g = g0 + (r >> TWl), xx = x0 + (r & (TW - 1));
             const int n = n0 + cc * 8;
-            if (g >= GROWS || xx >= W || n >= N) continue;
-            const int m = g * W + xx;
+            mrow[it] = (g < GROWS && xx < W && n < N) ? g * W + xx : -1;
+            rres[it] = u32x4{0u, 0u, 0u, 0u};
+            if (res && !wsp && mrow[it] >= 0) rres[it] = *(const u32x4*)(res + (int64_t)mrow[it] * p.ldr + n);
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int e = tid + it * NT;
+            const int rl = e / NC8, cc = e - rl * NC8;
+            const int n = n0 + cc * 8, m = mrow[it];
+            if (m < 0) continue;
             const f32x4 v0_ = *(const f32x4*)(stg + rl * SROW + cc * 8);
             const f32x4 v1_ = *(const f32x4*)(stg + rl * SROW + cc * 8 + 4);
             float v[8] = {v0_[0], v0_[1], v0_[2], v0_[3], v1_[0], v1_[1], v1_[2], v1_[3]};
@@ -325,7 +397,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
                 for (int q = 0; q < 4; ++q) { v[q] += b0[q]; v[4 + q] += b1[q]; }
             }
             if (res) {
-                const u32x4 rr = *(const u32x4*)(res + (int64_t)m * p.ldr + n);
+                const u32x4 rr = rres[it];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     v[2 * q] += bf2f((bf16_t)(rr[q] & 0xffffu));
@@ -382,6 +454,7 @@ int launch_patch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s,
     const int64_t e0 = ((pixels - 1) * a.lda0 + c0) * 2, e1 = a.a1 ? ((pixels - 1) * a.lda1 + c1) * 2 : 0;
     const int64_t ew = ((int64_t)(a.n - 1) * a.ldw + a.k) * 2;
     if (e0 >= (1ll << 31) || e1 >= (1ll << 31) || ew >= (1ll << 31)) return 1;
+    if ((int64_t)a.batch * (a.h_out + 1) >= (1 << 18)) return 1;      // exact float-reciprocal divisions in the kernel
     PatchRt rt{tn, g.tiles_x, g.tiles_g, split_k, g.tw_log2, (unsigned)e0, (unsigned)e1, (unsigned)ew, ws};
     dim3 grid((unsigned)(g.tiles_g * g.tiles_x * tn), (unsigned)split_k);
     if (describe) {
@@ -401,14 +474,18 @@ int launch_patch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s,
     hipLaunchKernelGGL((conv_patch_kernel<BM, BN, NSW>), grid, dim3(512), Cf::LDS_BYTES, s, a, rt);
     return 0;
 }
+
+bool patch_applicable(const leco_gemm_args& a) {
+    if (a.a_mode != LECO_A_CONV3_S1 || a.a_ext || a.t_w || a.act == LECO_ACT_GEGLU) return false;
+    return a.h_in == a.h_out && a.w_in == a.w_out;
+}
 }  // namespace
 
 // 0: launched (or described); 1: this problem / variant cannot take the patch path (the caller falls back to the
 // implicit-GEMM kernel); < 0: error.  variant: 7 = 256 x 128, 8 = 128 x 160, 9 = 128 x 128, 10 = 256 x 160.
 int conv_patch_try(const leco_gemm_args& a, int variant, int split_k, float* ws, hipStream_t s, char* describe,
                    int describe_len) {
-    if (a.a_mode != LECO_A_CONV3_S1 || a.a_ext || a.t_w || a.act == LECO_ACT_GEGLU) return 1;
-    if (a.h_in != a.h_out || a.w_in != a.w_out) return 1;
+    if (!patch_applicable(a)) return 1;
     const int nchunks = a.k / 9 / BK;
     if (split_k > nchunks) split_k = nchunks;
     if (split_k < 1) split_k = 1;
@@ -419,5 +496,37 @@ int conv_patch_try(const leco_gemm_args& a, int variant, int split_k, float* ws,
         case 10: return launch_patch<256, 160, 3>(a, split_k, ws, s, describe, describe_len);
         default: return 1;
     }
+}
+
+// Launch shape for a 3x3 / stride-1 convolution without a tuner-table entry: every (variant, split_k) is priced with
+// a small model fitted to MI355X measurements (profiles/r03_conv_patch.txt) and the cheapest wins:
+//   one workgroup = ~5 us of prologue + epilogue + 9 * ceil(chunks / split) tap steps of 0.33 / 0.49 / 0.70 / 0.93 us
+//   (128x128, 128x160, 256x128, 256x160: MFMA issue + the LDS traffic of the fragment reads), rounds = ceil(workgroups /
+//   256 CUs); split-K adds the finishing launch (~3 us) and the fp32 slabs' write + read at ~4 TB/s.
+// Returns the tile id (7..10) and sets *split, or 0 when the patch path does not apply.
+int conv_patch_choose(const leco_gemm_args& a, int64_t ws_bytes, int split_in, int* split) {
+    if (!patch_applicable(a)) return 0;
+    struct V { int id, bm, bn, pcap; double step_us; };
+    const V vs[4] = {{9, 128, 128, PatchCfg<128, 128, 4>::PCAP, 0.33}, {8, 128, 160, PatchCfg<128, 160, 4>::PCAP, 0.49},
+                     {7, 256, 128, PatchCfg<256, 128, 4>::PCAP, 0.70}, {10, 256, 160, PatchCfg<256, 160, 3>::PCAP, 0.93}};
+    const int nchunks = a.k / 9 / BK;
+    const int splits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+    double best = 1e30;
+    int best_id = 0;
+    *split = 1;
+    for (const V& v : vs) {
+        const PatchGeom g = patch_geometry(a, v.bm, v.pcap);
+        if (!g.fits) continue;
+        const long wgs1 = (long)g.tiles_g * g.tiles_x * cdiv(a.n, v.bn);
+        for (int sp : splits) {
+            if (split_in > 0 && sp != split_in) continue;
+            if (sp > nchunks || (sp > 1 && (int64_t)sp * a.m * a.n * 4 > ws_bytes)) continue;
+            const long rounds = (wgs1 * sp + 255) / 256;
+            double us = rounds * (5.0 + 9.0 * cdiv(nchunks, sp) * v.step_us);
+            if (sp > 1) us += 3.0 + 2.0 * sp * (double)a.m * a.n * 4.0 / 4.0e6;
+            if (us < best) { best = us; best_id = v.id; *split = sp; }
+        }
+    }
+    return best_id;
 }
 }  // namespace leco

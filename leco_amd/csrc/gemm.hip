@@ -718,7 +718,7 @@ void splitk_finish_launch(const leco_gemm_args& a, const float* ws, int splits, 
 }
 }  // namespace leco
 
-// tile: 0 = heuristic, 1 = 128x128 (wave shape by grid size), 2 = 128x160, 3 = 64x64, 4 = 256x128, 5 = 128x128 as
+// tile: 0 = heuristic (-1: heuristic restricted to the implicit-GEMM kernel), 1 = 128x128 (wave shape by grid size), 2 = 128x160, 3 = 64x64, 4 = 256x128, 5 = 128x128 as
 // 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU; 7..10 = the patch-staged 3x3 / stride-1
 // convolution (conv_patch.hip) on 256x128 / 128x160 / 128x128 / 256x160 tiles -- problems it does not cover (other
 // gathers, a LoRA K-extension, a patch that does not fit) fall back to the heuristic.  split_k: 0 = heuristic (needs a
@@ -738,7 +738,14 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         if (tile == 0) tile = 1;
         split_k = 1;
     }
-    if (tile == 0) {
+    static const bool no_patch = getenv("LECO_NO_CONV_PATCH") != nullptr;      // A/B switch for measurements
+    if (tile == 0 && args->a_mode == LECO_A_CONV3_S1 && !no_patch) {
+        // 3x3 / stride-1 convolutions: the patch-staged kernel (conv_patch.hip) with the launch shape of its cost model
+        int sp = 1;
+        const int t = conv_patch_choose(*args, workspace ? workspace_bytes : 0, split_k, &sp);
+        if (t) { tile = t; split_k = sp; }
+    }
+    if (tile <= 0) {      // (-1: the implicit-GEMM heuristic, whatever the gather)
         if (n <= 64 || m <= 64) tile = 3;
         else {
             const int bn = (n % 128 == 0) ? 128 : ((n % 160 == 0) ? 160 : 128);
@@ -799,7 +806,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
     }
     if (tile >= 7 && tile <= 10) {
         rc = conv_patch_try(*args, tile, split_k, (float*)workspace, s, tl_describe, tl_describe_len);
-        if (rc == 1) return leco_gemm_ex(args, 0, 0, workspace, workspace_bytes, stream);
+        if (rc == 1) return leco_gemm_ex(args, -1, 0, workspace, workspace_bytes, stream);
         if (rc < 0 || tl_describe) return rc;
         const int nchunks = args->k / 9 / BK;
         if (split_k > 1) splitk_finish_launch(*args, (const float*)workspace, split_k < nchunks ? split_k : nchunks, s);

@@ -44,12 +44,15 @@ def table() -> Dict[str, list]:
     return _table
 
 
-def shape_key(g: GemmArgs) -> str:
+def shape_key(g: GemmArgs, has_ws: bool = True) -> str:
+    """Everything the best launch shape depends on, including whether the call site supplies a split-K workspace (the
+    same contraction appears with and without one; a table entry with split > 1 must not be applied to the latter)."""
     conv = f"c{g.batch}x{g.h_out}x{g.w_out}<{g.h_in}x{g.w_in}" if g.a_mode else ""
     ext = g.ext_k if (g.a_ext or g.t_w) else 0
     return (f"m{g.m}n{g.n}k{g.k}a{g.a_mode}{conv}"
             f"{'s' if g.a1 else ''}e{ext}{'T%d' % g.t_rows if g.t_w else ''}{'o' if g.t_out else ''}"
-            f"{'r' if g.residual else ''}{'b' if g.bias else ''}{'B' if g.rowbias else ''}A{g.act}{'f' if g.c_f32 else ''}")
+            f"{'r' if g.residual else ''}{'b' if g.bias else ''}{'B' if g.rowbias else ''}A{g.act}{'f' if g.c_f32 else ''}"
+            f"{'' if has_ws else 'W0'}")
 
 
 def candidates(g: GemmArgs, has_ws: bool):
@@ -58,6 +61,16 @@ def candidates(g: GemmArgs, has_ws: bool):
     geglu = g.act == hip.ACT_GEGLU
     tiles = [1, 4, 5, 6] if geglu else [1, 2, 3, 4] + ([5, 6] if plain else [])
     out = [(0, 0)]                                   # the C heuristic itself
+    if g.a_mode == hip.A_CONV3_S1 and not (g.a_ext or g.t_w):
+        # patch-staged kernel (conv_patch.hip): tile ids 7..10; K splits are whole 64-channel chunks
+        chunks = g.k // 9 // 64
+        for t, (bm, bn) in {7: (256, 128), 8: (128, 160), 9: (128, 128), 10: (256, 160)}.items():
+            if bn == 160 and g.n % 160:
+                continue
+            blocks = -(-g.m // bm) * -(-g.n // bn)
+            out.append((t, 1))
+            if has_ws and blocks < 256:
+                out += [(t, sp) for sp in (2, 3, 4, 5, 6, 8, 10, 12, 16) if blocks * sp <= 768 and sp <= chunks]
     for t in tiles:
         bm, bn = {1: (128, 128), 2: (128, 160), 3: (64, 64), 4: (256, 128), 5: (128, 128), 6: (128, 128)}[t]
         blocks = -(-g.m // bm) * -(-g.n // bn)
@@ -93,7 +106,7 @@ def choose(g: GemmArgs, ws: Optional[torch.Tensor]) -> Tuple[int, int]:
     m = mode()
     if m == "0" or hip.is_emulated() or not torch.cuda.is_available():
         return 0, 0
-    key = shape_key(g)
+    key = shape_key(g, ws is not None)
     if m != "force":
         hit = table().get(key) or (_measured.get(key, {}).get("best"))
         if hit:
@@ -102,6 +115,8 @@ def choose(g: GemmArgs, ws: Optional[torch.Tensor]) -> Tuple[int, int]:
             return 0, 0
     elif key in _measured:
         return _measured[key]["best"]
+    if g.residual and g.residual == g.c:             # in-place accumulation (chained LoRA slices): repeated timing launches
+        return 0, 0                                  # would compound garbage on a live plan buffer -- not worth tuning
     fn = hip.lib().leco_gemm_ex
     stream = torch.cuda.current_stream().cuda_stream
     ws_ptr = ws.data_ptr() if ws is not None else None
@@ -113,6 +128,9 @@ def choose(g: GemmArgs, ws: Optional[torch.Tensor]) -> Tuple[int, int]:
         t = _time(fn, C.byref(g), tile, split, ws_ptr, ws_bytes, stream, iters)
         if t is not None:
             times[(tile, split)] = t
+    if not times:                                    # every candidate launch failed: leave it to the C side to report
+        _measured[key] = {"best": (0, 0), "times": {}}
+        return 0, 0
     base = times.get((0, 0))
     best = min(times, key=times.get)
     if base is not None and times[best] > 0.97 * base:      # within noise of the heuristic: keep the heuristic

@@ -273,8 +273,9 @@ def test_conv3x3_patch_staged(dev, tile, B, H, W_, Ci, Co, ks, split):
         x1h = x[:, ks:].permute(0, 2, 3, 1).contiguous().to(dev)
         kw = dict(lda=ks, a1=x1h, lda1=Ci - ks, k_split=ks)
         xh = x0h
+    bias_d, rowb_d = bias.to(dev), rowb.to(dev)      # (the argument block only holds raw pointers: keep them alive)
     g = hip.gemm_args(xh, wh, out, m=M, n=Co, k=9 * Ci, a_mode=hip.A_CONV3_S1, conv=(B, H, W_, H, W_), out_f32=o32,
-                      bias=bias.to(dev), rowbias=rowb.to(dev), rows_per_group=H * W_, residual=resh, act=hip.ACT_SILU,
+                      bias=bias_d, rowbias=rowb_d, rows_per_group=H * W_, residual=resh, act=hip.ACT_SILU,
                       **{"lda": Ci, **kw})
     desc = hip.gemm_describe(g, tile, split, None, 0)
     assert "conv_patch_kernel" in desc, desc

@@ -22,10 +22,15 @@ def test_describe_names_the_instantiation_the_dispatcher_would_launch():
     hip._use_library(hip.LIB_PATH) if os.path.exists(hip.LIB_PATH) else None
     ws = torch.zeros(32 * 1024 * 1024 // 4)
     wsp, wsb = ws.data_ptr(), ws.numel() * 4
-    assert hip.gemm_describe(_args(16384, 320, 2880, a_mode=hip.A_CONV3_S1, conv=(4, 64, 64, 64, 64)), 0, 0, wsp, wsb) \
-        .startswith("gemm_kernel<128, 160, true, 4, 4, 0> grid=256 split=1")
-    # deep K, small M: 256x128 tile, split over K so that one round fills the chip
+    # 3x3 / stride-1 convolutions: the patch-staged kernel, launch shape from its cost model -- the level-0 conv fills the
+    # chip in one round of 128x160 tiles; deep K / small M is split over whole channel chunks
+    g0 = _args(16384, 320, 2880, a_mode=hip.A_CONV3_S1, conv=(4, 64, 64, 64, 64))
+    assert hip.gemm_describe(g0, 0, 0, wsp, wsb) == "conv_patch_kernel<128, 160, 4> grid=256 split=1"
     d = hip.gemm_describe(_args(1024, 1280, 11520, a_mode=hip.A_CONV3_S1, conv=(4, 16, 16, 16, 16)), 0, 0, wsp, wsb)
+    assert d.startswith("conv_patch_kernel<128, 128, 4> grid=80 split=3"), d
+    # tile = -1 pins the implicit-GEMM family (what other gathers, and LoRA-carrying convs, run)
+    assert hip.gemm_describe(g0, -1, 0, wsp, wsb).startswith("gemm_kernel<128, 160, true, 4, 4, 0> grid=256 split=1")
+    d = hip.gemm_describe(_args(1024, 1280, 11520, a_mode=hip.A_CONV3_S1, conv=(4, 16, 16, 16, 16)), -1, 0, wsp, wsb)
     assert d.startswith("gemm_kernel<256, 128, true, 3, 4, 0>") and "split=6" in d
     # large plain 128x128 grids run as 4-wave workgroups (two per CU); explicit tile ids pin either form
     g = _args(16384, 2560, 320)
@@ -45,10 +50,12 @@ def test_tuner_keys_candidates_and_table():
     assert key == "m4096n640k5760a1c4x32x32<32x32e0rbA0"
     cands = tune.candidates(g, has_ws=True)
     assert (0, 0) in cands and (2, 2) in cands and (4, 1) in cands and all(t != 6 for t, _ in cands)   # 6: plain only
+    assert (7, 1) in cands and (8, 2) in cands and (9, 4) in cands                                     # patch-staged variants
+    assert tune.shape_key(g, has_ws=False) == key + "W0"
     geglu = _args(16384, 2560, 320, act=hip.ACT_GEGLU)
     assert {t for t, _ in tune.candidates(geglu, has_ws=True)} == {0, 1, 4, 5, 6}                     # 128-column tiles
     tab = json.load(open(tune.TABLE_PATH))
-    assert tab[key] in ([2, 2], [2, 4], [2, 1]) and len(tab) > 100
+    assert len(tab) > 100 and all(len(v) == 2 for v in tab.values())
     # without a GPU (or on the emulator) the tuner never measures and defers to the C heuristic
     assert tune.choose(g, None) == (0, 0)
 
