@@ -64,7 +64,7 @@ struct PatchCfg {
     static constexpr int OFF_A = NSW * WTILE, OFF_DUMP = OFF_A + 2 * PBUF;
     static constexpr int LDS_BYTES = OFF_DUMP + (RAGW ? 1024 : 0);
     static constexpr int SROW = BN + 4;                    // epilogue staging row (fp32)
-    static_assert(APW <= 10 - NSW, "the next chunk's patch must be covered by the wait of tap 8");
+    static_assert(APW <= 11 - NSW, "the next chunk's patch must be covered by the wait of tap 8");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS layout does not fit");
     static_assert(64 * SROW * 4 <= LDS_BYTES, "epilogue staging does not fit");
 };
@@ -213,14 +213,14 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
     };
 
-    // ---- prologue: weight tiles of steps 0 .. NSW - 1 first (their addresses are cheap), then -- while those fly --
+    // ---- prologue: weight tiles of steps 0 .. NSW - 2 first (their addresses are cheap), then -- while those fly --
     // the patch loader table, then the patch of the first chunk.  Small-operand integer divisions go through an exact
     // float reciprocal (operands < 2^18, validated on the host): a 32-bit division is ~40 instructions, and the table
     // needs 2 APW of them per lane.
     auto divf = [](int a, float rcp) { return (int)(((float)a + 0.5f) * rcp); };
     if (chunk_begin < chunk_end) {
 #pragma unroll
-        for (int s_ = 0; s_ < NSW; ++s_) issue_w(chunk_begin, s_, s_);
+        for (int s_ = 0; s_ < NSW - 1; ++s_) issue_w(chunk_begin, s_, s_);
         const float rpw = 1.0f / (float)PW, rh1 = 1.0f / (float)(H + 1);
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
@@ -256,20 +256,40 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
         // fragments (x 2 patch buffers) out of the loop and spills; recomputing them costs 5 VALU per read beside 2 FN MFMAs
 #pragma unroll
         for (int i = 0; i < FM; ++i) opaque(abase[i]);
-        // one tap step; everything that depends on `tap` is a compile-time constant
+        // One tap step; everything that depends on `tap` is a compile-time constant.  Step t consumes weight tile t and
+        // issues tile t + NSW - 1 into the slot tile t - 1 vacated at the PREVIOUS step's barrier, so its DMA pieces may go
+        // out anywhere in the step.  They are spread evenly over the step's 2 FM FN MFMAs: a vector-memory instruction
+        // occupies its wave for ~100-150 cycles (MI355X probe: ~14 GB/s of LDS-DMA per wave whatever the depth), and the two
+        // waves of a SIMD run this stream in lockstep behind the barrier -- back-to-back pieces stall both, the matrix pipe idles.
         auto step = [&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
-            constexpr int tn = (tap + NSW) % 9, cn = (tap + NSW) / 9;            // the weight tile this step refills with
-            // DMAs younger than weight tile t + 1 at this step's wait: everything issued in steps t - (NSW - 2) .. t - 1
-            constexpr int younger = [] {
-                int n = 0;
-                for (int d = 1; d <= NSW - 2; ++d) n += GW + ((((tap - d) % 9 + 9) % 9) < APW ? 1 : 0);
+            constexpr int D = NSW - 1;
+            constexpr int tn = (tap + D) % 9, cn = (tap + D) / 9;                // the weight tile this step issues
+            constexpr int ND = GW + (tap < APW ? 1 : 0), P = FM * FN;
+            // MFMA index (0 .. 2P - 1) AFTER which piece d is issued
+            // (never in the last MFMAs before the barrier, where its issue time would delay the wave's arrival)
+            constexpr auto dpos = [](int d, int nd) {
+                const int x = ((2 * d + 1) * 2 * P) / (2 * nd) - 1;
+                return (x >= P - 4 && x <= P + 1) ? P + 2 : x;
+            };
+            // pieces of this step issued before the barrier (which sits after MFMA P - 1)
+            constexpr auto npre = [dpos](int nd) { int n = 0; for (int d = 0; d < nd; ++d) n += dpos(d, nd) < P ? 1 : 0; return n; };
+            // DMAs younger than weight tile t + 1 (issued in step t + 1 - D) at this step's wait: steps t + 2 - D .. t - 1 in
+            // full, and this step's pre-barrier pieces
+            constexpr int younger = [npre] {
+                int n = npre(ND);
+                for (int d = 1; d <= D - 2; ++d) n += GW + ((((tap - d) % 9 + 9) % 9) < APW ? 1 : 0);
                 return n;
             }();
             const int dnext = ((tap + 1) % 9 / 3) * PW + (tap + 1) % 9 % 3;      // patch offset of the next step's tap
+            const int sfill = slot == 0 ? NSW - 1 : slot - 1;                    // slot of tile t - 1 = of tile t + NSW - 1
+            const int snext = slot + 1 == NSW ? 0 : slot + 1;
+            const int pbn = tap == 8 ? pb ^ 1 : pb;
+            const unsigned char* abuf = lds + OFF_A + pbn * PBUF;
+            const unsigned char* wbuf = lds + snext * WTILE + wl0;
             read_a1(pb, afB);
             read_w(slot, 1, wfB);
-            // byte offsets of the NEXT step's activation fragments: VALU work placed beside the MFMAs of set A, so the reads
+            // byte offsets of the NEXT step's activation fragments: VALU work beside the MFMAs of set A, so that the reads
             // themselves can go out right behind the barrier
 #pragma unroll
             for (int q = 0; q < FM; ++q) {
@@ -278,42 +298,31 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             }
             lds_wait<FM + FN>();
             landed(afA, wfA);
-            mma(afA, wfA);
-            sched_fence();
-            wait_vmcnt<younger>();            // weight tile t + 1 (and, at tap 8, the next chunk's patch) landed
-            barrier_keep_dma();               // ... for every wave; all waves are done with slot `slot` (completes set B)
-            landed(afB, wfB);
-            // second half step: the MFMAs of set B with this step's DMA pieces and the next step's first fragment reads
-            // PINNED between them -- after the barrier both waves of a SIMD are at the same point, and three back-to-back
-            // DMA issues (~60-100 cycles each) ahead of the first MFMA leave the matrix pipe idle for both
-            const int snext = slot + 1 == NSW ? 0 : slot + 1;
-            const int pbn = tap == 8 ? pb ^ 1 : pb;
-            constexpr int ND = GW + (tap < APW ? 1 : 0), NACT = ND + 2, P = FM * FN;
-            constexpr int SP = P / (NACT + 1) > 0 ? P / (NACT + 1) : 1;
-            const unsigned char* abuf = lds + OFF_A + pbn * PBUF;
-            const unsigned char* wbuf = lds + snext * WTILE + wl0;
 #pragma unroll
-            for (int m = 0; m < P; ++m) {
-                const int i = m / FN, j = m % FN;
-                acc[i][j] = mfma16(wfB[j], afB[i], acc[i][j]);
-                if ((m + 1) % SP == 0 && (m + 1) / SP <= NACT) {
-                    const int a = (m + 1) / SP - 1;          // action index: R0 R1 D0 D1 [D2 ..]: reads as early as possible
+            for (int m = 0; m < 2 * P; ++m) {
+                const int mm = m < P ? m : m - P, i = mm / FN, j = mm % FN;
+                if (m == P) {
                     sched_fence();
-                    if (a == 0) {                            // activation fragments of the next step (ks = 0)
+                    wait_vmcnt<younger>();    // weight tile t + 1 (and, at tap 8, the next chunk's patch) landed
+                    barrier_keep_dma();       // ... for every wave; all waves are done with tile t's slot (completes set B)
+                    landed(afB, wfB);
+                    // first fragment reads of the next step (ks = 0) right behind the barrier
 #pragma unroll
-                        for (int q = 0; q < FM; ++q) afA[q] = lds_read16_async(abuf + aoff[q]);
-                    } else if (a == 1) {                     // weight fragments of the next step (ks = 0)
+                    for (int q = 0; q < FM; ++q) afA[q] = lds_read16_async(abuf + aoff[q]);
 #pragma unroll
-                        for (int q = 0; q < FN; ++q) wfA[q] = lds_read16_async(wbuf + q * (16 * BK * 2));
-                    } else {
-                        const int d = a - 2;                 // DMA piece
-                        if (d < ND) {
-                            if (tap < APW && d == 0) issue_a(tap, c + 1, pb ^ 1);
-                            else issue_w1(c + cn, tn, slot, d - (tap < APW ? 1 : 0));
-                        }
-                    }
+                    for (int q = 0; q < FN; ++q) wfA[q] = lds_read16_async(wbuf + q * (16 * BK * 2));
                     sched_fence();
                 }
+                if (m < P) acc[i][j] = mfma16(wfA[j], afA[i], acc[i][j]);
+                else acc[i][j] = mfma16(wfB[j], afB[i], acc[i][j]);
+#pragma unroll
+                for (int d = 0; d < ND; ++d)
+                    if (dpos(d, ND) == m) {
+                        sched_fence();
+                        if (tap < APW && d == 0) issue_a(tap, c + 1, pb ^ 1);
+                        else issue_w1(c + cn, tn, sfill, d - (tap < APW ? 1 : 0));
+                        sched_fence();
+                    }
             }
             sched_fence();
             slot = snext;
