@@ -37,7 +37,7 @@ def step_flops(bs: int, k: int, arch: str = "sd15", res: int = 512) -> float:
     return 2 * bs * f * (k + 5 + a)
 
 
-def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 210.0):
+def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 900.0):
     """The reference loop on the host CPU (BASELINE.json configs[0]: SD1.5, rank 4, 512^2, prompt batch 1, fp32,
     DDIM, AdamW), as a port: `oracle/step_ref.leco_step` restates one iteration of train_lora.py:141-281 on the
     oracle UNet / DDIM / LoRA (the reference's own files need `diffusers` and do not exist on the GPU box), followed
@@ -71,7 +71,8 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 210.0):
     times, losses = [], []
     t_all = time.perf_counter()
     for i, k in enumerate(ks):
-        if times and time.perf_counter() - t_all + times[-1] * 1.3 > budget_s:
+        # ALWAYS at least two full steps (the first still pays allocator / autograd warm-up); further ones only inside the budget
+        if len(times) >= 2 and time.perf_counter() - t_all + times[-1] * 1.3 > budget_s:
             break
         lat = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(1000 + i))
         t0 = time.perf_counter()
@@ -90,11 +91,14 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 210.0):
     b = times[-1] / (ks[len(times) - 1] + 5 + ATTN_SHARE)
     a = b * (5 + ATTN_SHARE)
     how = f"W_ref(k): {b:.1f} s per forward-equivalent from the last step"
-    t_step = bs * (a + b * k_mean)
+    t_bs1 = a + b * k_mean
+    t_step = bs * t_bs1
     return {"value": 1.0 / t_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{len(times)} full fp32 optimizer steps of the ported reference loop at prompt batch 1 with k = "
-                      f"{list(ks[:len(times)])}: {', '.join(f'{t:.1f} s' for t in times)}; evaluated at k = {k_mean:.1f} "
-                      f"and prompt batch {bs} ({how})",
+                      f"{list(ks[:len(times)])}: {', '.join(f'{t:.1f} s' for t in times)}; the LAST one, evaluated at k = "
+                      f"{k_mean:.1f} ({how}); prompt batch {bs} is ASSUMED to cost {bs}x prompt batch 1 (not measured: the "
+                      f"CPU has no idle lanes to fill) -- value_prompt_batch_1 is the measured-batch figure",
+            "value_prompt_batch_1": 1.0 / t_bs1,
             "steps_timed": len(times), "k": list(ks[:len(times)]), "step_seconds": times,
             "host_cpus": os.cpu_count(), "threads": torch.get_num_threads()}
 
@@ -102,9 +106,45 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 210.0):
 # ---------------------------------------------------------------------------------------------------------------
 # dominant kernel: found LIVE (every distinct launch of a step timed with HIP events on the compute stream, weighted by how
 # often the step issues it), cross-checked against the top row of the committed rocprofv3 kernel trace
-PROFILE_STATS = os.path.join(ROOT, "profiles", "r02_step_kernel_stats.txt")
-PMC_FETCH = os.path.join(ROOT, "profiles", "r02_pmc_dominant_fetch.csv")
-PMC_MFMA = os.path.join(ROOT, "profiles", "r02_pmc_dominant_mfma.csv")
+def _latest(suffix):
+    """profiles/rNN_<suffix> of the newest round that has one."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
+    return hits[-1] if hits else os.path.join(ROOT, "profiles", "r00_" + suffix)
+
+
+PROFILE_STATS = _latest("step_kernel_stats.txt")
+PMC_FETCH = _latest("pmc_dominant_fetch.csv")
+PMC_MFMA = _latest("pmc_dominant_mfma.csv")
+
+
+def kernel_sources_hash():
+    """sha1 over the kernel sources (leco_amd/csrc): counter summaries carry it in their header (tools/pmc_summary.py),
+    and numbers from a summary whose hash differs from the tree's are NOT printed -- they describe other kernels."""
+    import hashlib
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "leco_amd", "csrc")
+    for dp, _, files in sorted(os.walk(csrc)):
+        if os.path.basename(dp) == "_obj":
+            continue
+        for f in sorted(files):
+            if f.endswith((".hip", ".h", ".cpp")):
+                with open(os.path.join(dp, f), "rb") as fh:
+                    h.update(f.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:12]
+
+
+def _summary_hash(path):
+    try:
+        with open(path) as fh:
+            for line in fh:
+                if not line.startswith("#"):
+                    break
+                if "csrc_sha1=" in line:
+                    return line.split("csrc_sha1=")[1].split()[0]
+    except OSError:
+        pass
+    return None
 
 
 def _launch_identity(op):
@@ -151,7 +191,7 @@ def _profile_top_row():
 
 def _pmc_row(path, name):
     try:
-        lines = open(path).read().splitlines()
+        lines = [l for l in open(path).read().splitlines() if not l.startswith("#")]
         hdr = lines[0].split(",")
         for line in lines[1:]:
             if line.startswith(name + ","):
@@ -213,15 +253,24 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False):
                               "tflops": heavy[1][2] / heavy[1][1] / 1e6 if heavy[1][1] else 0.0},
            "profile_top_row": top,
            "agrees_with_profile": bool(top and top["name"] == name)}
-    fetch, mfma = _pmc_row(PMC_FETCH, name), _pmc_row(PMC_MFMA, name)
+    # counter passes are separate rocprofv3 runs (tools/gpu_round_run.sh); their summaries are only quoted when they were
+    # taken on THESE kernel sources (hash in the header) and every number names the file it comes from
+    cur = kernel_sources_hash()
+    out["kernel_sources"] = cur
+    fetch = _pmc_row(PMC_FETCH, name) if _summary_hash(PMC_FETCH) == cur else None
+    mfma = _pmc_row(PMC_MFMA, name) if _summary_hash(PMC_MFMA) == cur else None
     if fetch and fetch.get("calls"):
         # FETCH_SIZE is in KB and counts a wide coalesced read at half its bytes on gfx950 (MI355X_MICROARCH.md, HBM)
         out["traffic"] = fetch.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0 / fetch["calls"]
-        out["traffic_note"] = "HBM-side read bytes per launch (FETCH_SIZE KB x 1024 x 2), counter pass over the same launches"
+        out["traffic_note"] = (f"HBM-side read bytes per launch (FETCH_SIZE KB x 1024 x 2) from {os.path.relpath(PMC_FETCH, ROOT)}: "
+                               f"rocprofv3 --pmc FETCH_SIZE over `bench.py --dominant-only` on kernel sources {cur}")
     else:
         out["traffic"] = None
+        out["traffic_note"] = (f"no counter pass on kernel sources {cur} ({os.path.relpath(PMC_FETCH, ROOT)} has "
+                               f"{_summary_hash(PMC_FETCH)}): not quoted")
     if mfma and mfma.get("GRBM_GUI_ACTIVE"):
         out["mfma_busy"] = mfma.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (mfma["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        out["mfma_busy_note"] = f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) from {os.path.relpath(PMC_MFMA, ROOT)}"
     return out
 
 
@@ -241,6 +290,9 @@ def main():
     ap.add_argument("--dominant-only", action="store_true",
                     help="counter passes: build the plans, replay only the dominant kernel's launches of one step "
                          "(rocprofv3 --pmc ... -- python bench.py --dominant-only), print nothing else")
+    ap.add_argument("--no-dominant", action="store_true",
+                    help="skip the per-launch isolation timing behind the roofline object (kernel traces of the benchmark "
+                         "command are taken with it, so the trace holds the step's own launches only)")
     ap.add_argument("--k", type=int, default=0, help="profiling only: fixed number of denoising passes per step "
                                                      "(0 = the seeded reference distribution; the headline number uses 0)")
     args = ap.parse_args()
@@ -260,11 +312,30 @@ def main():
     from leco_amd.lora import LoRANetwork
     from leco_amd.train import FusedStep, init_distributed
 
-    rank, world, local = init_distributed()
+    # LECO_BENCH_EMU=1 (tests/test_dist.py only): the same launch / rendezvous / timing / JSON plumbing with the host
+    # emulator of the kernel sources on CPU tensors and gloo -- a dry run of the multi-GPU path for boxes without GPUs.
+    # It measures nothing (the emulator is test infrastructure) and says so in the output.
+    emu = os.environ.get("LECO_BENCH_EMU") == "1"
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+        import build_emu
+        from leco_amd import hip
+        hip._use_library(build_emu.build())
+    rank, world, local = init_distributed("gloo" if emu else None)
     assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
-    dev = torch.device(f"cuda:{local}")
-    torch.cuda.set_device(dev)
+    assert emu or torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    dev = torch.device("cpu") if emu else torch.device(f"cuda:{local}")
+    if not emu:
+        torch.cuda.set_device(dev)
+    n_allreduce = [0]
+    if world > 1:      # count the data-path collectives of the timed steps (must be exactly one per step)
+        import torch.distributed as dist
+        _all_reduce = dist.all_reduce
+
+        def counted(*a, **k):
+            n_allreduce[0] += 1
+            return _all_reduce(*a, **k)
+        dist.all_reduce = counted
 
     import io
     import contextlib
@@ -276,7 +347,7 @@ def main():
     unet.to(dev, dtype=torch.bfloat16)
     unet.requires_grad_(False)
     unet.eval()
-    unet.use_graphs = not args.no_graphs
+    unet.use_graphs = not args.no_graphs and not emu
     torch.manual_seed(1234)
     from leco_amd.lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV
     targets = list(DEFAULT_TARGET_REPLACE) + (list(UNET_TARGET_REPLACE_MODULE_CONV) if args.c3lier else [])
@@ -323,27 +394,37 @@ def main():
     def barrier():
         if world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[local])
-        torch.cuda.synchronize()
+            dist.barrier(**({} if emu else {"device_ids": [local]}))
+        if not emu:
+            torch.cuda.synchronize()
 
     for i in range(args.warmup):
         one(i)
     barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if not emu:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    e0.record()
+    if not emu:
+        e0.record()
+    n_allreduce[0] = 0
     losses = []
     for i in range(args.warmup, args.warmup + args.steps):
         losses.append(one(i).clone())       # device-side copy of the loss scalar: no host sync in the timed loop
-    e1.record()
+    if not emu:
+        e1.record()
+    collectives = n_allreduce[0]
     barrier()
     dt = time.perf_counter() - t0
-    dt_ev = e0.elapsed_time(e1) * 1e-3
+    dt_ev = e0.elapsed_time(e1) * 1e-3 if not emu else dt
+    ks_same = True
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
+        all_ks = [None] * world
+        dist.all_gather_object(all_ks, ks)
+        ks_same = all(x == all_ks[0] for x in all_ks)
     losses = [float(l.item()) for l in losses]
     finite = all(math.isfinite(l) for l in losses)
     if rank != 0:
@@ -365,12 +446,18 @@ def main():
                                f"{args.res}x{args.res}, prompt batch {args.bs} (UNet batch {2 * args.bs}), DDIM 50, "
                                f"reference-faithful pass structure (k+3+1 fwd, 1 bwd)",
                    "global_batch": args.bs * world, "k_sequence_seed": 0 if args.k <= 0 else f"fixed k={args.k} (profiling run)", "k_mean": sum(timed_ks) / len(timed_ks),
-                   "hip_graphs": bool(unet.use_graphs), "parallelism": f"dp{world}", "loss": losses[-1], "losses": losses},
+                   "hip_graphs": bool(unet.use_graphs), "parallelism": f"dp{world}", "loss": losses[-1], "losses": losses,
+                   "collectives_per_step": collectives / args.steps, "k_identical_across_ranks": ks_same},
     }
+    if emu:
+        out["data"] = "synthetic; HOST EMULATOR DRY RUN (LECO_BENCH_EMU=1): plumbing check, not a measurement"
+        out["dtype"] = "bf16 (emulated)"
     whole = {"achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12),
              "note": "algorithmic FLOPs W_ref(k) = 2 bs F_fwd (k + 5 + a) summed over the timed steps / HIP-event time on the "
                      "compute stream (rank 0)"}
     try:
+        if args.no_dominant or emu:
+            raise RuntimeError("--no-dominant")
         st = fused._state[(args.bs, args.res // 8, args.res // 8)]
         dom = dominant_kernel_roofline(st, sum(timed_ks) / len(timed_ks))
         # the roofline object is the DOMINANT KERNEL's (algorithmic FLOPs per launch / its average launch duration);
@@ -380,7 +467,7 @@ def main():
     except Exception as e:  # never hide the step number
         out["roofline"] = {"bound": "mfma", "achieved": whole["achieved"], "peak": whole["peak"], "unit": "TFLOP/s",
                            "frac": whole["frac"], "traffic": None, "whole_step": whole, "kernel": {"error": repr(e)}}
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not emu:
         try:
             out["cpu_baseline"] = cpu_baseline(sum(timed_ks) / len(timed_ks), args.bs)
         except Exception as e:  # the baseline leg must never hide the GPU number

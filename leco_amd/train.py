@@ -99,6 +99,9 @@ class FusedStep:
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ctx_cache = {}
         self._state = {}
+        # ancestral schedulers (ddpm / euler_a): `noise_fn(i, numel)` supplies the noise of denoising pass i (a replayable
+        # stream for parity tests); None = fresh device-RNG noise, like diffusers' randn_tensor on the UNet's device
+        self.noise_fn = None
 
     def _scale_at(self, t_train: int) -> float:
         """scale_model_input factor at train timestep `t_train` of the 1000-step schedule (train_lora.py:195-199)."""
@@ -224,9 +227,12 @@ class FusedStep:
         dplan.t_table[:n].copy_(self.ts_f)
         dplan.t_idx.zero_()
         self._run(dplan, "ctx_on")
-        for _ in range(k):
+        for i in range(k):
             if self.generic and st["noise"] is not None:
-                st["noise"].normal_()          # fresh ancestral noise (device RNG, like diffusers' randn_tensor)
+                if self.noise_fn is not None:
+                    st["noise"].copy_(self.noise_fn(i, st["half_n"]).to(self.dev, torch.float32).reshape(-1))
+                else:
+                    st["noise"].normal_()      # fresh ancestral noise (device RNG, like diffusers' randn_tensor)
             self._run(dplan, "denoise")
         # 2. frozen predictions at the "current" timestep (train_lora.py:195-237)
         t_cur = int(self.sched.num_train_timesteps - 1 - int(k * self.sched.num_train_timesteps / n))

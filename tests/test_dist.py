@@ -161,3 +161,28 @@ def test_train_under_dp_draws_per_rank_data_and_a_shared_k(tmp_path):
     assert torch.equal(res[0][1], res[1][1]), "LoRA parameters diverged across ranks"
     blob = torch.load(tmp_path / "dp_state.pt", map_location="cpu", weights_only=True)
     assert len(blob["rng"]) == 2 and not torch.equal(blob["rng"][0]["cpu"], blob["rng"][1]["cpu"])
+
+
+def test_bench_multi_gpu_launch_path_dry_run():
+    """`python bench.py --gpus 2` end to end WITHOUT GPUs: the self-relaunch under torch.distributed.run (one process per
+    rank, 127.0.0.1 rendezvous), per-rank build lock and library load, barrier-bracketed timing, max over ranks, rank 0's
+    single JSON line -- with the host emulator as kernel backend and gloo (LECO_BENCH_EMU=1).  Asserts what the driver's
+    scaling run relies on: whole-job value = world * steps / time, global batch = world * bs, the same k on every rank,
+    exactly one data-path collective (the LoRA gradient all-reduce) per step."""
+    import json
+    import subprocess
+    env = dict(os.environ, LECO_BENCH_EMU="1", LECO_EMU_THREADS="4", OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--arch", "tiny", "--res", "128", "--bs", "1", "--k", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only, one line
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["collectives_per_step"] == 1.0 and out["config"]["k_identical_across_ranks"] is True
+    assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-6 * out["value"]
+    assert "EMULATOR" in out["data"] and all(l == l for l in out["config"]["losses"])       # finite losses (NaN != NaN)

@@ -25,6 +25,13 @@ def main(d):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             calls[k].add(r["Dispatch_Id"])
     names = sorted({c for v in agg.values() for c in v})
+    try:      # which kernel sources these counters describe (bench.py refuses summaries taken on other sources)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        print(f"# csrc_sha1={bench.kernel_sources_hash()}")
+    except Exception as e:      # noqa: BLE001 -- the summary itself must never fail on this
+        print(f"# csrc_sha1=unknown ({e!r})")
     print("kernel,calls," + ",".join(names))
     key = names[0]
     for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get(key, 0))[:40]:
