@@ -289,10 +289,18 @@ __global__ __launch_bounds__(256) void cfg_sched_kernel(const float* pred, float
 // each *_pred is the raw fp32 [2*bs][n] UNet output; guided = u + g_pred*(c - u) (train_util.py:163-166).
 // target_goal = neutral + sign * g_loss * (positive - unconditional); loss = mean((target - goal)^2).
 // dpred[2*bs][n]: d loss / d raw target output = {(1-g_pred) * d, g_pred * d}, d = 2 (target-goal)/N.
+// Up to ESD_BLOCKS blocks; each leaves its partial sum in g_esd_part and draws a ticket; the block that draws the last
+// ticket adds the partials IN BLOCK ORDER, so the loss is bitwise reproducible although the blocks finish in any order
+// (one 256-thread block alone serialised the eight fp32 streams of a >= 500k-element batch on one CU).  The scratch is
+// per device: launches of this kernel must be stream-ordered (they are: one loss per step).
+constexpr int ESD_BLOCKS = 64;
+__device__ float g_esd_part[ESD_BLOCKS];
+__device__ unsigned g_esd_ticket = 0;
 __global__ __launch_bounds__(256) void esd_loss_kernel(const float* tgt, const float* pos, const float* neu,
                                                         const float* unc, float g_pred, float g_loss, float sign,
                                                         int64_t half_n, float* loss, float* dpred) {
     __shared__ float red[4];
+    __shared__ bool last;
     float part = 0.f;
     const float inv_n = 1.f / (float)half_n;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < half_n; e += (int64_t)gridDim.x * 256) {
@@ -313,7 +321,25 @@ __global__ __launch_bounds__(256) void esd_loss_kernel(const float* tgt, const f
     for (int m = 32; m >= 1; m >>= 1) part += shfl_xor(part, m);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
-    if (threadIdx.x == 0) *loss = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;   // ONE block: fixed summation order
+    if (threadIdx.x == 0) {
+        const float mine = (red[0] + red[1]) + (red[2] + red[3]);
+        if (gridDim.x == 1) {
+            *loss = mine * inv_n;
+            last = false;
+        } else {
+            g_esd_part[blockIdx.x] = mine;
+            __threadfence();                                           // partial visible device-wide before the ticket
+            last = atomicAdd(&g_esd_ticket, 1u) == gridDim.x - 1;
+        }
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        float tot = 0.f;
+        for (unsigned b = 0; b < gridDim.x; ++b) tot += ((volatile float*)g_esd_part)[b];   // fixed order
+        *loss = tot * inv_n;
+        g_esd_ticket = 0;                                              // re-armed for the next (stream-ordered) launch
+    }
 }
 
 // ---- fused AdamW over the flat LoRA slab (torch.optim.AdamW semantics, train_lora.py:280) ----------------
@@ -650,7 +676,9 @@ extern "C" int leco_esd_loss(const float* tgt, const float* pos, const float* ne
                              float g_loss, float sign, int64_t half_n, float* loss, float* dpred,
                              leco_stream_t stream) {
     // one workgroup (bs*4*h*w = 32 k .. 64 k elements): the loss is reduced in a fixed order -- bitwise reproducible
-    hipLaunchKernelGGL(esd_loss_kernel, dim3(1), dim3(256), 0, LECO_STREAM, tgt, pos, neu, unc, g_pred, g_loss, sign,
+    const int64_t want = (half_n + 4095) / 4096;       // >= 16 elements of each stream per thread
+    const int blocks = (int)(want < 1 ? 1 : (want > ESD_BLOCKS ? ESD_BLOCKS : want));
+    hipLaunchKernelGGL(esd_loss_kernel, dim3(blocks), dim3(256), 0, LECO_STREAM, tgt, pos, neu, unc, g_pred, g_loss, sign,
                        half_n, loss, dpred);
     return check_launch("leco_esd_loss");
 }

@@ -34,6 +34,12 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
                                                    __builtin_bit_cast(hw_bf16x8, b), c, 0, 0, 0);
 }
 
+// D(16x16,f32) = A(16x4,f32) * B(4x16,f32) + C -- v_mfma_f32_16x16x4_f32: f32 inputs, exact f32 products and sums (the fp32
+// compute mode, f32.hip).  Lane l supplies A[l&15][l>>4] and B[l>>4][l&15] and holds C/D[4*(l>>4)+r][l&15], r=0..3.
+__device__ __forceinline__ f32x4 mfma16x4_f32(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
 // Asynchronous 16-byte global -> LDS copy (global_load_lds_dwordx4): lane l of the wave writes
 // lds_wave_base + 16*l; the SOURCE address is per lane.  Completion is tracked by vmcnt
 // (__syncthreads() drains it).

@@ -243,6 +243,10 @@ class LoRANetwork(nn.Module):
         self.mark_updated()
         self.sync_shadow()
 
+    def needs_repack(self) -> bool:
+        """True when the packed MFMA operand images are older than the parameters."""
+        return self._packed_version != self.version
+
     def __enter__(self):
         self.multiplier = 1.0
         for lora in self.unet_loras:
@@ -252,3 +256,81 @@ class LoRANetwork(nn.Module):
         self.multiplier = 0
         for lora in self.unet_loras:
             lora.multiplier = 0
+
+
+class _ForeignModuleView:
+    """One forward-patching LoRA module of another implementation, seen through the fields the engine needs."""
+
+    def __init__(self, leaf_name: str, fm):
+        self.fm = fm
+        self.leaf_name = leaf_name
+        self.lora_name = getattr(fm, "lora_name", LORA_PREFIX_UNET + "_" + leaf_name.replace(".", "_"))
+        self.lora_down, self.lora_up = fm.lora_down, fm.lora_up
+        self.lora_dim = int(fm.lora_down.weight.shape[0])
+        self.scale = float(fm.scale)
+        self.alpha = fm.alpha if hasattr(fm, "alpha") else torch.tensor(self.scale * self.lora_dim)
+        self.down_off = self.up_off = -1
+
+    @property
+    def multiplier(self):
+        return self.fm.multiplier
+
+    @multiplier.setter
+    def multiplier(self, v):
+        self.fm.multiplier = v
+
+    def parameters(self):
+        return [self.lora_down.weight, self.lora_up.weight]
+
+
+class ForeignLoRANetwork(LoRANetwork):
+    """The reference's LoRA-injection seam (lora.py:97-106): its own ``lora.LoRANetwork`` works by
+    re-assigning ``org_module.forward`` of every target leaf.  This UNet never calls leaf modules, so instead of
+    ignoring (or refusing) such a network the engine ADOPTS it: the foreign ``lora_down`` / ``lora_up`` Parameters become
+    views into a flat fp32 slab exactly like this package's own modules (`_adopt`), the low-rank products run fused in
+    the GEMMs, gradients land in ``param.grad`` views of the gradient slab -- the foreign optimizer, ``with network:``
+    switch (its ``multiplier`` fields are read at every forward), ``state_dict()`` and ``save_weights`` keep working on
+    the objects the caller created.  The parameters can change behind the engine's back (a torch optimizer stepping the
+    views), so the operand images are re-packed before every LoRA-on pass."""
+
+    def __init__(self, unet, patched):      # patched: [(leaf qualified name, foreign LoRA module)]
+        nn.Module.__init__(self)
+        self.strict_reference = False
+        self.unet_loras = [_ForeignModuleView(n, fm) for n, fm in patched]
+        self.lora_dim = self.unet_loras[0].lora_dim
+        self.alpha = float(self.unet_loras[0].scale * self.lora_dim)
+        self.version = 0
+        self._packed_version = -1
+        self._unet = [unet]
+        self._build_slab(unet.device)
+        unet.engine().attach_lora(self)
+
+    @property
+    def multiplier(self):
+        return self.unet_loras[0].multiplier
+
+    @multiplier.setter
+    def multiplier(self, v):
+        for lora in self.unet_loras:
+            lora.multiplier = v
+
+    def needs_repack(self) -> bool:
+        return True
+
+
+def adopt_forward_patches(unet) -> Optional[ForeignLoRANetwork]:
+    """Finds leaves whose ``forward`` was re-assigned to a bound method of an object carrying ``lora_down`` / ``lora_up`` /
+    ``multiplier`` / ``scale`` (the reference's LoRAModule.apply_to, lora.py:97-100) and adopts them (None if there are
+    none).  Leaves patched by anything else raise: the launch plans would silently ignore such a patch."""
+    patched = []
+    for name, m in unet.named_modules():
+        if isinstance(m, (nn.Linear, nn.Conv2d)) and "forward" in m.__dict__:
+            fm = getattr(m.__dict__["forward"], "__self__", None)
+            if fm is None or not all(hasattr(fm, a) for a in ("lora_down", "lora_up", "multiplier", "scale")):
+                raise RuntimeError(
+                    f"{name}.forward has been re-assigned by something that is not a LoRA module (lora_down / lora_up / "
+                    "multiplier / scale): this UNet executes static launch plans and never calls leaf modules.")
+            patched.append((name, fm))
+    if not patched:
+        return None
+    return ForeignLoRANetwork(unet, patched)

@@ -50,6 +50,35 @@ _SIGS = {
     "leco_lora_wgrad_grouped": [_vp, _i32, _i32, _i32, _vp],
     "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp],
 }
+# fp32 compute mode (csrc/f32.hip): the same argument lists behind `leco_f32_` entry points; activations / weights /
+# LoRA operand images are float.  While `f32_mode(True)` is active (the plan builder of an fp32 engine), every Op that
+# has an fp32 twin is created on it.
+_F32_TWINS = ("leco_groupnorm_fwd", "leco_groupnorm_bwd", "leco_layernorm_fwd", "leco_layernorm_bwd", "leco_attention_fwd",
+              "leco_attention_bwd", "leco_geglu_fwd", "leco_geglu_bwd", "leco_add", "leco_upsample2x_bwd", "leco_conv_in",
+              "leco_conv_out", "leco_conv_out_bwd", "leco_timestep_embedding", "leco_cfg_ddim_step", "leco_cfg_sched_step",
+              "leco_cast_f32_bf16", "leco_lora_pack", "leco_lora_wgrad_conv", "leco_rowgroup_sum", "leco_lora_wgrad")
+for _n in _F32_TWINS:
+    _SIGS["leco_f32_" + _n[len("leco_"):]] = _SIGS[_n]
+_SIGS["leco_f32_gemm"] = [C.POINTER(GemmArgs), _vp]
+_f32_active = False
+
+
+class f32_mode:
+    """Context manager: Ops created inside are bound to the fp32 kernels."""
+
+    def __init__(self, on: bool = True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _f32_active
+        self.prev, _f32_active = _f32_active, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _f32_active
+        _f32_active = self.prev
+
+
 _fn_cache = {}
 _fn_lib = None
 
@@ -76,6 +105,11 @@ class Op:
 
     def __init__(self, name: str, args: tuple, keep=None):
         self.tag = None   # plan builders label ops (e.g. "ctx": depends only on the prompt embeddings)
+        if _f32_active:
+            if name in _F32_TWINS:
+                name = "leco_f32_" + name[len("leco_"):]
+            elif name == "leco_lora_wgrad_grouped":
+                raise RuntimeError("fp32 mode accumulates the LoRA weight gradients per problem (leco_f32_lora_wgrad)")
         self.name = name
         self.fn = _fn(name)
         self.args = args
@@ -109,6 +143,8 @@ def run_plan(plan: Sequence[Op], stream=None) -> None:
 def gemm(args: GemmArgs, keep=None, ws: Optional[torch.Tensor] = None, tile: int = 0, split_k: int = 0) -> Op:
     """``ws``: fp32 scratch for split-K partial slabs (without it the GEMM never splits).  ``tile == 0 and
     split_k == 0``: the launch shape comes from the tuner (leco_amd/tune.py: table / measurement), else the C heuristic."""
+    if _f32_active:      # one exact-fp32 MFMA kernel, no launch shapes to choose
+        return Op("leco_f32_gemm", (C.byref(args),), keep=(args, keep))
     if tile == 0 and split_k == 0:
         from . import tune
         tile, split_k = tune.choose(args, ws)

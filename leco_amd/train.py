@@ -97,6 +97,8 @@ class FusedStep:
         self.single_slot = 512
         self.slot_idx = torch.tensor([self.single_slot], dtype=torch.int32, device=dev)
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        # activation dtype of the engine: bf16 (MFMA path) or fp32 (`train.precision: float32`, csrc/f32.hip)
+        self.adt = unet.engine().adt
         self._ctx_cache = {}
         self._state = {}
         # ancestral schedulers (ddpm / euler_a): `noise_fn(i, numel)` supplies the noise of denoising pass i (a replayable
@@ -142,6 +144,8 @@ class FusedStep:
                       preds={n: fplan.pred[2 * bs * i:2 * bs * (i + 1)]
                              for i, n in enumerate(("positive", "neutral", "unconditional"))},
                       half_n=bs * 4 * h * w)
+            f32ctx = ops.f32_mode(eng.f32)
+            f32ctx.__enter__()
             if self.generic:
                 st["noise"] = (torch.zeros(st["half_n"], dtype=torch.float32, device=self.dev)
                                if self.sched.needs_noise else None)
@@ -154,6 +158,7 @@ class FusedStep:
                 tail = [ops.cfg_ddim_step(dplan.pred, st["x"], dplan.x_in, self.coef, dplan.t_idx, DENOISE_GUIDANCE,
                                           st["half_n"]),
                         ops.advance(dplan.t_idx)]
+            f32ctx.__exit__()
             # cross-attention K/V (+ their LoRA down projections) depend only on the prompt embeddings: the k
             # denoising passes of a step share one evaluation ("ctx_on"), the per-pass list skips those ops
             dplan.lists["ctx_on"] = [op for op in dplan.lists["fwd_on"] if op.tag == "ctx"]
@@ -170,7 +175,7 @@ class FusedStep:
         c = self._ctx_cache.get(key)
         if c is None:
             c = train_util.concat_embeddings(self._text(pair.unconditional), self._text(getattr(pair, which)), bs)
-            c = c.to(self.dev, torch.bfloat16).contiguous()
+            c = c.to(self.dev, self.adt).contiguous()
             self._ctx_cache[key] = c
         return c
 
@@ -180,7 +185,7 @@ class FusedStep:
         c = self._ctx_cache.get(key)
         if c is None:
             c = train_util.concat_embeddings(pair.unconditional.pooled_embeds, getattr(pair, which).pooled_embeds, bs)
-            c = c.to(self.dev, torch.bfloat16).contiguous()
+            c = c.to(self.dev, self.adt).contiguous()
             self._ctx_cache[key] = c
         return c
 
@@ -214,7 +219,7 @@ class FusedStep:
         x.copy_(latents.to(self.dev, torch.float32))
         dplan = st["dplan"]
         x_first = x * self.first_scale if self.generic else x        # scale_model_input of the first step
-        dplan.x_in.copy_(torch.cat([x_first, x_first]).to(torch.bfloat16))
+        dplan.x_in.copy_(torch.cat([x_first, x_first]).to(self.adt))
         if self.generic and st["hist"] is not None:
             st["hist"].zero_()
         dplan.ctx.copy_(self._ctx(pair, "target", bs))
@@ -240,7 +245,8 @@ class FusedStep:
             # sigma-space schedulers: the UNet input of the remaining passes is x / sqrt(sigma(t_cur)^2 + 1)
             sc = self._scale_at(t_cur)
             self.coef[n, 6:7].copy_(torch.tensor([sc], dtype=torch.float32), non_blocking=True)
-            ops.cfg_sched_step(None, x, plan.x_in, self.coef, self.fin_idx, 0.0, st["half_n"]).run()
+            with ops.f32_mode(unet.engine().f32):
+                ops.cfg_sched_step(None, x, plan.x_in, self.coef, self.fin_idx, 0.0, st["half_n"]).run()
         else:
             plan.x_in.copy_(dplan.x_in)
         plan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])
@@ -327,7 +333,7 @@ def save_training_state(path, fused: "FusedStep", iteration: int, lr_scheduler=N
     if rank != 0:
         return
     blob = {k: getattr(net, k).detach().cpu().clone() for k in STATE_KEYS}
-    blob.update(opt_step=fused.opt_step, iteration=int(iteration), rng=rngs,
+    blob.update(format=2, world_size=int(fused.world), opt_step=fused.opt_step, iteration=int(iteration), rng=rngs,
                 lr_scheduler=None if lr_scheduler is None else lr_scheduler.state_dict(),
                 optimizer=None if isinstance(fused.optimizer, str) else fused.optimizer.state_dict())
     torch.save(blob, path)
@@ -353,8 +359,14 @@ def load_training_state(path, fused: "FusedStep", lr_scheduler=None) -> int:
         import torch.distributed as dist
         rank = dist.get_rank(fused.pg)
     rngs = blob["rng"]
-    if rank >= len(rngs):
-        raise ValueError(f"state file holds RNG streams for {len(rngs)} ranks; this run has rank {rank}")
+    if isinstance(rngs, torch.Tensor):          # format 1 (single process): the CPU generator state alone
+        rngs = [{"cpu": rngs}]
+    saved_world = int(blob.get("world_size", len(rngs)))
+    if saved_world != fused.world or len(rngs) != fused.world:
+        # a different rank count means a different global batch and a different replay of the shared k stream: the
+        # continuation would silently be another run
+        raise ValueError(f"{path}: training state was saved by {saved_world} rank(s) ({len(rngs)} RNG streams); this run "
+                         f"has {fused.world}.  Resume with the same number of ranks.")
     torch.set_rng_state(rngs[rank]["cpu"])
     if fused.dev.type == "cuda" and "cuda" in rngs[rank]:
         torch.cuda.set_rng_state(rngs[rank]["cuda"], fused.dev)
@@ -404,24 +416,28 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
         wandb.init(project=f"LECO_{config.save.name}", config=metadata)
     weight_dtype = config_util.parse_precision(config.train.precision)
     save_weight_dtype = config_util.parse_precision(config.train.precision)  # sic, train_lora.py:55
-    if weight_dtype != torch.bfloat16:
-        print(f"note: the MI355X path computes in bf16 MFMA with fp32 accumulation; train.precision="
-              f"{config.train.precision} only selects the dtype of the saved LoRA.")
+    # train.precision (config_util.py:75-83, train_lora.py:54-67): float32 runs the fp32 compute mode (fp32 activations,
+    # weights and LoRA operands, exact fp32 MFMA contractions: csrc/f32.hip -- the reference's arithmetic for such
+    # configs, several times slower than the bf16 MFMA path); bfloat16 is the MFMA path; float16 has no kernels here
+    # and is computed in bf16 (same 16-bit storage cost, wider exponent), the saved LoRA is fp16 as requested.
+    compute_dtype = torch.float32 if weight_dtype == torch.float32 else torch.bfloat16
+    if weight_dtype == torch.float16:
+        print("note: train.precision=float16 is computed on the bf16 MFMA path; only the saved LoRA is fp16.")
 
     if xl:
         tokenizers, text_encoders, unet, noise_scheduler = model_util.load_models_xl(
             config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler)
         for text_encoder in text_encoders:
-            text_encoder.to(device, dtype=torch.bfloat16)
+            text_encoder.to(device, dtype=compute_dtype)
             text_encoder.eval()
         tokenizer = None
     else:
         tokenizer, text_encoder, unet, noise_scheduler = model_util.load_models(
             config.pretrained_model.name_or_path, scheduler_name=config.train.noise_scheduler,
             v2=config.pretrained_model.v2, v_pred=config.pretrained_model.v_pred)
-        text_encoder.to(device, dtype=torch.bfloat16)
+        text_encoder.to(device, dtype=compute_dtype)
         text_encoder.eval()
-    unet.to(device, dtype=torch.bfloat16)
+    unet.to(device, dtype=compute_dtype)
     unet.enable_xformers_memory_efficient_attention()
     unet.requires_grad_(False)
     unet.eval()

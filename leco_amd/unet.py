@@ -238,7 +238,8 @@ class UNetOutput:
 # plan-time tensors and the build-time autograd tape
 # =============================================================================================
 class TRef:
-    """A row-major [rows][cols] bf16 activation view (row stride ``ld``) inside a device buffer."""
+    """A row-major [rows][cols] activation view (row stride ``ld``; bf16, or fp32 in the fp32 compute mode) inside a
+    device buffer."""
     __slots__ = ("t", "ptr", "ld", "rows", "cols", "rg", "gparts", "name")
 
     def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None, offset: int = 0,
@@ -253,7 +254,7 @@ class TRef:
 
     def cols_view(self, c0: int, c1: int) -> "TRef":
         v = TRef(self.t, self.rows, c1 - c0, self.ld, 0, self.rg, self.name)
-        v.ptr = self.ptr + c0 * 2
+        v.ptr = self.ptr + c0 * self.t.element_size()
         return v
 
 
@@ -275,13 +276,14 @@ class LoraSiteState:
         else:
             self.Rp = (self.R + 31) // 32 * 32 if self.R <= 64 else (self.R + 63) // 64 * 64
         K, N = site.lora_k, site.n
+        dt = site.eng.adt
         # dn_s / up_t get Rp rows (rows beyond R16 stay zero) so they can be GEMM weight operands
-        self.dn_s = torch.zeros(self.Rp, K, dtype=bf16, device=dev)
-        self.up_p = torch.zeros(N, self.Rp, dtype=bf16, device=dev)
-        self.up_t = torch.zeros(self.Rp, N, dtype=bf16, device=dev)
-        self.dn_p = torch.zeros(K, self.Rp, dtype=bf16, device=dev)
-        # GEGLU input projections keep a second, row-interleaved copy of up_p for the fused-GEGLU epilogue
-        self.up_pg = torch.zeros(N, self.Rp, dtype=bf16, device=dev) if site.geglu_ok else None
+        self.dn_s = torch.zeros(self.Rp, K, dtype=dt, device=dev)
+        self.up_p = torch.zeros(N, self.Rp, dtype=dt, device=dev)
+        self.up_t = torch.zeros(self.Rp, N, dtype=dt, device=dev)
+        self.dn_p = torch.zeros(K, self.Rp, dtype=dt, device=dev)
+        # GEGLU input projections keep a second, row-interleaved copy of up_p for the fused-GEGLU epilogue (bf16 path)
+        self.up_pg = torch.zeros(N, self.Rp, dtype=dt, device=dev) if (site.geglu_ok and not site.eng.f32) else None
 
 
 class GemmSite:
@@ -303,7 +305,7 @@ class GemmSite:
             ws.append(w)
             bs.append(None if m.bias is None else m.bias.detach().float())
         self.group_n = ws[0].shape[0]
-        self.w = torch.cat(ws, 0).to(device=dev, dtype=bf16).contiguous()
+        self.w = torch.cat(ws, 0).to(device=dev, dtype=eng.adt).contiguous()
         self.n, self.k = self.w.shape
         self.cin = self.k // 9 if conv3 else self.k
         self.lora_k = self.k
@@ -360,6 +362,12 @@ class Plan:
 class Engine:
     def __init__(self, unet: "UNet2DConditionModel", device: torch.device):
         self.unet, self.cfg, self.device = unet, unet.cfg, device
+        # compute mode = the dtype the model holds when its engine is built: bf16 MFMA path, or -- for models kept in
+        # torch.float32, what `train.precision: float32` selects (config_util.py:75-83, train_lora.py:54-67) -- the fp32
+        # mode of csrc/f32.hip: fp32 activations / weights / LoRA operands, exact fp32 contractions, no fused fast paths
+        self.f32 = unet.conv_in.weight.dtype == torch.float32
+        self.adt = torch.float32 if self.f32 else bf16
+        self.esz = 4 if self.f32 else 2
         self.sites: Dict[str, GemmSite] = {}      # by site name
         self.leaf_site: Dict[str, Tuple[GemmSite, int]] = {}  # leaf qualified name -> (site, group)
         self.plans: Dict[tuple, Plan] = {}
@@ -406,7 +414,7 @@ class Engine:
             self._site("add_embedding.linear_2", [("add_embedding.linear_2", u.add_embedding.linear_2)])
         self.conv_in_w = self._f32(u.conv_in.weight.detach().permute(1, 2, 3, 0))  # [Cin][3][3][Cout]
         self.conv_in_b = self._f32(u.conv_in.bias)
-        self.conv_out_w = u.conv_out.weight.detach().permute(0, 2, 3, 1).contiguous().to(self.device, bf16)
+        self.conv_out_w = u.conv_out.weight.detach().permute(0, 2, 3, 1).contiguous().to(self.device, self.adt)
         self.conv_out_b = self._f32(u.conv_out.bias)
         self.norm_p: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
         for n, m in named.items():
@@ -475,13 +483,15 @@ class Engine:
                 if mod is None:  # group without a LoRA module: zero operands
                     key = (st.r, site.k, site.group_n)
                     if key not in self._zero_dummy:
-                        self._zero_dummy[key] = (torch.zeros(st.r, site.k, dtype=bf16, device=self.device),
-                                                 torch.zeros(site.group_n, st.r, dtype=bf16, device=self.device))
+                        self._zero_dummy[key] = (torch.zeros(st.r, site.k, dtype=self.adt, device=self.device),
+                                                 torch.zeros(site.group_n, st.r, dtype=self.adt, device=self.device))
                     dn, up = self._zero_dummy[key]
                     d.down[g], d.up[g] = dn.data_ptr(), up.data_ptr()
                 else:
-                    d.down[g] = net.shadow.data_ptr() + mod.down_off * 2
-                    d.up[g] = net.shadow.data_ptr() + mod.up_off * 2
+                    # bf16 path: the bf16 shadow of the slab; fp32 mode: the fp32 master slab itself
+                    src = net.slab if self.f32 else net.shadow
+                    d.down[g] = src.data_ptr() + mod.down_off * self.esz
+                    d.up[g] = src.data_ptr() + mod.up_off * self.esz
             d.groups, d.r, d.k, d.n = len(st.mods), st.r, site.k, site.n
             d.scale = 0.0  # filled by refresh_lora
             d.taps = 9 if site.conv3 else 1
@@ -502,7 +512,8 @@ class Engine:
             raw = torch.frombuffer(bytearray(bytes(self._pack_host)), dtype=torch.uint8)
             self._pack_dev.copy_(raw)
             self._pack_scale = multiplier
-        ops.lora_pack(self._pack_dev, len(self.lora_sites)).run()
+        with ops.f32_mode(self.f32):
+            ops.lora_pack(self._pack_dev, len(self.lora_sites)).run()
         net._packed_version = net.version
 
     # ---- plan construction ---------------------------------------------------------------------
@@ -511,7 +522,8 @@ class Engine:
         LoRA-off passes, which never run a backward."""
         key = (B, h, w, need_bwd)
         if key not in self.plans:
-            self.plans[key] = PlanBuilder(self, B, h, w, need_bwd).build()
+            with ops.f32_mode(self.f32):
+                self.plans[key] = PlanBuilder(self, B, h, w, need_bwd).build()
         return self.plans[key]
 
     def drop_plan(self, key: tuple) -> None:
@@ -551,8 +563,8 @@ class PlanBuilder:
         self.wgrad_keep: List = []
 
     # ---- helpers -----------------------------------------------------------------------------
-    def buf(self, name, shape, dtype=bf16, zero=False) -> torch.Tensor:
-        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+    def buf(self, name, shape, dtype=None, zero=False) -> torch.Tensor:
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype or self.eng.adt, device=self.dev)
         key = name
         while key in self.plan.bufs:
             self.nbuf += 1
@@ -614,7 +626,7 @@ class PlanBuilder:
         self._last_T = None
         if lora is not None:
             T = self._last_T = self.act(name + ".loraT", rows, lora.Rp)
-            if amode == A_PLAIN and lora.Rp == 32:
+            if amode == A_PLAIN and lora.Rp == 32 and not self.eng.f32:
                 # down-projection fused into the main GEMM's K sweep (T is still written: lora_up wgrad)
                 g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, w_ext=lora.up_p, ext_k=32, ld_wext=32,
                                  t_w=lora.dn_s, t_rows=lora.R16, t_out=T.ptr, ld_tout=T.ld, **common)
@@ -631,7 +643,7 @@ class PlanBuilder:
                 self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y), ws=self.eng.workspace))
                 for c in range(64, lora.Rp, 64):   # further 64-column slices of T . (scale up)^T, accumulated into y
                     assert y is not None and act == ACT_NONE
-                    g_c = gemm_args(T.ptr + 2 * c, lora.up_p.data_ptr() + 2 * c, y.ptr, m=rows, n=site.n, k=64, lda=T.ld,
+                    g_c = gemm_args(T.ptr + self.eng.esz * c, lora.up_p.data_ptr() + self.eng.esz * c, y.ptr, m=rows, n=site.n, k=64, lda=T.ld,
                                     ldw=lora.Rp, ldc=y.ld, residual=y.ptr, ldr=y.ld)
                     self.f_on.append(ops.gemm(g_c, keep=(lora, T, y), ws=self.eng.workspace))
         else:
@@ -681,13 +693,15 @@ class PlanBuilder:
         out, lora, net = self.plan.bwd, site.lora, self.eng.network
         gn, r = site.group_n, lora.r
         cin_total = sum(t.cols for t in xs)
-        det = self.eng.workspace if self.eng.deterministic else None   # atomic-free wgrad accumulation
+        # atomic-free wgrad accumulation: deterministic mode, and always in the fp32 mode (one fixed-order kernel per problem)
+        det = self.eng.workspace if (self.eng.deterministic or self.eng.f32) else None
+        esz = self.eng.esz
         det_bytes = 0 if det is None else det.numel() * det.element_size()
 
         def emit(p, ldp, q, ldq, g, g_sj, g_sc, cols, s, cv=None, keep=(), r=r):
-            if r > 16:   # the wgrad kernel keeps <= 16 rank columns in registers: one problem per 16-column slice
+            if r > 16 and not self.eng.f32:   # the bf16 wgrad kernel keeps <= 16 rank columns in registers: one problem per 16-column slice
                 for j0 in range(0, r, 16):
-                    emit(p + 2 * j0, ldp, q, ldq, g + 4 * j0 * g_sj, g_sj, g_sc, cols, s, cv, keep, min(16, r - j0))
+                    emit(p + esz * j0, ldp, q, ldq, g + 4 * j0 * g_sj, g_sj, g_sc, cols, s, cv, keep, min(16, r - j0))
                 return
             if det is None:
                 pr = dict(p=p, ldp=ldp, q=q, ldq=ldq, g=g, g_sj=g_sj, g_sc=g_sc, m=rows, r=r, cols=cols, scale=s)
@@ -710,16 +724,16 @@ class PlanBuilder:
             for t in xs:
                 if amode == A_PLAIN:
                     # d lora_down[j][c_off + c] = s * sum_m U[m][g r + j] x[m][c]
-                    emit(U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * c_off, cin_total, 1, t.cols, s, keep=(U, t))
+                    emit(U.ptr + esz * g * r, U.ld, t.ptr, t.ld, gdown + 4 * c_off, cin_total, 1, t.cols, s, keep=(U, t))
                 else:
                     # conv lora_down [r][Cin][3][3]: one gathered product per tap
                     _, ho, wo, hi, wi = conv
                     for tap in range(9):
-                        emit(U.ptr + 2 * g * r, U.ld, t.ptr, t.ld, gdown + 4 * (c_off * 9 + tap), cin_total * 9, 9, t.cols, s,
+                        emit(U.ptr + esz * g * r, U.ld, t.ptr, t.ld, gdown + 4 * (c_off * 9 + tap), cin_total * 9, 9, t.cols, s,
                              cv=(amode, ho, wo, hi, wi, tap // 3, tap % 3), keep=(U, t))
                 c_off += t.cols
             # d lora_up[n][j] = s * sum_m dy[m][g gn + n] T[m][g r + j]
-            emit(T.ptr + 2 * g * r, T.ld, dy.ptr + 2 * g * gn, dy.ld, net.grad.data_ptr() + 4 * mod.up_off, 1, r, gn, s,
+            emit(T.ptr + esz * g * r, T.ld, dy.ptr + esz * g * gn, dy.ld, net.grad.data_ptr() + 4 * mod.up_off, 1, r, gn, s,
                  keep=(T, dy))
 
     def gemm_bwd(self, site: GemmSite, xs, y: TRef, T: Optional[TRef], conv, amode, rows, residual):
@@ -733,7 +747,7 @@ class PlanBuilder:
         need = [t for t in xs if t.rg]
         # plain sites whose input needs a gradient: U = dY up^T rides in the dgrad GEMM's K sweep (fused `t_w`), like T in
         # the forward -- 192 skinny N = 32 GEMMs (~9 us each) less per backward
-        fuse_u = lora is not None and bool(need) and amode == A_PLAIN and lora.Rp == 32
+        fuse_u = lora is not None and bool(need) and amode == A_PLAIN and lora.Rp == 32 and not self.eng.f32
         U = self.lora_bwd(site, xs, dy, T, conv, amode, rows, y.name, fuse_u) if lora is not None else None
         if not need:
             return
@@ -752,7 +766,7 @@ class PlanBuilder:
                               ld_wext=lora.Rp if lora is not None else 0)
                 out.append(ops.gemm(g, keep=(site, dy, dx, U), ws=self.eng.workspace))
                 for c in range(64, lora.Rp if lora is not None else 0, 64):   # further slices of U . (scale down)
-                    g_c = gemm_args(U.ptr + 2 * c, lora.dn_p.data_ptr() + 2 * c, dx.ptr, m=rows, n=kin, k=64, lda=U.ld,
+                    g_c = gemm_args(U.ptr + self.eng.esz * c, lora.dn_p.data_ptr() + self.eng.esz * c, dx.ptr, m=rows, n=kin, k=64, lda=U.ld,
                                     ldw=lora.Rp, ldc=dx.ld, residual=dx.ptr, ldr=dx.ld)
                     out.append(ops.gemm(g_c, keep=(lora, U, dx), ws=self.eng.workspace))
         else:
@@ -947,7 +961,7 @@ class PlanBuilder:
         h2 = self.gemm_fwd(S[bname + ".attn2.to_out.0"], a2, bname + ".h2", rows=rows, residual=h1)
         l3 = self.layernorm(bname + ".norm3", h2, bname + ".l3")
         ff1 = S[bname + ".ff.net.0.proj"]
-        if not self.need_bwd and ff1.geglu_ok and (ff1.lora is None or (ff1.lora.Rp == 32 and ff1.lora.up_pg is not None)):
+        if not self.need_bwd and not eng.f32 and ff1.geglu_ok and (ff1.lora is None or (ff1.lora.Rp == 32 and ff1.lora.up_pg is not None)):
             gg = self.gemm_fwd(ff1, l3, bname + ".geglu", rows=rows, geglu=True)
             return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2)
         u = self.gemm_fwd(ff1, l3, bname + ".u", rows=rows)
@@ -1190,7 +1204,7 @@ class UNet2DConditionModel(nn.Module):
         B, _, h, w = sample_shape
         eng = self.engine()
         net = eng.network
-        if net is not None and lora_on and (net._packed_version != net.version or eng._pack_scale != net.multiplier):
+        if net is not None and lora_on and (net.needs_repack() or eng._pack_scale != net.multiplier):
             net.sync_shadow()
             eng.refresh_lora(net.multiplier)
         return eng.plan(B, h, w)
@@ -1199,22 +1213,18 @@ class UNet2DConditionModel(nn.Module):
         net = self.engine().network
         return net is not None and net.multiplier != 0
 
-    def _reject_foreign_patches(self) -> None:
-        """The reference's LoRAModule (lora.py:97-100) works by re-assigning ``org_module.forward``.  The leaves here
-        only HOLD weights -- the launch plans never call ``leaf.forward`` -- so such a patch would silently do nothing:
-        refuse it and point at the slab-backed drop-in."""
-        leaves = getattr(self, "_leaves", None)
-        if leaves is None:
-            leaves = self._leaves = [(n, m) for n, m in self.named_modules() if isinstance(m, (nn.Linear, nn.Conv2d))]
-        for name, m in leaves:
-            if "forward" in m.__dict__:
-                raise RuntimeError(
-                    f"{name}.forward has been re-assigned (a LoRA network that patches module.forward, such as the "
-                    "reference's lora.LoRANetwork): this UNet executes static launch plans and never calls leaf modules. "
-                    "Use leco_amd.lora.LoRANetwork (same constructor, names and save format).")
+    def _adopt_foreign_patches(self) -> None:
+        """The reference's LoRAModule (lora.py:97-100) works by re-assigning ``org_module.forward``.  The leaves here only
+        HOLD weights -- the launch plans never call ``leaf.forward`` -- so such a network is ADOPTED instead
+        (`lora.adopt_forward_patches`: its parameters become slab views, its products run fused in the GEMMs).  Checked
+        only while no LoRA network is attached: one walk over the leaves per forward until then, nothing afterwards."""
+        if self.engine().network is not None:
+            return
+        from .lora import adopt_forward_patches
+        adopt_forward_patches(self)
 
     def forward(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None):
-        self._reject_foreign_patches()
+        self._adopt_foreign_patches()
         eng = self.engine()
         lora_on = self.lora_active()
         plan = self.prepare(sample.shape, lora_on)

@@ -68,6 +68,8 @@ void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 
 #define __expf(x) expf(x)
 #define __logf(x) logf(x)
+static inline unsigned atomicAdd(unsigned* addr, unsigned v) { return __atomic_fetch_add(addr, v, __ATOMIC_SEQ_CST); }
+static inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
 static inline float atomicAdd(float* addr, float v) {
     unsigned* p = reinterpret_cast<unsigned*>(addr);
     unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);

@@ -50,6 +50,25 @@ static inline f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
     return out;
 }
 
+// v_mfma_f32_16x16x4_f32: lane l supplies A[l&15][l>>4], B[l>>4][l&15]; holds D[4*(l>>4)+r][l&15]
+static inline f32x4 mfma16x4_f32(float a, float b, f32x4 c) {
+    struct Dep { float a, b; } d{a, b};
+    const unsigned char* all = emu::wave_gather(&d, sizeof(d));
+    const int l = emu::lane(), j = l & 15, g = l >> 4;
+    f32x4 out = c;
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            const Dep* la = reinterpret_cast<const Dep*>(all + (size_t)(i + 16 * k) * emu::kSlot);
+            const Dep* lb = reinterpret_cast<const Dep*>(all + (size_t)(j + 16 * k) * emu::kSlot);
+            acc = fmaf(la->a, lb->b, acc);
+        }
+        out[r] = acc;
+    }
+    return out;
+}
+
 // LDS-DMA model.  Default: the copy completes at issue (earliest possible landing: exposes a DMA that overwrites
 // a ring slot other waves still read).  With LECO_EMU_DMA=late in the environment every copy is DEFERRED until
 // the issuing lane's counted wait (`wait_vmcnt<N>` completes all but its N youngest) or a full

@@ -480,6 +480,19 @@ def test_timestep_ddim_loss_adamw(dev):
     ref.backward()
     assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
     assert rel_err(dp.cpu(), tt_.grad) < 1e-5
+    # a large batch runs on many blocks; the last-arriving block adds the partials in block order: repeated launches give
+    # the same bits (and re-arm the ticket)
+    big = 300000
+    tb, pb_, nb, ub = [torch.randn(2 * big, device=dev) for _ in range(4)]
+    lb = torch.zeros(3, device=dev)
+    for i in range(3):
+        ops.esd_loss(tb, pb_, nb, ub, 0.5, 2.0, 1.0, big, lb[i:i + 1], None).run()
+    _sync(dev)
+
+    def gd5(z):
+        return (z[:big] + 0.5 * (z[big:] - z[:big])).double().cpu()
+    refb = ((gd5(tb) - (gd5(nb) + 2.0 * (gd5(pb_) - gd5(ub)))) ** 2).mean().item()
+    assert abs(lb[0].item() - refb) < 1e-5 * refb and lb[0].item() == lb[1].item() == lb[2].item()
     N = 1000
     p0 = torch.randn(N); g0 = torch.randn(N)
     pp = p0.clone().to(dev); m0 = torch.zeros(N, device=dev); v0 = torch.zeros(N, device=dev)

@@ -157,3 +157,60 @@ def test_reference_lora_patch_on_the_hip_unet_fails_loudly(ref):
         ref["lora"].LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
     with pytest.raises(RuntimeError, match="leco_amd.lora.LoRANetwork"):
         m(torch.zeros(2, 4, 16, 16), torch.tensor(1), encoder_hidden_states=torch.zeros(2, 77, 64))
+
+
+def test_reference_lora_network_applied_to_this_unet_is_adopted(ref):
+    """SURVEY 8b seam 2, the reference's LoRA injection (lora.py:97-106): the reference's OWN `lora.LoRANetwork`, built on
+    this package's UNet, patches `leaf.forward`; the engine adopts it -- its parameters become slab views, the products
+    run fused in the GEMMs -- so the reference's loop body works unmodified on it: `with network:` on / off,
+    `loss.backward()` filling the foreign parameters' .grad, the foreign torch optimizer stepping them, `save_weights`.
+    Checked against the reference network patched onto the fp32 oracle UNet (emulator backend, fp32 compute mode)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    from leco_amd import hip, model_util
+    from leco_amd.lora import ForeignLoRANetwork
+    from leco_amd.unet import UNet2DConditionModel
+    from oracle import unet_ref as R
+    hip._use_library(build_emu.build())
+    ru = R.init_synthetic_(R.UNet2DConditionModel(R.tiny_config()), seed=1234)
+    ru.requires_grad_(False)
+    m = UNet2DConditionModel(model_util.tiny_config())
+    m.load_state_dict(ru.state_dict())
+    m.requires_grad_(False)                      # fp32 model -> fp32 compute mode: tight comparison
+    nets = []
+    for unet in (ru, m):
+        torch.manual_seed(42)
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = ref["lora"].LoRANetwork(unet, rank=4, multiplier=1.0, alpha=1.0)
+        g = torch.Generator().manual_seed(3)
+        with torch.no_grad():
+            for l in net.unet_loras:
+                l.lora_up.weight.copy_(torch.randn(l.lora_up.weight.shape, generator=g) * 0.05)
+        nets.append(net)
+    rnet, fnet = nets
+    opt_r = torch.optim.AdamW(rnet.prepare_optimizer_params(), lr=1e-3)
+    opt_f = torch.optim.AdamW(fnet.prepare_optimizer_params(), lr=1e-3)
+    g = torch.Generator().manual_seed(9)
+    x, ctx = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 77, 64, generator=g)
+    tgt = torch.randn(2, 4, 16, 16, generator=g)
+
+    def rel(a, b):
+        return ((a.float() - b.float()).norm() / b.float().norm()).item()
+    for it in range(2):          # second iteration: parameters changed by the FOREIGN optimizer behind the engine's back
+        with rnet:
+            yr = ru(x, torch.tensor(500), encoder_hidden_states=ctx).sample
+        with fnet:
+            yf = m(x, torch.tensor(500), encoder_hidden_states=ctx).sample
+        assert isinstance(m.engine().network, ForeignLoRANetwork)
+        assert rel(yf, yr) < 1e-4, (it, rel(yf, yr))
+        ((yr - tgt) ** 2).mean().backward()
+        ((yf - tgt) ** 2).mean().backward()
+        for a, b in zip(rnet.unet_loras, fnet.unet_loras):
+            assert rel(b.lora_up.weight.grad, a.lora_up.weight.grad) < 1e-3
+        opt_r.step(); opt_f.step()
+        opt_r.zero_grad(); opt_f.zero_grad()
+    # outside `with network:` the multiplier is 0: the frozen model
+    y0 = m(x, torch.tensor(500), encoder_hidden_states=ctx).sample
+    assert rel(y0, ru(x, torch.tensor(500), encoder_hidden_states=ctx).sample) < 1e-4
+    sa, sb = rnet.state_dict(), fnet.state_dict()
+    assert list(sa) == list(sb) and all(rel(sb[k], sa[k]) < 1e-4 for k in sa if "lora_up" in k)

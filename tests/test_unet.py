@@ -582,3 +582,106 @@ def test_lora_ranks_above_16_forward_backward(dev, rank, c3lier):
     assert rel_err(y.float().cpu(), yr.detach()) < 3e-2
     gr = torch.cat([p.grad.reshape(-1) for l in rnet.unet_loras for p in (l.lora_down.weight, l.lora_up.weight)])
     assert rel_err(flat(net, "grad"), gr) < 6e-2
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fp32 compute mode (`train.precision: float32`; csrc/f32.hip)
+# ---------------------------------------------------------------------------------------------------------------------
+def hip_unet_f32(dev, cfg_fn=model_util.tiny_config, ref=None):
+    m = UNet2DConditionModel(cfg_fn())
+    m.load_state_dict((ref or oracle_unet()).state_dict())
+    m = m.to(dev, torch.float32)
+    m.requires_grad_(False)
+    return m
+
+
+def test_fp32_mode_forward_backward_match_oracle(dev):
+    """A model kept in torch.float32 runs the fp32 kernels: forward (LoRA on, c3lier: every conv gather mode carries a
+    LoRA product) and the LoRA gradients agree with the fp32 oracle to fp32 rounding -- `north_star`'s <= 1e-3 with two
+    orders of magnitude to spare (the bf16 path sits at ~1e-2 here)."""
+    from leco_amd.lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV
+    ref = oracle_unet()
+    m = hip_unet_f32(dev)
+    assert m.engine().f32
+    targets = list(DEFAULT_TARGET_REPLACE) + list(UNET_TARGET_REPLACE_MODULE_CONV)
+    with contextlib.redirect_stdout(io.StringIO()):
+        rnet = lora_ref.LoRANetworkRef(ref, rank=8, targets=targets)
+        net = LoRANetwork(m, rank=8, target_replace_modules=targets)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for rl, l in zip(rnet.unet_loras, net.unet_loras):
+            d = torch.randn(rl.lora_down.weight.shape, generator=g) * 0.05
+            u = torch.randn(rl.lora_up.weight.shape, generator=g) * 0.05
+            rl.lora_down.weight.copy_(d); rl.lora_up.weight.copy_(u)
+            l.lora_down.weight.copy_(d); l.lora_up.weight.copy_(u)
+    net.mark_updated()
+    x = torch.randn(2, 4, 16, 16, generator=g); ctx = torch.randn(2, 77, 64, generator=g)
+    tgt = torch.randn(2, 4, 16, 16, generator=g)
+    with net:
+        y = m(x.to(dev), torch.tensor(500), encoder_hidden_states=ctx.to(dev)).sample
+    assert y.dtype == torch.float32
+    ((y - tgt.to(dev)) ** 2).mean().backward()
+    with rnet:
+        yr = ref(x, torch.tensor(500), encoder_hidden_states=ctx).sample
+    ((yr - tgt) ** 2).mean().backward()
+    e_y = rel_err(y.cpu(), yr.detach())
+    gr = torch.cat([p.grad.reshape(-1) for l in rnet.unet_loras for p in (l.lora_down.weight, l.lora_up.weight)])
+    e_g = rel_err(flat(net, "grad"), gr)
+    print(f"fp32 mode: forward rel {e_y:.3g}, LoRA gradients rel {e_g:.3g}")
+    assert e_y < 2e-5 and e_g < 2e-4
+    # LoRA off: the frozen model
+    y0 = m(x.to(dev), torch.tensor(500), encoder_hidden_states=ctx.to(dev)).sample
+    assert rel_err(y0.cpu(), ref(x, torch.tensor(500), encoder_hidden_states=ctx).sample) < 2e-5
+
+
+def test_fp32_mode_fused_step_matches_reference_golden(dev):
+    """The whole fused step in fp32 mode against the goldens generated from the reference's own loop files in fp32
+    (tests/golden/make_golden.py): every quantity to <= 1e-3 -- denoised latents, the four predictions, loss, LoRA
+    gradients, AdamW-updated parameters."""
+    m = hip_unet_f32(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
+    load_lora(net)
+    emb = _golden_emb()
+    settings = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=2.0,
+                                          batch_size=BS, resolution=128, action="erase")
+    pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["target"], emb["positive"], emb["unconditional"],
+                                        emb["neutral"], settings)
+    fs = FusedStep(m, net, create_noise_scheduler("ddim"), N_STEPS, lr=1e-3)
+    loss = fs.step(pair, K, GOLD["latents"].clone())
+    st = fs._state[(BS, 16, 16)]
+    errs = dict(denoised=rel_err(st["x"].cpu(), GOLD["step.denoised"]),
+                target=rel_err(st["plan"].pred.cpu()[BS:], GOLD["step.pred.target"]),
+                positive=rel_err(st["preds"]["positive"].cpu()[BS:], GOLD["step.pred.positive"]),
+                neutral=rel_err(st["preds"]["neutral"].cpu()[BS:], GOLD["step.pred.neutral"]),
+                unconditional=rel_err(st["preds"]["unconditional"].cpu()[BS:], GOLD["step.pred.unconditional"]),
+                loss=abs(loss.item() - GOLD["step.loss"].item()) / GOLD["step.loss"].item(),
+                grads=rel_err(net.grad[:net.numel].cpu(), GOLD["step.grads"]),
+                params=rel_err(net.slab.detach()[:net.numel].cpu(), GOLD["step.params_after"]))
+    print("fp32 mode fused step: " + "  ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert all(v < 1e-3 for v in errs.values()), errs
+
+
+@pytest.mark.gpu
+def test_fp32_mode_sd15_full_size_forward_within_1e3_of_oracle_on_gpu():
+    """`north_star`: predicted noise within 1e-3 relative of the reference UNet on identical latents / timesteps / embeds.
+    SD1.5 architecture at 512^2 (latents 64^2), UNet batch 2, fp32 compute mode vs the fp32 oracle, both on the GPU box."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from conftest import _bind_hip
+    _bind_hip()
+    dev = torch.device("cuda:0")
+    ref, m = _device_models(R.sd15_config(), None, dev, 1234)
+    m.release()
+    m = m.to(torch.float32)
+    m._engine = None                       # the compute mode is fixed when the engine is built
+    m.load_state_dict(ref.state_dict())
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 64, 64, generator=g).to(dev)
+    ctx = torch.randn(2, 77, 768, generator=g).to(dev)
+    with torch.no_grad():
+        gold = ref(x, torch.tensor(500, device=dev), encoder_hidden_states=ctx).sample
+        y = m(x, torch.tensor(500), encoder_hidden_states=ctx).sample
+    err = rel_err(y, gold)
+    print(f"SD1.5 512^2 B=2 fp32 compute mode: rel = {err:.3e} (north_star bar 1e-3)")
+    assert y.dtype == torch.float32 and err <= 1e-3
