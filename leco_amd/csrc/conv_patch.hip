@@ -420,11 +420,51 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             if (cp) {
                 const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
                 *(u32x4*)(cp + (int64_t)m * p.ldc + n) = o;
+                if (p.col_stats) {   // the values as stored (bf16-rounded) go back to the staging tile for the column sums
+                    float* sr = stg + rl * SROW + cc * 8;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        sr[2 * q] = bf2f((bf16_t)(o[q] & 0xffffu));
+                        sr[2 * q + 1] = bf2f((bf16_t)(o[q] >> 16));
+                    }
+                }
             }
             if (p.c_f32) {
                 const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
                 *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n) = o0;
                 *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n + 4) = o1;
+            }
+        }
+        if (p.col_stats && !wsp) {
+            // GroupNorm statistics of the tensor this convolution produces (leco_hip.h): per column {sum, sumsq} over the
+            // round's rows -- thread = (column, one of NSEG row segments) walking down the staged tile, a pair of fp32
+            // atomics per (sample, column, segment); rows outside the problem contribute nothing
+            barrier_keep_dma();
+            constexpr int NSEG = NT / BN, SEGR = (RR + NSEG - 1) / NSEG;
+            const int col = tid % BN, seg = tid / BN, n = n0 + col;
+            if (seg < NSEG && n < N) {
+                float s1 = 0.f, s2 = 0.f;
+                int bcur = -1;
+                for (int rl = seg * SEGR; rl < (seg + 1) * SEGR && rl < RR; ++rl) {
+                    const int r = h * RR + rl;
+                    const int g = g0 + (r >> TWl), xx = x0 + (r & (TW - 1));
+                    if (g >= GROWS || xx >= W) continue;
+                    const int b = (g * W + xx) / p.stats_rows;
+                    if (b != bcur) {
+                        if (bcur >= 0) {
+                            atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2, s1);
+                            atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2 + 1, s2);
+                        }
+                        bcur = b; s1 = 0.f; s2 = 0.f;
+                    }
+                    const float x = stg[rl * SROW + col];
+                    s1 += x;
+                    s2 += x * x;
+                }
+                if (bcur >= 0) {
+                    atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2, s1);
+                    atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2 + 1, s2);
+                }
             }
         }
     }

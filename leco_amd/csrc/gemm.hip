@@ -537,11 +537,50 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             if (cp) {
                 const u32x4 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
                 *(u32x4*)(cp + (int64_t)m * p.ldc + n) = o;
+                if (p.col_stats) {   // the values as stored (bf16-rounded) go back to the staging tile for the column sums
+                    float* sr = stg + rl * SROW + cc * 8;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        sr[2 * r] = bf2f((bf16_t)(o[r] & 0xffffu));
+                        sr[2 * r + 1] = bf2f((bf16_t)(o[r] >> 16));
+                    }
+                }
             }
             if (p.c_f32) {
                 const f32x4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
                 *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n) = o0;
                 *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n + 4) = o1;
+            }
+        }
+        if (p.col_stats && !wsp) {
+            // GroupNorm statistics of the tensor this GEMM produces (leco_hip.h): per column {sum, sumsq} over this half's
+            // rows, one thread per column walking down the staged tile (bank-conflict free), one pair of fp32 atomics per
+            // (sample, column) -- the consumer GroupNorm then needs no reduction pass over the tensor
+            barrier_keep_dma();
+            for (int col = tid; col < BN; col += NT) {
+                const int n = n0 + col;
+                if (n >= N) continue;
+                float s1 = 0.f, s2 = 0.f;
+                int bcur = -1;
+                for (int rl = 0; rl < 64; ++rl) {
+                    const int m = m0 + h * 64 + rl;
+                    if (m >= M) break;
+                    const int b = m / p.stats_rows;
+                    if (b != bcur) {
+                        if (bcur >= 0) {
+                            atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2, s1);
+                            atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2 + 1, s2);
+                        }
+                        bcur = b; s1 = 0.f; s2 = 0.f;
+                    }
+                    const float x = stg[rl * SROW + col];
+                    s1 += x;
+                    s2 += x * x;
+                }
+                if (bcur >= 0) {
+                    atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2, s1);
+                    atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2 + 1, s2);
+                }
             }
         }
     }
@@ -688,6 +727,8 @@ int validate(const leco_gemm_args& a) {
             return fail(-EINVAL, "leco_gemm: t_w needs w_ext, ext_k == 32, t_rows in {16, 32}, 16-byte aligned strides");
     }
     if (a.rowbias && a.rows_per_group <= 0) return fail(-EINVAL, "leco_gemm: rowbias needs rows_per_group");
+    if (a.col_stats && (!a.c || a.stats_rows <= 0 || a.act == LECO_ACT_GEGLU))
+        return fail(-EINVAL, "leco_gemm: col_stats needs a bf16 output, stats_rows > 0 and no fused GEGLU");
     if (a.act == LECO_ACT_GEGLU && (a.n % 128 || !a.c || a.residual || a.rowbias || a.c_f32 || a.ldc % 8))
         return fail(-EINVAL, "leco_gemm: LECO_ACT_GEGLU needs n %% 128 == 0, a bf16 output and no residual / rowbias / fp32 copy");
     if (a.a_mode < LECO_A_PLAIN || a.a_mode > LECO_A_CONV3_TR2) return fail(-EINVAL, "leco_gemm: bad a_mode %d", a.a_mode);
@@ -715,6 +756,8 @@ void splitk_finish_launch(const leco_gemm_args& a, const float* ws, int splits, 
     const int64_t quads = (int64_t)a.m * a.n / 4;
     const int g = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
     hipLaunchKernelGGL(splitk_finish_kernel, dim3(g), dim3(256), 0, s, a, ws, splits);
+    // the finishing kernel is elementwise: the GroupNorm statistics of a split-K output come from one more light pass
+    if (a.col_stats && a.c) (void)leco_colstats(a.c, a.ldc, a.col_stats, a.m / a.stats_rows, a.stats_rows, a.n, (leco_stream_t)s);
 }
 }  // namespace leco
 

@@ -376,6 +376,89 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc src, const bf16_t* 
     }
 }
 
+// ---- GroupNorm from producer-side statistics ----------------------------------------------------------------------
+// The producers of a tensor (GEMM / conv epilogues, leco_gemm_args.col_stats; colstats_kernel below for the rest) leave
+// {sum, sumsq} per (sample, channel).  One block = (sample, a chunk of pixels): it folds the channel sums of its sample
+// into group statistics in LDS (C <= a few thousand values) and then normalises its pixels: ONE pass over the tensor, no
+// reduction over pixels, one launch -- against read + reduce + read + write in gn_block_kernel, or three launches.
+__global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const float* cs0, const float* cs1, const float* gamma,
+                                                              const float* beta, int act, float eps, int hw, int C, int G,
+                                                              int rows_per_block, float* stats, bf16_t* out, int64_t ldo) {
+    __shared__ float gsum[2 * GN_MAX_GROUPS];
+    __shared__ float gmr[2 * GN_MAX_GROUPS];
+    const int tid = (int)threadIdx.x, b = (int)blockIdx.y, cg = C / G, c1n = C - src.c0;
+    __shared__ float part[GN_MAX_GROUPS * 8 * 2];
+    {   // 8 threads per group, each over every 8th channel of the group, combined in a fixed order: all blocks of a sample
+        // arrive at bit-identical group statistics
+        const int g = tid >> 3, pt = tid & 7;
+        float a0 = 0.f, a1 = 0.f;
+        if (g < G)
+            for (int c = g * cg + pt; c < (g + 1) * cg; c += 8) {
+                const float* p = c < src.c0 ? cs0 + ((int64_t)b * src.c0 + c) * 2 : cs1 + ((int64_t)b * c1n + (c - src.c0)) * 2;
+                a0 += p[0];
+                a1 += p[1];
+            }
+        if (g < GN_MAX_GROUPS) { part[tid * 2] = a0; part[tid * 2 + 1] = a1; }
+    }
+    __syncthreads();
+    if (tid < G) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a0 += part[(tid * 8 + k) * 2]; a1 += part[(tid * 8 + k) * 2 + 1]; }
+        gsum[2 * tid] = a0;
+        gsum[2 * tid + 1] = a1;
+        const float inv_n = 1.f / ((float)hw * (float)cg);
+        const float m = gsum[2 * tid] * inv_n, var = gsum[2 * tid + 1] * inv_n - m * m;
+        gmr[2 * tid] = m;
+        gmr[2 * tid + 1] = rsqrtf(fmaxf(var, 0.f) + eps);
+        if (blockIdx.x == 0 && stats) {       // group sums in the layout the backward kernels read
+            stats[((int64_t)b * G + tid) * 2] = gsum[2 * tid];
+            stats[((int64_t)b * G + tid) * 2 + 1] = gsum[2 * tid + 1];
+        }
+    }
+    __syncthreads();
+    const int nvec = C / 8;
+    const int p0 = (int)blockIdx.x * rows_per_block;
+    const int p1 = min(hw, p0 + rows_per_block);
+    const int total = (p1 - p0) * nvec;
+    for (int e = tid; e < total; e += 256) {
+        const int pr = e / nvec, c = (e - pr * nvec) * 8;
+        const int64_t row = (int64_t)b * hw + p0 + pr;
+        float x[8], o[8];
+        unpack8(gn_load(src, row, c), x);
+        const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int g = (c + i) / cg;
+            const float z = (x[i] - gmr[2 * g]) * gmr[2 * g + 1] * (i < 4 ? g0[i] : g1[i - 4]) + (i < 4 ? b0[i] : b1[i - 4]);
+            o[i] = act ? silu(z) : z;
+        }
+        *(u32x4*)(out + row * ldo + c) = pack8(o);
+    }
+}
+// col_stats[b][c] += {sum, sumsq} over a chunk of sample b's rows (tensors whose producer has no statistics epilogue)
+__global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* x, int64_t ld, float* cs, int hw, int C, int rows_per_block) {
+    const int tid = (int)threadIdx.x, b = (int)blockIdx.y, nvec = C / 8;
+    const int p0 = (int)blockIdx.x * rows_per_block, p1 = min(hw, p0 + rows_per_block);
+    for (int v = tid; v < nvec; v += 256) {
+        float s1[8], s2[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+        for (int p = p0; p < p1; ++p) {
+            float xv[8];
+            unpack8(*(const u32x4*)(x + ((int64_t)b * hw + p) * ld + v * 8), xv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            atomicAdd(cs + ((int64_t)b * C + v * 8 + i) * 2, s1[i]);
+            atomicAdd(cs + ((int64_t)b * C + v * 8 + i) * 2 + 1, s2[i]);
+        }
+    }
+}
+
 constexpr int LN_MAXV = 4;  // vectors of 8 per lane => C <= 2048
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -557,6 +640,34 @@ extern "C" int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, i
                        (int64_t)0, (const float*)stats, (const float*)nullptr, gamma, beta, act, eps, hw, c,
                        groups, total, (bf16_t*)y, ldy);
     return check_launch("leco_groupnorm_fwd");
+}
+
+extern "C" int leco_groupnorm_apply_stats(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
+                                          const float* cstats0, const float* cstats1, const float* gamma, const float* beta,
+                                          int32_t batch, int32_t hw, int32_t c, int32_t groups, float eps, int32_t act,
+                                          float* stats, void* y, int64_t ldy, leco_stream_t stream) {
+    int rc = gn_check(c, groups, c0, x1);
+    if (rc) return rc;
+    if (!cstats0 || (x1 && !cstats1)) return fail(-EINVAL, "leco_groupnorm_apply_stats: missing channel statistics");
+    GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
+    // pixels per block: enough blocks to fill the chip (~4 per CU), at least 8 KB of the tensor each
+    int rpb = cdiv((int64_t)batch * hw, 1024);
+    const int min_rows = cdiv(8192, (int64_t)c * 2);
+    if (rpb < min_rows) rpb = min_rows;
+    if (rpb > hw) rpb = hw;
+    hipLaunchKernelGGL(gn_apply_stats_kernel, dim3(cdiv(hw, rpb), batch), dim3(256), 0, (hipStream_t)stream, src, cstats0,
+                       cstats1, gamma, beta, act, eps, hw, c, groups, rpb, stats, (bf16_t*)y, ldy);
+    return check_launch("leco_groupnorm_apply_stats");
+}
+extern "C" int leco_colstats(const void* x, int64_t ld, float* col_stats, int32_t batch, int32_t hw, int32_t c,
+                             leco_stream_t stream) {
+    if (c % 8 || ld % 8) return fail(-EINVAL, "leco_colstats: c=%d / ld must be multiples of 8", c);
+    int rpb = cdiv((int64_t)batch * hw, 1024);
+    if (rpb < 16) rpb = 16;
+    if (rpb > hw) rpb = hw;
+    hipLaunchKernelGGL(colstats_kernel, dim3(cdiv(hw, rpb), batch), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld,
+                       col_stats, hw, c, rpb);
+    return check_launch("leco_colstats");
 }
 
 extern "C" int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,

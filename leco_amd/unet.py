@@ -240,7 +240,7 @@ class UNetOutput:
 class TRef:
     """A row-major [rows][cols] activation view (row stride ``ld``; bf16, or fp32 in the fp32 compute mode) inside a
     device buffer."""
-    __slots__ = ("t", "ptr", "ld", "rows", "cols", "rg", "gparts", "name")
+    __slots__ = ("t", "ptr", "ld", "rows", "cols", "rg", "gparts", "name", "cstats")
 
     def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None, offset: int = 0,
                  rg: bool = False, name: str = ""):
@@ -251,6 +251,7 @@ class TRef:
         self.rg = rg            # requires grad (some LoRA site is upstream)
         self.gparts: List["TRef"] = []
         self.name = name
+        self.cstats: Optional[int] = None   # device address of fp32 [B][cols][2] {sum, sumsq} left by the producer, or None
 
     def cols_view(self, c0: int, c1: int) -> "TRef":
         v = TRef(self.t, self.rows, c1 - c0, self.ld, 0, self.rg, self.name)
@@ -561,6 +562,18 @@ class PlanBuilder:
         self.nbuf = 0
         self.wgrad_problems: List[dict] = []     # LoRA weight gradients of the backward: one grouped launch at its end
         self.wgrad_keep: List = []
+        # GroupNorm statistics from the producers (leco_gemm_args.col_stats): every tensor that feeds a GroupNorm -- the
+        # outputs of the resnet / down / upsampler convolutions, of Transformer2DModel.proj_out and of conv_in -- gets a
+        # fp32 [B][C][2] slice of ONE arena, zeroed by one memset at the head of each forward list; the GroupNorm itself is
+        # then a single apply pass (leco_groupnorm_apply_stats).  Off in deterministic mode (the statistics are accumulated
+        # with fp32 atomics) and in the fp32 mode; LECO_GN_FUSED=0 turns it off for A/B measurements.
+        import os
+        self.gn_fused = (not eng.f32) and (not eng.deterministic) and os.environ.get("LECO_GN_FUSED", "1") != "0"
+        self.stat_used = 0
+        self.stat_arena = None
+        if self.gn_fused:
+            chans = sum(st.n for nm, st in eng.sites.items() if st.conv3 or nm.endswith(".proj_out")) + self.cfg.block_out_channels[0]
+            self.stat_arena = torch.zeros(2 * B * chans + 64, dtype=torch.float32, device=self.dev)
 
     # ---- helpers -----------------------------------------------------------------------------
     def buf(self, name, shape, dtype=None, zero=False) -> torch.Tensor:
@@ -578,6 +591,16 @@ class PlanBuilder:
     def both(self, op: ops.Op):
         self.f_on.append(op)
         self.f_off.append(op)
+
+    def stat_slice(self, cols: int) -> Optional[int]:
+        """Device address of a fresh [B][cols][2] slice of the statistics arena (None when the fusion is off)."""
+        if not self.gn_fused:
+            return None
+        n = 2 * self.B * cols
+        assert self.stat_used + n <= self.stat_arena.numel(), "GroupNorm statistics arena too small"
+        p = self.stat_arena.data_ptr() + 4 * self.stat_used
+        self.stat_used += n
+        return p
 
     def total_grad(self, t: TRef, out: List[ops.Op]) -> Optional[TRef]:
         """Sum of the gradient contributions recorded for ``t`` (None if there are none)."""
@@ -602,7 +625,7 @@ class PlanBuilder:
     def gemm_fwd(self, site: GemmSite, x: Union[TRef, Tuple[TRef, TRef]], name: str, *, conv=None, amode=A_PLAIN,
                  rows: int, residual: Optional[TRef] = None, rowbias=None, rows_per_group=0, ld_rowbias=0,
                  act=ACT_NONE, out: Optional[TRef] = None, out_f32: Optional[torch.Tensor] = None,
-                 bias="site", ldc32_override: int = 0, geglu: bool = False) -> TRef:
+                 bias="site", ldc32_override: int = 0, geglu: bool = False, stats_hw: int = 0) -> TRef:
         if geglu:
             return self._gemm_fwd_geglu(site, x, name, rows)
         xs = x if isinstance(x, tuple) else (x,)
@@ -617,6 +640,11 @@ class PlanBuilder:
                       ldc32=(ldc32_override or (out_f32.shape[-1] if out_f32 is not None else 0)))
         if len(xs) == 2:
             common.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
+        # GroupNorm statistics of the output from this launch's epilogue (not when further LoRA slices accumulate into y)
+        if stats_hw and y is not None and (lora is None or lora.Rp <= 64):
+            y.cstats = self.stat_slice(site.n)
+            if y.cstats is not None:
+                common.update(col_stats=y.cstats, stats_rows=stats_hw)
         a0, lda0 = xs[0].ptr, xs[0].ld
         yptr = y.ptr if y is not None else None
         ldc = y.ld if y is not None else site.n
@@ -808,9 +836,16 @@ class PlanBuilder:
         y = self.act(name, rows, Cc, rg=any(t.rg for t in xs))
         stats = self.buf(name + ".stats", (self.B * G * 2 * 257,), torch.float32)
         x1 = xs[1] if len(xs) == 2 else None
-        self.both(ops.Op("leco_groupnorm_fwd", (xs[0].ptr, xs[0].ld, x1.ptr if x1 else None, x1.ld if x1 else 0,
-                                                xs[0].cols if x1 else 0, gamma.data_ptr(), beta.data_ptr(), self.B, hw,
-                                                Cc, G, eps, act, stats.data_ptr(), y.ptr, y.ld), keep=(xs, y, stats)))
+        if all(t.cstats is not None for t in xs):
+            # the producers left per-(sample, channel) statistics: one apply pass, no reduction over the tensor
+            self.both(ops.Op("leco_groupnorm_apply_stats", (
+                xs[0].ptr, xs[0].ld, x1.ptr if x1 else None, x1.ld if x1 else 0, xs[0].cols if x1 else 0, xs[0].cstats,
+                x1.cstats if x1 else None, gamma.data_ptr(), beta.data_ptr(), self.B, hw, Cc, G, eps, act, stats.data_ptr(),
+                y.ptr, y.ld), keep=(xs, y, stats, self.stat_arena)))
+        else:
+            self.both(ops.Op("leco_groupnorm_fwd", (xs[0].ptr, xs[0].ld, x1.ptr if x1 else None, x1.ld if x1 else 0,
+                                                    xs[0].cols if x1 else 0, gamma.data_ptr(), beta.data_ptr(), self.B, hw,
+                                                    Cc, G, eps, act, stats.data_ptr(), y.ptr, y.ld), keep=(xs, y, stats)))
         if y.rg:
             def bwd():
                 out = self.plan.bwd
@@ -918,7 +953,8 @@ class PlanBuilder:
                           out_f32=temb[:, off:off + cout], ldc32_override=eng.temb_total)
             temb_T = self._last_T
         h1 = self.gemm_fwd(eng.sites[rname + ".conv1"], n1, rname + ".h1", conv=conv, amode=A_CONV3_S1, rows=rows,
-                           rowbias=temb.data_ptr() + 4 * off, rows_per_group=hw, ld_rowbias=eng.temb_total, bias=None)
+                           rowbias=temb.data_ptr() + 4 * off, rows_per_group=hw, ld_rowbias=eng.temb_total, bias=None,
+                           stats_hw=hw)
         if tsite is not None and h1.rg:
             def temb_bwd():
                 out = self.plan.bwd
@@ -939,7 +975,7 @@ class PlanBuilder:
             assert not isinstance(x, tuple)
             sc = x
         return self.gemm_fwd(eng.sites[rname + ".conv2"], n2, rname + ".out", conv=conv, amode=A_CONV3_S1, rows=rows,
-                             residual=sc)
+                             residual=sc, stats_hw=hw)
 
     def basic_block(self, bname: str, hcur: TRef, ctx: TRef, heads: int, hw: int) -> TRef:
         eng = self.eng
@@ -987,7 +1023,7 @@ class PlanBuilder:
         p = self.gemm_fwd(eng.sites[tname + ".proj_in"], n, tname + ".pin", rows=rows)
         for i in range(len(m.transformer_blocks)):
             p = self.basic_block(f"{tname}.transformer_blocks.{i}", p, ctx, self.cfg.heads(level), hw)
-        return self.gemm_fwd(eng.sites[tname + ".proj_out"], p, tname + ".out", rows=rows, residual=x)
+        return self.gemm_fwd(eng.sites[tname + ".proj_out"], p, tname + ".out", rows=rows, residual=x, stats_hw=hw)
 
     # ---- whole network ---------------------------------------------------------------------------
     def build(self) -> Plan:
@@ -1025,6 +1061,9 @@ class PlanBuilder:
         # -- conv_in
         h0 = self.act("conv_in", B * h * w, ch[0])
         self.both(ops.conv_in(P.x_in, eng.conv_in_w, eng.conv_in_b, h0.t, B, h, w, cfg.in_channels, ch[0]))
+        h0.cstats = self.stat_slice(ch[0])
+        if h0.cstats is not None:   # conv_in has no statistics epilogue: one light pass over its output
+            self.both(ops.Op("leco_colstats", (h0.ptr, h0.ld, h0.cstats, B, h * w, ch[0]), keep=(h0, self.stat_arena)))
         cur, hs, ws = h0, h, w
         skips = [h0]
         for i, blk in enumerate(eng.unet.down_blocks):
@@ -1037,7 +1076,7 @@ class PlanBuilder:
             if blk.downsamplers is not None:
                 ho, wo = (hs + 1) // 2, (ws + 1) // 2
                 cur = self.gemm_fwd(S[f"{bn}.downsamplers.0.conv"], cur, f"{bn}.down", conv=(B, ho, wo, hs, ws),
-                                    amode=A_CONV3_S2, rows=B * ho * wo)
+                                    amode=A_CONV3_S2, rows=B * ho * wo, stats_hw=ho * wo)
                 hs, ws = ho, wo
                 skips.append(cur)
         lvl = len(ch) - 1
@@ -1054,7 +1093,7 @@ class PlanBuilder:
                     cur = self.transformer(f"{bn}.attentions.{j}", cur, ctx, level, hs, ws)
             if blk.upsamplers is not None:
                 cur = self.gemm_fwd(S[f"{bn}.upsamplers.0.conv"], cur, f"{bn}.up", conv=(B, 2 * hs, 2 * ws, hs, ws),
-                                    amode=A_CONV3_UP2, rows=B * 4 * hs * ws)
+                                    amode=A_CONV3_UP2, rows=B * 4 * hs * ws, stats_hw=4 * hs * ws)
                 hs, ws = 2 * hs, 2 * ws
         assert (hs, ws) == (h, w), "latent size must be divisible by the down-sampling factor"
         nout = self.groupnorm("conv_norm_out", cur, h * w, ACT_SILU, cfg.norm_eps, "norm_out")
@@ -1071,6 +1110,11 @@ class PlanBuilder:
             if grouped is not None:
                 grouped.keep = (grouped.keep, self.wgrad_keep)
                 P.bwd.append(grouped)
+        if self.gn_fused and self.stat_used:
+            zero = ops.memset(self.stat_arena[:self.stat_used])
+            zero.keep = (self.stat_arena,)
+            self.f_on.insert(0, zero)
+            self.f_off.insert(0, zero)
         self.tape = []
         return P
 
