@@ -89,12 +89,15 @@ typedef struct leco_gemm_args {
     void* t_out;
     int64_t ld_tout;
     /* GroupNorm statistics emitted by the PRODUCER of a tensor (diffusers' GroupNorm re-reads the whole tensor for them;
-     * `north_star`: conv2d / GroupNorm fused): col_stats != NULL accumulates, per (sample, output column), {sum, sum of
-     * squares} of the bf16-ROUNDED values this call stores to c -- fp32 [m / stats_rows][n][2], with fp32 atomics, into a
-     * buffer the caller has zeroed; stats_rows = rows (pixels) per sample.  leco_groupnorm_apply_stats consumes them.
-     * Needs a bf16 output; not with LECO_ACT_GEGLU. */
+     * `north_star`: conv2d / GroupNorm fused): col_stats != NULL accumulates {sum, sum of squares} of the bf16-ROUNDED
+     * values this call stores to c, per sample and per ATOM of stats_atom adjacent output columns -- fp32
+     * [m / stats_rows][n / stats_atom][2], fp32 atomics (a global fp32 atomic costs ~12 ns at its memory channel: one per
+     * atom and tile, not one per column), into a buffer the caller has zeroed.  stats_rows = rows (pixels) per sample;
+     * stats_atom divides every GroupNorm group the tensor will be part of (SD: 320 / 32 = 10 channels).
+     * leco_groupnorm_apply_stats consumes them.  Needs a bf16 output; not with LECO_ACT_GEGLU. */
     float* col_stats;
     int32_t stats_rows;
+    int32_t stats_atom;
 } leco_gemm_args;
 
 int leco_gemm(const leco_gemm_args* args, leco_stream_t stream);
@@ -196,16 +199,20 @@ int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1,
                        const float* stats, int32_t batch, int32_t hw, int32_t c, int32_t groups,
                        float eps, int32_t act, float* bstats, void* dx, int64_t lddx,
                        leco_stream_t stream);
+/* 1 if leco_groupnorm_fwd handles this shape in one launch, 0 if it takes three (statistics, finish, apply) */
+int leco_groupnorm_single_launch(int32_t batch, int32_t hw, int32_t c, int32_t groups);
 /* GroupNorm forward from per-(sample, channel) {sum, sumsq} statistics that the producers of x0 / x1 left behind
  * (leco_gemm_args.col_stats, or leco_colstats for tensors whose producer has no such epilogue): ONE pass over x, no
- * reduction over pixels.  cstats0: fp32 [batch][c0 or c][2] for x0's channels, cstats1: [batch][c - c0][2] for x1's.
- * Also writes stats[b][g] = {sum, sumsq} per group, which leco_groupnorm_bwd expects. */
+ * reduction over pixels.  cstats0: fp32 [batch][(c0 or c) / atom][2] for x0's channels, cstats1: [batch][(c - c0) / atom][2]
+ * for x1's; atom divides c0 and c / groups.  Also writes stats[b][g] = {sum, sumsq} per group, which leco_groupnorm_bwd
+ * expects. */
 int leco_groupnorm_apply_stats(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0, const float* cstats0,
-                               const float* cstats1, const float* gamma, const float* beta, int32_t batch, int32_t hw,
-                               int32_t c, int32_t groups, float eps, int32_t act, float* stats, void* y, int64_t ldy,
-                               leco_stream_t stream);
-/* col_stats[b][ch] += {sum, sumsq} over the hw rows of sample b of a bf16 [batch * hw][c] tensor (row stride ld) */
-int leco_colstats(const void* x, int64_t ld, float* col_stats, int32_t batch, int32_t hw, int32_t c, leco_stream_t stream);
+                               const float* cstats1, int32_t atom, const float* gamma, const float* beta, int32_t batch,
+                               int32_t hw, int32_t c, int32_t groups, float eps, int32_t act, float* stats, void* y,
+                               int64_t ldy, leco_stream_t stream);
+/* col_stats[b][ch / atom] += {sum, sumsq} over the hw rows of sample b of a bf16 [batch * hw][c] tensor (row stride ld) */
+int leco_colstats(const void* x, int64_t ld, float* col_stats, int32_t atom, int32_t batch, int32_t hw, int32_t c,
+                  leco_stream_t stream);
 int leco_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps,
                        int32_t m, int32_t c, void* y, int64_t ldy, float* mean, float* rstd,
                        leco_stream_t stream);

@@ -350,6 +350,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     constexpr int RR = BM * SROW * 4 <= Cf::LDS_BYTES ? BM : ((BM / 2) * SROW * 4 <= Cf::LDS_BYTES ? BM / 2 : 64);
     constexpr int ITEMS = RR * NC8 / NT;
     static_assert(RR * NC8 % NT == 0 && RR % WM == 0, "epilogue items must divide evenly over the threads");
+    static_assert((RR * SROW + (NT / BN) * BN * 2) * 4 <= Cf::LDS_BYTES, "column-sum scratch must fit behind the staging rows");
     float* stg = (float*)lds;
     bf16_t* cp = (bf16_t*)p.c;
     const bf16_t* res = (const bf16_t*)p.residual;
@@ -436,34 +437,64 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             }
         }
         if (p.col_stats && !wsp) {
-            // GroupNorm statistics of the tensor this convolution produces (leco_hip.h): per column {sum, sumsq} over the
-            // round's rows -- thread = (column, one of NSEG row segments) walking down the staged tile, a pair of fp32
-            // atomics per (sample, column, segment); rows outside the problem contribute nothing
+            // GroupNorm statistics of the tensor this convolution produces (leco_hip.h): {sum, sumsq} per sample and ATOM of
+            // stats_atom columns.  Thread = (column, one of NSEG row segments) walks down the staged tile; the partial column
+            // sums meet in LDS and one thread per atom sends ONE pair of fp32 atomics (tiles whose rows belong to several
+            // samples -- the small levels -- send one pair per column, segment and sample instead).
             barrier_keep_dma();
             constexpr int NSEG = NT / BN, SEGR = (RR + NSEG - 1) / NSEG;
+            const int A = p.stats_atom, NA = N / A;
+            float* csum = stg + RR * SROW;                      // [NSEG][BN][2], behind the staging rows
+            // first / last valid row of the round -> one sample?  (rows are TH x TW blocks of the global row space)
+            const int glo = g0 + ((h * RR) >> TWl), ghi_ = g0 + ((h * RR + RR - 1) >> TWl);
+            const int ghi = ghi_ < GROWS ? ghi_ : GROWS - 1;
+            const bool any = glo < GROWS;
+            const bool single = any && (glo * W) / p.stats_rows == (ghi * W + W - 1) / p.stats_rows;
             const int col = tid % BN, seg = tid / BN, n = n0 + col;
-            if (seg < NSEG && n < N) {
+            if (seg < NSEG) {
                 float s1 = 0.f, s2 = 0.f;
                 int bcur = -1;
                 for (int rl = seg * SEGR; rl < (seg + 1) * SEGR && rl < RR; ++rl) {
                     const int r = h * RR + rl;
                     const int g = g0 + (r >> TWl), xx = x0 + (r & (TW - 1));
                     if (g >= GROWS || xx >= W) continue;
-                    const int b = (g * W + xx) / p.stats_rows;
-                    if (b != bcur) {
-                        if (bcur >= 0) {
-                            atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2, s1);
-                            atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2 + 1, s2);
+                    if (!single) {
+                        const int b = (g * W + xx) / p.stats_rows;
+                        if (b != bcur) {
+                            if (bcur >= 0 && n < N) {
+                                atomicAdd(p.col_stats + ((int64_t)bcur * NA + n / A) * 2, s1);
+                                atomicAdd(p.col_stats + ((int64_t)bcur * NA + n / A) * 2 + 1, s2);
+                            }
+                            bcur = b; s1 = 0.f; s2 = 0.f;
                         }
-                        bcur = b; s1 = 0.f; s2 = 0.f;
                     }
                     const float x = stg[rl * SROW + col];
                     s1 += x;
                     s2 += x * x;
                 }
-                if (bcur >= 0) {
-                    atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2, s1);
-                    atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2 + 1, s2);
+                if (single) {
+                    csum[(seg * BN + col) * 2] = s1;
+                    csum[(seg * BN + col) * 2 + 1] = s2;
+                } else if (bcur >= 0 && n < N) {
+                    atomicAdd(p.col_stats + ((int64_t)bcur * NA + n / A) * 2, s1);
+                    atomicAdd(p.col_stats + ((int64_t)bcur * NA + n / A) * 2 + 1, s2);
+                }
+            }
+            if (single) {
+                barrier_keep_dma();
+                const int b = (glo * W) / p.stats_rows, nhi = (n0 + BN < N ? n0 + BN : N);
+                const int a0 = n0 / A, a1 = (nhi - 1) / A;
+                for (int a = a0 + tid; a <= a1; a += NT) {
+                    const int c0 = a * A > n0 ? a * A : n0, c1 = (a + 1) * A < nhi ? (a + 1) * A : nhi;
+                    float s1 = 0.f, s2 = 0.f;
+                    for (int c = c0; c < c1; ++c)
+#pragma unroll
+                        for (int sg = 0; sg < NSEG; ++sg) {
+                            s1 += csum[(sg * BN + c - n0) * 2];
+                            s2 += csum[(sg * BN + c - n0) * 2 + 1];
+                        }
+                    atomicAdd(p.col_stats + ((int64_t)b * NA + a) * 2, s1);
+                    atomicAdd(p.col_stats + ((int64_t)b * NA + a) * 2 + 1, s2);
                 }
             }
         }

@@ -553,33 +553,52 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             }
         }
         if (p.col_stats && !wsp) {
-            // GroupNorm statistics of the tensor this GEMM produces (leco_hip.h): per column {sum, sumsq} over this half's
-            // rows, one thread per column walking down the staged tile (bank-conflict free), one pair of fp32 atomics per
-            // (sample, column) -- the consumer GroupNorm then needs no reduction pass over the tensor
+            // GroupNorm statistics of the tensor this GEMM produces (leco_hip.h): {sum, sumsq} per sample and ATOM of
+            // stats_atom columns.  One thread per column walks down the staged tile (bank-conflict free); the column sums
+            // meet in LDS and one thread per atom sends ONE pair of fp32 atomics (a tile whose rows belong to several samples
+            // -- the small levels -- sends one pair per column and sample instead).
             barrier_keep_dma();
+            const int A = p.stats_atom, NA = N / A;
+            const int mlo = m0 + h * 64, mhi = (mlo + 64 < M ? mlo + 64 : M);
+            float* csum = stg + 64 * SROW;                      // [BN][2], behind the staging rows
+            const bool single = mhi > mlo && mlo / p.stats_rows == (mhi - 1) / p.stats_rows;
             for (int col = tid; col < BN; col += NT) {
                 const int n = n0 + col;
-                if (n >= N) continue;
                 float s1 = 0.f, s2 = 0.f;
                 int bcur = -1;
-                for (int rl = 0; rl < 64; ++rl) {
-                    const int m = m0 + h * 64 + rl;
-                    if (m >= M) break;
-                    const int b = m / p.stats_rows;
-                    if (b != bcur) {
-                        if (bcur >= 0) {
-                            atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2, s1);
-                            atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2 + 1, s2);
-                        }
-                        bcur = b; s1 = 0.f; s2 = 0.f;
-                    }
+                for (int rl = 0; rl < mhi - mlo; ++rl) {
                     const float x = stg[rl * SROW + col];
+                    if (!single) {
+                        const int b = (mlo + rl) / p.stats_rows;
+                        if (b != bcur) {
+                            if (bcur >= 0 && n < N) {
+                                atomicAdd(p.col_stats + ((int64_t)bcur * NA + n / A) * 2, s1);
+                                atomicAdd(p.col_stats + ((int64_t)bcur * NA + n / A) * 2 + 1, s2);
+                            }
+                            bcur = b; s1 = 0.f; s2 = 0.f;
+                        }
+                    }
                     s1 += x;
                     s2 += x * x;
                 }
-                if (bcur >= 0) {
-                    atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2, s1);
-                    atomicAdd(p.col_stats + ((int64_t)bcur * N + n) * 2 + 1, s2);
+                if (single) {
+                    csum[2 * col] = s1;
+                    csum[2 * col + 1] = s2;
+                } else if (bcur >= 0 && n < N) {
+                    atomicAdd(p.col_stats + ((int64_t)bcur * NA + n / A) * 2, s1);
+                    atomicAdd(p.col_stats + ((int64_t)bcur * NA + n / A) * 2 + 1, s2);
+                }
+            }
+            if (single) {
+                barrier_keep_dma();
+                const int b = mlo / p.stats_rows, nhi = (n0 + BN < N ? n0 + BN : N);
+                const int a0 = n0 / A, a1 = (nhi - 1) / A;        // atoms this tile's columns touch (edge atoms partially)
+                for (int a = a0 + tid; a <= a1; a += NT) {
+                    const int c0 = a * A > n0 ? a * A : n0, c1 = (a + 1) * A < nhi ? (a + 1) * A : nhi;
+                    float s1 = 0.f, s2 = 0.f;
+                    for (int c = c0; c < c1; ++c) { s1 += csum[2 * (c - n0)]; s2 += csum[2 * (c - n0) + 1]; }
+                    atomicAdd(p.col_stats + ((int64_t)b * NA + a) * 2, s1);
+                    atomicAdd(p.col_stats + ((int64_t)b * NA + a) * 2 + 1, s2);
                 }
             }
         }
@@ -625,6 +644,94 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const leco_gemm_args
             f32x4 o = {v[0], v[1], v[2], v[3]};
             *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n) = o;
         }
+    }
+}
+
+// Split-K finish that also leaves the GroupNorm statistics of its output (leco_gemm_args.col_stats): one block = a 64-row x
+// 64-column tile, thread (row lane t / 16, 4 columns t % 16) over rows lane, lane + 16, ...; per-column {sum, sumsq} of the
+// bf16-rounded values are combined over the 16 row lanes in LDS and leave as one pair of fp32 atomics per atom (tiles that
+// span samples: one pair per column, row lane and sample).
+__global__ __launch_bounds__(256) void splitk_finish_stats_kernel(const leco_gemm_args p, const float* ws, int splits) {
+    __shared__ float red[16 * 64 * 2];
+    const int M = p.m, N = p.n, A = p.stats_atom, NA = N / A;
+    const int tid = (int)threadIdx.x, rlane = tid >> 4, c4 = tid & 15;
+    const int m0 = (int)blockIdx.y * 64, n = (int)blockIdx.x * 64 + c4 * 4;
+    const int mhi = m0 + 64 < M ? m0 + 64 : M;
+    const bool single = m0 / p.stats_rows == (mhi - 1) / p.stats_rows;
+    bf16_t* cp = (bf16_t*)p.c;
+    const bf16_t* res = (const bf16_t*)p.residual;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    int bcur = -1;
+    auto flush = [&](int b) {
+        for (int r = 0; r < 4; ++r)
+            if (n + r < N) {
+                atomicAdd(p.col_stats + ((int64_t)b * NA + (n + r) / A) * 2, s1[r]);
+                atomicAdd(p.col_stats + ((int64_t)b * NA + (n + r) / A) * 2 + 1, s2[r]);
+            }
+    };
+    if (n < N) {
+        for (int m = m0 + rlane; m < mhi; m += 16) {
+            f32x4 a = *(const f32x4*)(ws + (int64_t)m * N + n);
+            for (int sp = 1; sp < splits; ++sp) {
+                const f32x4 b = *(const f32x4*)(ws + ((int64_t)sp * M + m) * N + n);
+                a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
+            }
+            float v[4] = {a[0], a[1], a[2], a[3]};
+            if (p.bias) {
+                const f32x4 b = *(const f32x4*)(p.bias + n);
+                v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+            }
+            if (p.rowbias) {
+                const f32x4 b = *(const f32x4*)(p.rowbias + (int64_t)(m / p.rows_per_group) * p.ld_rowbias + n);
+                v[0] += b[0]; v[1] += b[1]; v[2] += b[2]; v[3] += b[3];
+            }
+            if (res) {
+                const u32x2 rr = *(const u32x2*)(res + (int64_t)m * p.ldr + n);
+                v[0] += bf2f((bf16_t)(rr[0] & 0xffffu)); v[1] += bf2f((bf16_t)(rr[0] >> 16));
+                v[2] += bf2f((bf16_t)(rr[1] & 0xffffu)); v[3] += bf2f((bf16_t)(rr[1] >> 16));
+            }
+            if (p.act == LECO_ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.f + __expf(-v[r]));
+            }
+            const u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+            *(u32x2*)(cp + (int64_t)m * p.ldc + n) = o;
+            if (p.c_f32) {
+                const f32x4 of = {v[0], v[1], v[2], v[3]};
+                *(f32x4*)(p.c_f32 + (int64_t)m * p.ldc32 + n) = of;
+            }
+            if (!single) {
+                const int b = m / p.stats_rows;
+                if (b != bcur) {
+                    if (bcur >= 0) flush(bcur);
+                    bcur = b;
+                    for (int r = 0; r < 4; ++r) { s1[r] = 0.f; s2[r] = 0.f; }
+                }
+            }
+            const float q[4] = {bf2f((bf16_t)(o[0] & 0xffffu)), bf2f((bf16_t)(o[0] >> 16)), bf2f((bf16_t)(o[1] & 0xffffu)),
+                                bf2f((bf16_t)(o[1] >> 16))};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[r] += q[r]; s2[r] += q[r] * q[r]; }
+        }
+        if (!single && bcur >= 0) flush(bcur);
+    }
+    if (!single) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        red[(rlane * 64 + c4 * 4 + r) * 2] = s1[r];
+        red[(rlane * 64 + c4 * 4 + r) * 2 + 1] = s2[r];
+    }
+    __syncthreads();
+    const int n0 = (int)blockIdx.x * 64, nhi = n0 + 64 < N ? n0 + 64 : N, b = m0 / p.stats_rows;
+    const int a0 = n0 / A, a1 = (nhi - 1) / A;
+    for (int a = a0 + tid; a <= a1; a += 256) {
+        const int c0 = a * A > n0 ? a * A : n0, c1 = (a + 1) * A < nhi ? (a + 1) * A : nhi;
+        float t1 = 0.f, t2 = 0.f;
+        for (int c = c0; c < c1; ++c)
+#pragma unroll
+            for (int l = 0; l < 16; ++l) { t1 += red[(l * 64 + c - n0) * 2]; t2 += red[(l * 64 + c - n0) * 2 + 1]; }
+        atomicAdd(p.col_stats + ((int64_t)b * NA + a) * 2, t1);
+        atomicAdd(p.col_stats + ((int64_t)b * NA + a) * 2 + 1, t2);
     }
 }
 
@@ -727,8 +834,9 @@ int validate(const leco_gemm_args& a) {
             return fail(-EINVAL, "leco_gemm: t_w needs w_ext, ext_k == 32, t_rows in {16, 32}, 16-byte aligned strides");
     }
     if (a.rowbias && a.rows_per_group <= 0) return fail(-EINVAL, "leco_gemm: rowbias needs rows_per_group");
-    if (a.col_stats && (!a.c || a.stats_rows <= 0 || a.act == LECO_ACT_GEGLU))
-        return fail(-EINVAL, "leco_gemm: col_stats needs a bf16 output, stats_rows > 0 and no fused GEGLU");
+    if (a.col_stats && (!a.c || a.stats_rows <= 0 || a.stats_atom <= 0 || a.n % a.stats_atom || a.m % a.stats_rows ||
+                        a.act == LECO_ACT_GEGLU))
+        return fail(-EINVAL, "leco_gemm: col_stats needs a bf16 output, stats_rows | m, stats_atom | n and no fused GEGLU");
     if (a.act == LECO_ACT_GEGLU && (a.n % 128 || !a.c || a.residual || a.rowbias || a.c_f32 || a.ldc % 8))
         return fail(-EINVAL, "leco_gemm: LECO_ACT_GEGLU needs n %% 128 == 0, a bf16 output and no residual / rowbias / fp32 copy");
     if (a.a_mode < LECO_A_PLAIN || a.a_mode > LECO_A_CONV3_TR2) return fail(-EINVAL, "leco_gemm: bad a_mode %d", a.a_mode);
@@ -753,11 +861,14 @@ int validate(const leco_gemm_args& a) {
 }  // namespace
 
 void splitk_finish_launch(const leco_gemm_args& a, const float* ws, int splits, hipStream_t s) {
+    if (a.col_stats && a.c) {
+        // tiled form: the same sums + epilogue, plus the GroupNorm statistics of the output it writes
+        hipLaunchKernelGGL(splitk_finish_stats_kernel, dim3(cdiv(a.n, 64), cdiv(a.m, 64)), dim3(256), 0, s, a, ws, splits);
+        return;
+    }
     const int64_t quads = (int64_t)a.m * a.n / 4;
     const int g = (int)((quads + 255) / 256 < 2048 ? (quads + 255) / 256 : 2048);
     hipLaunchKernelGGL(splitk_finish_kernel, dim3(g), dim3(256), 0, s, a, ws, splits);
-    // the finishing kernel is elementwise: the GroupNorm statistics of a split-K output come from one more light pass
-    if (a.col_stats && a.c) (void)leco_colstats(a.c, a.ldc, a.col_stats, a.m / a.stats_rows, a.stats_rows, a.n, (leco_stream_t)s);
 }
 }  // namespace leco
 

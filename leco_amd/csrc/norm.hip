@@ -381,20 +381,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc src, const bf16_t* 
 // {sum, sumsq} per (sample, channel).  One block = (sample, a chunk of pixels): it folds the channel sums of its sample
 // into group statistics in LDS (C <= a few thousand values) and then normalises its pixels: ONE pass over the tensor, no
 // reduction over pixels, one launch -- against read + reduce + read + write in gn_block_kernel, or three launches.
-__global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const float* cs0, const float* cs1, const float* gamma,
+__global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const float* cs0, const float* cs1, int A, const float* gamma,
                                                               const float* beta, int act, float eps, int hw, int C, int G,
                                                               int rows_per_block, float* stats, bf16_t* out, int64_t ldo) {
     __shared__ float gsum[2 * GN_MAX_GROUPS];
     __shared__ float gmr[2 * GN_MAX_GROUPS];
-    const int tid = (int)threadIdx.x, b = (int)blockIdx.y, cg = C / G, c1n = C - src.c0;
+    const int tid = (int)threadIdx.x, b = (int)blockIdx.y, cg = C / G;
+    const int na0 = src.c0 / A, na1 = (C - src.c0) / A, ag = cg / A;        // atoms of x0 / x1, atoms per group
     __shared__ float part[GN_MAX_GROUPS * 8 * 2];
     {   // 8 threads per group, each over every 8th channel of the group, combined in a fixed order: all blocks of a sample
         // arrive at bit-identical group statistics
         const int g = tid >> 3, pt = tid & 7;
         float a0 = 0.f, a1 = 0.f;
         if (g < G)
-            for (int c = g * cg + pt; c < (g + 1) * cg; c += 8) {
-                const float* p = c < src.c0 ? cs0 + ((int64_t)b * src.c0 + c) * 2 : cs1 + ((int64_t)b * c1n + (c - src.c0)) * 2;
+            for (int a = g * ag + pt; a < (g + 1) * ag; a += 8) {       // atom index in the concatenated channel space
+                const float* p = a < na0 ? cs0 + ((int64_t)b * na0 + a) * 2 : cs1 + ((int64_t)b * na1 + (a - na0)) * 2;
                 a0 += p[0];
                 a1 += p[1];
             }
@@ -437,8 +438,10 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
         *(u32x4*)(out + row * ldo + c) = pack8(o);
     }
 }
-// col_stats[b][c] += {sum, sumsq} over a chunk of sample b's rows (tensors whose producer has no statistics epilogue)
-__global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* x, int64_t ld, float* cs, int hw, int C, int rows_per_block) {
+// col_stats[b][c / A] += {sum, sumsq} over a chunk of sample b's rows (tensors whose producer has no statistics
+// epilogue: conv_in, split-K outputs): column sums in LDS, one pair of atomics per atom and block
+__global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* x, int64_t ld, float* cs, int A, int hw, int C, int rows_per_block) {
+    float* csum = (float*)dyn_lds();                                   // [C][2]
     const int tid = (int)threadIdx.x, b = (int)blockIdx.y, nvec = C / 8;
     const int p0 = (int)blockIdx.x * rows_per_block, p1 = min(hw, p0 + rows_per_block);
     for (int v = tid; v < nvec; v += 256) {
@@ -452,10 +455,15 @@ __global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* x, int64_t 
             for (int i = 0; i < 8; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            atomicAdd(cs + ((int64_t)b * C + v * 8 + i) * 2, s1[i]);
-            atomicAdd(cs + ((int64_t)b * C + v * 8 + i) * 2 + 1, s2[i]);
-        }
+        for (int i = 0; i < 8; ++i) { csum[(v * 8 + i) * 2] = s1[i]; csum[(v * 8 + i) * 2 + 1] = s2[i]; }
+    }
+    __syncthreads();
+    const int na = C / A;
+    for (int a = tid; a < na; a += 256) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int c = a * A; c < (a + 1) * A; ++c) { t1 += csum[2 * c]; t2 += csum[2 * c + 1]; }
+        atomicAdd(cs + ((int64_t)b * na + a) * 2, t1);
+        atomicAdd(cs + ((int64_t)b * na + a) * 2 + 1, t2);
     }
 }
 
@@ -642,31 +650,41 @@ extern "C" int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, i
     return check_launch("leco_groupnorm_fwd");
 }
 
+/* 1: leco_groupnorm_fwd runs this shape as ONE launch (a block owns whole groups); 0: it needs the three-launch
+ * statistics -> finish -> apply path (few, large slices).  The plan builder asks producers for statistics only in the
+ * second case -- measured on MI355X, that is where the producer-side path pays (profiles/r03_groupnorm_fusion.txt). */
+extern "C" int leco_groupnorm_single_launch(int32_t batch, int32_t hw, int32_t c, int32_t groups) {
+    if (groups <= 0 || c % groups) return 1;
+    return gn_use_block_kernel(gn_geom(hw, c, groups), batch, hw, c, groups) ? 1 : 0;
+}
 extern "C" int leco_groupnorm_apply_stats(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
-                                          const float* cstats0, const float* cstats1, const float* gamma, const float* beta,
-                                          int32_t batch, int32_t hw, int32_t c, int32_t groups, float eps, int32_t act,
-                                          float* stats, void* y, int64_t ldy, leco_stream_t stream) {
+                                          const float* cstats0, const float* cstats1, int32_t atom, const float* gamma,
+                                          const float* beta, int32_t batch, int32_t hw, int32_t c, int32_t groups, float eps,
+                                          int32_t act, float* stats, void* y, int64_t ldy, leco_stream_t stream) {
     int rc = gn_check(c, groups, c0, x1);
     if (rc) return rc;
     if (!cstats0 || (x1 && !cstats1)) return fail(-EINVAL, "leco_groupnorm_apply_stats: missing channel statistics");
+    if (atom <= 0 || (c / groups) % atom || (x1 && c0 % atom))
+        return fail(-EINVAL, "leco_groupnorm_apply_stats: atom %d must divide the group size %d and the concat split", atom, c / groups);
     GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
-    // pixels per block: enough blocks to fill the chip (~4 per CU), at least 8 KB of the tensor each
-    int rpb = cdiv((int64_t)batch * hw, 1024);
-    const int min_rows = cdiv(8192, (int64_t)c * 2);
+    // pixels per block: ~2 blocks per CU (every block first folds its sample's atom sums into group statistics), at least
+    // 16 KB of the tensor each
+    int rpb = cdiv((int64_t)batch * hw, 512);
+    const int min_rows = cdiv(16384, (int64_t)c * 2);
     if (rpb < min_rows) rpb = min_rows;
     if (rpb > hw) rpb = hw;
     hipLaunchKernelGGL(gn_apply_stats_kernel, dim3(cdiv(hw, rpb), batch), dim3(256), 0, (hipStream_t)stream, src, cstats0,
-                       cstats1, gamma, beta, act, eps, hw, c, groups, rpb, stats, (bf16_t*)y, ldy);
+                       cstats1, atom, gamma, beta, act, eps, hw, c, groups, rpb, stats, (bf16_t*)y, ldy);
     return check_launch("leco_groupnorm_apply_stats");
 }
-extern "C" int leco_colstats(const void* x, int64_t ld, float* col_stats, int32_t batch, int32_t hw, int32_t c,
+extern "C" int leco_colstats(const void* x, int64_t ld, float* col_stats, int32_t atom, int32_t batch, int32_t hw, int32_t c,
                              leco_stream_t stream) {
-    if (c % 8 || ld % 8) return fail(-EINVAL, "leco_colstats: c=%d / ld must be multiples of 8", c);
-    int rpb = cdiv((int64_t)batch * hw, 1024);
+    if (c % 8 || ld % 8 || atom <= 0 || c % atom) return fail(-EINVAL, "leco_colstats: c=%d (multiple of 8 and of atom %d)", c, atom);
+    int rpb = cdiv((int64_t)batch * hw, 256);        // ~one block per CU: few atomics
     if (rpb < 16) rpb = 16;
     if (rpb > hw) rpb = hw;
-    hipLaunchKernelGGL(colstats_kernel, dim3(cdiv(hw, rpb), batch), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ld,
-                       col_stats, hw, c, rpb);
+    hipLaunchKernelGGL(colstats_kernel, dim3(cdiv(hw, rpb), batch), dim3(256), (size_t)c * 2 * sizeof(float), (hipStream_t)stream,
+                       (const bf16_t*)x, ld, col_stats, atom, hw, c, rpb);
     return check_launch("leco_colstats");
 }
 

@@ -35,7 +35,7 @@ class GemmArgs(C.Structure):
         ("act", C.c_int32),
         ("c", C.c_void_p), ("ldc", C.c_int64), ("c_f32", C.c_void_p), ("ldc32", C.c_int64),
         ("t_w", C.c_void_p), ("ld_tw", C.c_int64), ("t_rows", C.c_int32), ("t_out", C.c_void_p), ("ld_tout", C.c_int64),
-        ("col_stats", C.c_void_p), ("stats_rows", C.c_int32),
+        ("col_stats", C.c_void_p), ("stats_rows", C.c_int32), ("stats_atom", C.c_int32),
     ]
 
 
@@ -157,7 +157,8 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, 
               rows_per_group: int = 0, ld_rowbias: int = 0, residual: Optional[torch.Tensor] = None, ldr: int = 0,
               act: int = ACT_NONE, ldc: Optional[int] = None, out_f32: Optional[torch.Tensor] = None,
               ldc32: int = 0, t_w: Optional[torch.Tensor] = None, t_rows: int = 0,
-              t_out: Optional[torch.Tensor] = None, ld_tout: int = 0, col_stats=None, stats_rows: int = 0) -> GemmArgs:
+              t_out: Optional[torch.Tensor] = None, ld_tout: int = 0, col_stats=None, stats_rows: int = 0,
+              stats_atom: int = 1) -> GemmArgs:
     """Build the argument block for leco_gemm.  ``conv`` = (batch, h_out, w_out, h_in, w_in).
     ``t_w`` ([32][k] stacked lora_down rows) selects the fused down-projection (see include/leco_hip.h)."""
     g = GemmArgs()
@@ -182,7 +183,7 @@ def gemm_args(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor], *, 
     g.c_f32, g.ldc32 = ptr(out_f32), ldc32 or n
     g.t_w, g.ld_tw, g.t_rows = ptr(t_w), k, t_rows
     g.t_out, g.ld_tout = ptr(t_out), ld_tout or 32
-    g.col_stats, g.stats_rows = ptr(col_stats), stats_rows
+    g.col_stats, g.stats_rows, g.stats_atom = ptr(col_stats), stats_rows, stats_atom
     return g
 
 

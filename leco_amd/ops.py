@@ -20,8 +20,8 @@ _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _SIGS = {
     "leco_groupnorm_fwd": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
     "leco_groupnorm_bwd": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
-    "leco_groupnorm_apply_stats": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
-    "leco_colstats": [_vp, _i64, _vp, _i32, _i32, _i32, _vp],
+    "leco_groupnorm_apply_stats": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
+    "leco_colstats": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "leco_layernorm_fwd": [_vp, _i64, _vp, _vp, _f32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     "leco_layernorm_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp],
     "leco_attention_fwd": [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _vp],

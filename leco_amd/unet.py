@@ -566,11 +566,18 @@ class PlanBuilder:
         # outputs of the resnet / down / upsampler convolutions, of Transformer2DModel.proj_out and of conv_in -- gets a
         # fp32 [B][C][2] slice of ONE arena, zeroed by one memset at the head of each forward list; the GroupNorm itself is
         # then a single apply pass (leco_groupnorm_apply_stats).  Off in deterministic mode (the statistics are accumulated
-        # with fp32 atomics) and in the fp32 mode; LECO_GN_FUSED=0 turns it off for A/B measurements.
+        # with fp32 atomics) and in the fp32 mode.  LECO_GN_FUSED: "auto" (default) = only tensors whose GroupNorm would
+        # otherwise take the three-launch path (few large slices: the 64^2 level at UNet batch 4) -- measured, that is where
+        # it pays (-13 us per GroupNorm); "1" = every tensor (2 % SLOWER on the whole step: the one-launch GroupNorm of the
+        # smaller levels is launch-latency bound and the statistics walk costs its producers ~1 us); "0" = off.
         import os
-        self.gn_fused = (not eng.f32) and (not eng.deterministic) and os.environ.get("LECO_GN_FUSED", "1") != "0"
+        self.gn_mode = os.environ.get("LECO_GN_FUSED", "auto")
+        self.gn_fused = (not eng.f32) and (not eng.deterministic) and self.gn_mode != "0"
         self.stat_used = 0
         self.stat_arena = None
+        # statistics are kept per ATOM of adjacent channels: the largest unit that divides every GroupNorm group and every
+        # concat split of the network (SD: 320 / 32 = 10)
+        self.stat_atom = max(1, self.cfg.block_out_channels[0] // self.cfg.norm_num_groups)
         if self.gn_fused:
             chans = sum(st.n for nm, st in eng.sites.items() if st.conv3 or nm.endswith(".proj_out")) + self.cfg.block_out_channels[0]
             self.stat_arena = torch.zeros(2 * B * chans + 64, dtype=torch.float32, device=self.dev)
@@ -592,11 +599,14 @@ class PlanBuilder:
         self.f_on.append(op)
         self.f_off.append(op)
 
-    def stat_slice(self, cols: int) -> Optional[int]:
-        """Device address of a fresh [B][cols][2] slice of the statistics arena (None when the fusion is off)."""
-        if not self.gn_fused:
+    def stat_slice(self, cols: int, hw: int) -> Optional[int]:
+        """Device address of a fresh [B][cols / atom][2] slice of the statistics arena (None when the fusion is off or does
+        not pay for a tensor of this shape)."""
+        if not self.gn_fused or cols % self.stat_atom:
             return None
-        n = 2 * self.B * cols
+        if self.gn_mode == "auto" and hip.lib().leco_groupnorm_single_launch(self.B, hw, cols, self.cfg.norm_num_groups):
+            return None
+        n = 2 * self.B * (cols // self.stat_atom)
         assert self.stat_used + n <= self.stat_arena.numel(), "GroupNorm statistics arena too small"
         p = self.stat_arena.data_ptr() + 4 * self.stat_used
         self.stat_used += n
@@ -642,9 +652,9 @@ class PlanBuilder:
             common.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
         # GroupNorm statistics of the output from this launch's epilogue (not when further LoRA slices accumulate into y)
         if stats_hw and y is not None and (lora is None or lora.Rp <= 64):
-            y.cstats = self.stat_slice(site.n)
+            y.cstats = self.stat_slice(site.n, stats_hw)
             if y.cstats is not None:
-                common.update(col_stats=y.cstats, stats_rows=stats_hw)
+                common.update(col_stats=y.cstats, stats_rows=stats_hw, stats_atom=self.stat_atom)
         a0, lda0 = xs[0].ptr, xs[0].ld
         yptr = y.ptr if y is not None else None
         ldc = y.ld if y is not None else site.n
@@ -836,11 +846,11 @@ class PlanBuilder:
         y = self.act(name, rows, Cc, rg=any(t.rg for t in xs))
         stats = self.buf(name + ".stats", (self.B * G * 2 * 257,), torch.float32)
         x1 = xs[1] if len(xs) == 2 else None
-        if all(t.cstats is not None for t in xs):
+        if all(t.cstats is not None for t in xs) and (Cc // G) % self.stat_atom == 0 and xs[0].cols % self.stat_atom == 0:
             # the producers left per-(sample, channel) statistics: one apply pass, no reduction over the tensor
             self.both(ops.Op("leco_groupnorm_apply_stats", (
                 xs[0].ptr, xs[0].ld, x1.ptr if x1 else None, x1.ld if x1 else 0, xs[0].cols if x1 else 0, xs[0].cstats,
-                x1.cstats if x1 else None, gamma.data_ptr(), beta.data_ptr(), self.B, hw, Cc, G, eps, act, stats.data_ptr(),
+                x1.cstats if x1 else None, self.stat_atom, gamma.data_ptr(), beta.data_ptr(), self.B, hw, Cc, G, eps, act, stats.data_ptr(),
                 y.ptr, y.ld), keep=(xs, y, stats, self.stat_arena)))
         else:
             self.both(ops.Op("leco_groupnorm_fwd", (xs[0].ptr, xs[0].ld, x1.ptr if x1 else None, x1.ld if x1 else 0,
@@ -1061,9 +1071,9 @@ class PlanBuilder:
         # -- conv_in
         h0 = self.act("conv_in", B * h * w, ch[0])
         self.both(ops.conv_in(P.x_in, eng.conv_in_w, eng.conv_in_b, h0.t, B, h, w, cfg.in_channels, ch[0]))
-        h0.cstats = self.stat_slice(ch[0])
+        h0.cstats = self.stat_slice(ch[0], h * w)
         if h0.cstats is not None:   # conv_in has no statistics epilogue: one light pass over its output
-            self.both(ops.Op("leco_colstats", (h0.ptr, h0.ld, h0.cstats, B, h * w, ch[0]), keep=(h0, self.stat_arena)))
+            self.both(ops.Op("leco_colstats", (h0.ptr, h0.ld, h0.cstats, self.stat_atom, B, h * w, ch[0]), keep=(h0, self.stat_arena)))
         cur, hs, ws = h0, h, w
         skips = [h0]
         for i, blk in enumerate(eng.unet.down_blocks):

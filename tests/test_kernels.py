@@ -296,45 +296,47 @@ def test_conv3x3_patch_falls_back_when_not_applicable(dev):
     assert "gemm_kernel" in hip.gemm_describe(g, 7, 1, None, 0)
 
 
-def _col_stats_ref(y_bf, B, HW):
-    """{sum, sumsq} per (sample, column) of the STORED bf16 values."""
-    y = y_bf.float().cpu().reshape(B, HW, -1)
-    return torch.stack([y.sum(1), (y * y).sum(1)], dim=-1)          # [B][C][2]
+def _col_stats_ref(y_bf, B, HW, atom=1):
+    """{sum, sumsq} per (sample, atom of adjacent columns) of the STORED bf16 values."""
+    y = y_bf.float().cpu().reshape(B, HW, -1, atom)
+    return torch.stack([y.sum((1, 3)), (y * y).sum((1, 3))], dim=-1)          # [B][C / atom][2]
 
 
-@pytest.mark.parametrize("kind", ["plain", "plain_split", "conv_old", "conv_patch", "conv_patch_split"])
-def test_producer_side_groupnorm_statistics(dev, kind):
+@pytest.mark.parametrize("atom", [1, 6])
+@pytest.mark.parametrize("kind", ["plain", "plain_split", "conv_old", "conv_patch", "conv_patch_split", "conv_patch_big"])
+def test_producer_side_groupnorm_statistics(dev, kind, atom):
     """leco_gemm_args.col_stats: the GEMM / conv epilogues (gemm.hip, conv_patch.hip) and the split-K finish leave
     {sum, sumsq} per (sample, output column) of the bf16 values they store -- tiles that span samples, ragged rows /
     columns, residual + bias + SiLU in front of the rounding."""
     torch.manual_seed(5)
-    B, H, W_ = 3, 6, 10
+    B, H, W_ = (2, 16, 16) if kind == "conv_patch_big" else (3, 6, 10)      # big: single-sample tiles (the LDS fast path)
     HW, Ci, Co = H * W_, 128, 72
     M = B * HW
     bias = torch.randn(Co).to(dev)
     res = torch.randn(M, Co).to(bf).to(dev)
     out = torch.zeros(M, Co, dtype=bf, device=dev)
-    cs = torch.zeros(B, Co, 2, device=dev)
+    cs = torch.zeros(B, Co // atom, 2, device=dev)
     ws = torch.zeros(4 * M * Co, device=dev)
     if kind.startswith("plain"):
         a = torch.randn(M, Ci).to(bf).to(dev); w = (torch.randn(Co, Ci) / Ci ** 0.5).to(bf).to(dev)
-        g = hip.gemm_args(a, w, out, m=M, n=Co, k=Ci, bias=bias, residual=res, act=hip.ACT_SILU, col_stats=cs, stats_rows=HW)
+        g = hip.gemm_args(a, w, out, m=M, n=Co, k=Ci, bias=bias, residual=res, act=hip.ACT_SILU, col_stats=cs, stats_rows=HW,
+                          stats_atom=atom)
         tile, split = (1, 2) if kind == "plain_split" else (3, 1)
     else:
         x = torch.randn(B, H, W_, Ci).to(bf).to(dev); w = (torch.randn(Co, 9 * Ci) / (9 * Ci) ** 0.5).to(bf).to(dev)
         g = hip.gemm_args(x, w, out, m=M, n=Co, k=9 * Ci, lda=Ci, a_mode=hip.A_CONV3_S1, conv=(B, H, W_, H, W_), bias=bias,
-                          residual=res, act=hip.ACT_SILU, col_stats=cs, stats_rows=HW)
-        tile, split = {"conv_old": (-1, 1), "conv_patch": (9, 1), "conv_patch_split": (7, 2)}[kind]
+                          residual=res, act=hip.ACT_SILU, col_stats=cs, stats_rows=HW, stats_atom=atom)
+        tile, split = {"conv_old": (-1, 1), "conv_patch": (9, 1), "conv_patch_split": (7, 2), "conv_patch_big": (8, 1)}[kind]
     hip.gemm(g, ops.default_stream(), tile=tile, split_k=split, ws=ws)
     _sync(dev)
-    ref = _col_stats_ref(out, B, HW)
+    ref = _col_stats_ref(out, B, HW, atom)
     assert out.float().abs().sum() > 0
     assert rel_err(cs.cpu(), ref) < 1e-5
 
 
-@pytest.mark.parametrize("act,B,HW,C0,C1,G", [(1, 2, 70, 64, 0, 32), (0, 3, 33, 64, 128, 32), (1, 1, 300, 320, 0, 32),
-                                              (1, 2, 16, 1280, 1280, 32)])
-def test_groupnorm_from_channel_statistics(dev, act, B, HW, C0, C1, G):
+@pytest.mark.parametrize("act,B,HW,C0,C1,G,atom", [(1, 2, 70, 64, 0, 32, 2), (0, 3, 33, 64, 128, 32, 2), (1, 1, 300, 320, 0, 32, 10),
+                                                   (1, 2, 16, 1280, 640, 32, 10), (0, 2, 20, 64, 0, 16, 1)])
+def test_groupnorm_from_channel_statistics(dev, act, B, HW, C0, C1, G, atom):
     """leco_colstats + leco_groupnorm_apply_stats == F.group_norm(+SiLU) on the (optionally two-source) input; the group
     sums it leaves in `stats` are what the backward kernel expects (same dx as with leco_groupnorm_fwd's statistics)."""
     torch.manual_seed(HW)
@@ -342,15 +344,15 @@ def test_groupnorm_from_channel_statistics(dev, act, B, HW, C0, C1, G):
     x0 = (torch.randn(B * HW, C0) * 2 + 0.5).to(bf).to(dev)
     x1 = (torch.randn(B * HW, C1) - 0.3).to(bf).to(dev) if C1 else None
     gamma, beta = torch.randn(C).to(dev), torch.randn(C).to(dev)
-    cs0 = torch.zeros(B, C0, 2, device=dev)
-    cs1 = torch.zeros(B, C1, 2, device=dev) if C1 else None
-    ops.Op("leco_colstats", (x0.data_ptr(), C0, cs0.data_ptr(), B, HW, C0)).run()
+    cs0 = torch.zeros(B, C0 // atom, 2, device=dev)
+    cs1 = torch.zeros(B, C1 // atom, 2, device=dev) if C1 else None
+    ops.Op("leco_colstats", (x0.data_ptr(), C0, cs0.data_ptr(), atom, B, HW, C0)).run()
     if C1:
-        ops.Op("leco_colstats", (x1.data_ptr(), C1, cs1.data_ptr(), B, HW, C1)).run()
+        ops.Op("leco_colstats", (x1.data_ptr(), C1, cs1.data_ptr(), atom, B, HW, C1)).run()
     y = torch.zeros(B * HW, C, dtype=bf, device=dev)
     stats = torch.zeros(B * G * 2 * 257, device=dev)
     ops.Op("leco_groupnorm_apply_stats", (x0.data_ptr(), C0, x1.data_ptr() if C1 else None, C1, C0 if C1 else 0, cs0.data_ptr(),
-                                          cs1.data_ptr() if C1 else None, gamma.data_ptr(), beta.data_ptr(), B, HW, C, G, 1e-5,
+                                          cs1.data_ptr() if C1 else None, atom, gamma.data_ptr(), beta.data_ptr(), B, HW, C, G, 1e-5,
                                           act, stats.data_ptr(), y.data_ptr(), C)).run()
     _sync(dev)
     xin = torch.cat([x0] + ([x1] if C1 else []), 1).float().cpu().reshape(B, HW, C).permute(0, 2, 1)

@@ -685,3 +685,24 @@ def test_fp32_mode_sd15_full_size_forward_within_1e3_of_oracle_on_gpu():
     err = rel_err(y, gold)
     print(f"SD1.5 512^2 B=2 fp32 compute mode: rel = {err:.3e} (north_star bar 1e-3)")
     assert y.dtype == torch.float32 and err <= 1e-3
+
+
+def test_unet_forward_with_producer_side_groupnorm_statistics(dev, monkeypatch):
+    """LECO_GN_FUSED=1: EVERY GroupNorm of the pass runs from the statistics its producers left (conv / GEMM / split-K
+    epilogues, colstats after conv_in) -- same result as the reducing GroupNorm kernels ("auto", the default, does this
+    only for the few-large-slices shapes of the 64^2 level, which tiny test models never have)."""
+    monkeypatch.setenv("LECO_GN_FUSED", "1")
+    m = hip_unet(dev)
+    x, ctx = GOLD["unet.x"].to(dev, bf), GOLD["unet.ctx"].to(dev, bf)
+    y = m(x, torch.tensor(500), encoder_hidden_states=ctx).sample.float().cpu()
+    plan = m.engine().plan(x.shape[0], x.shape[2], x.shape[3])
+    names = [op.name for op in plan.lists["fwd_off"]]
+    assert names.count("leco_groupnorm_apply_stats") == 39 and "leco_groupnorm_fwd" not in names and names[0] == "leco_memset"
+    monkeypatch.setenv("LECO_GN_FUSED", "0")
+    m0 = hip_unet(dev)
+    y0 = m0(x, torch.tensor(500), encoder_hidden_states=ctx).sample.float().cpu()
+    assert "leco_groupnorm_apply_stats" not in [op.name for op in m0.engine().plan(x.shape[0], x.shape[2], x.shape[3]).lists["fwd_off"]]
+    gold = GOLD["unet.y_t500"]
+    print(f"fused-statistics GroupNorm: rel vs golden {rel_err(y, gold):.4g} (reducing kernels {rel_err(y0, gold):.4g}), "
+          f"vs each other {rel_err(y, y0):.4g}")
+    assert rel_err(y, gold) <= 1.1 * rel_err(y0, gold) + 1e-3 and rel_err(y, y0) < 1e-2
