@@ -59,6 +59,45 @@ def init_distributed(backend: Optional[str] = None):
     return rank, world, local
 
 
+class StrictReferenceOptimizer:
+    """`--strict_reference`: the reference keeps its LoRA parameters AND the optimizer state in the training precision
+    (`network.to(DEVICE, dtype=weight_dtype)`, train_lora.py:72-78; the optimizer is built on those parameters, :80-89),
+    i.e. bf16 weights, bf16 exp_avg / exp_avg_sq, every elementwise op of the update rounded to bf16.  The fused AdamW
+    keeps fp32 masters instead (a deliberate improvement: an lr = 1e-4 update of a 3e-2 weight is at bf16 resolution).
+    This wrapper reproduces the reference's arithmetic exactly by running THE SAME torch optimizer class on parameters
+    of that dtype: gradients are rounded into them, `step()` runs, the results are written back to the slab (whose
+    values then are bf16-representable).  One small copy per LoRA matrix and step each way: a fidelity mode, not a fast
+    path."""
+
+    def __init__(self, network: LoRANetwork, optimizer_cls, dtype: torch.dtype, **kwargs):
+        self.net, self.dtype = network, dtype
+        self.views = [p for l in network.unet_loras for p in (l.lora_down.weight, l.lora_up.weight)]
+        self.params = [torch.nn.Parameter(v.detach().to(dtype).clone()) for v in self.views]
+        self.opt = optimizer_cls(self.params, **kwargs)
+        self.param_groups = self.opt.param_groups
+
+    def step(self):
+        net = self.net
+        with torch.no_grad():
+            off = 0
+            for p, v in zip(self.params, self.views):       # slab order = view order
+                n = v.numel()
+                p.grad = net.grad[off:off + n].view(v.shape).to(self.dtype)
+                off += n
+            self.opt.step()
+            for p, v in zip(self.params, self.views):
+                v.copy_(p.detach().float())
+
+    def state_dict(self):
+        return self.opt.state_dict()
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd)
+        with torch.no_grad():
+            for p, v in zip(self.params, self.views):
+                p.copy_(v.detach().to(self.dtype))
+
+
 class FusedStep:
     """One optimizer step of LECO training as launch plans on the UNet engine."""
 
@@ -297,7 +336,8 @@ class FusedStep:
         else:   # any torch optimizer over the slab views (prodigy, dadapt*, 8-bit ... when their packages exist)
             if self.world > 1:
                 net.grad.mul_(1.0 / self.world)
-            net.attach_grads()
+            if not isinstance(self.optimizer, StrictReferenceOptimizer):
+                net.attach_grads()
             for group in self.optimizer.param_groups:
                 group["lr"] = lr
             self.optimizer.step()
@@ -393,11 +433,13 @@ def _parse_optimizer_args(s: str) -> dict:
 
 def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[torch.device] = None,
           use_graphs: bool = True, progress: bool = True, xl: bool = False, resume_from: Optional[str] = None,
-          save_state: bool = False, stop_after: Optional[int] = None):
+          save_state: bool = False, stop_after: Optional[int] = None, strict_reference: bool = False):
     """Reference entry point ``train(config, prompts)`` (train_lora.py:34; ``xl=True``: train_lora_xl.py:40).
     Extra keyword arguments only select the device and execution mode, and the resume extension:
     ``save_state`` writes ``{save.name}_state.pt`` next to every saved LoRA, ``resume_from`` continues from one
-    (same config), ``stop_after`` ends the run after that iteration index (used to test resumption)."""
+    (same config), ``stop_after`` ends the run after that iteration index (used to test resumption);
+    ``strict_reference`` keeps the LoRA parameters and the optimizer state in ``train.precision`` like the reference
+    (`StrictReferenceOptimizer`) instead of fp32 masters."""
     rank, world, local = init_distributed()
     if device is None:
         device = torch.device(f"cuda:{local}" if torch.cuda.is_available() else "cpu")
@@ -446,8 +488,8 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
     if world > 1:   # identical LoRA init on every rank ...
         torch.manual_seed(DP_BASE_SEED)
     network = LoRANetwork(unet, rank=config.network.rank, multiplier=1.0, alpha=config.network.alpha,
-                          train_method=config.network.training_method, target_replace_modules=modules
-                          ).to(device, dtype=weight_dtype)
+                          train_method=config.network.training_method, target_replace_modules=modules,
+                          strict_reference=strict_reference).to(device, dtype=weight_dtype)
 
     if world > 1:
         # ... and from here on every rank draws its OWN prompt pair / resolution / crops / latents (the reference's
@@ -467,6 +509,10 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
         fused_opt = opt_name if not (coupled_l2 or unsupported) else None
     else:
         fused_opt = None
+    if strict_reference and weight_dtype != torch.float32:
+        # the reference's own optimizer class on parameters of the training precision (train_lora.py:78-89)
+        fused_opt = StrictReferenceOptimizer(network, train_util.get_optimizer(opt_name), weight_dtype, lr=config.train.lr,
+                                             **optimizer_kwargs)
     if fused_opt is None:
         optimizer_module = train_util.get_optimizer(opt_name)     # ImportError names the missing package
         fused_opt = optimizer_module(network.prepare_optimizer_params(), lr=config.train.lr, **optimizer_kwargs)
@@ -564,4 +610,5 @@ def main(args, xl: bool = False):
     config = config_util.load_config_from_yaml(args.config_file)
     prompts = prompt_util.load_prompts_from_yaml(config.prompts_file)
     train(config, prompts, xl=xl, resume_from=getattr(args, "resume", None),
-          save_state=bool(getattr(args, "save_state", False)))
+          save_state=bool(getattr(args, "save_state", False)),
+          strict_reference=bool(getattr(args, "strict_reference", False)))

@@ -706,3 +706,36 @@ def test_unet_forward_with_producer_side_groupnorm_statistics(dev, monkeypatch):
     print(f"fused-statistics GroupNorm: rel vs golden {rel_err(y, gold):.4g} (reducing kernels {rel_err(y0, gold):.4g}), "
           f"vs each other {rel_err(y, y0):.4g}")
     assert rel_err(y, gold) <= 1.1 * rel_err(y0, gold) + 1e-3 and rel_err(y, y0) < 1e-2
+
+
+def test_strict_reference_optimizer_reproduces_bf16_adamw(dev):
+    """`--strict_reference`: parameters and AdamW state in the training precision (train_lora.py:72-89).  After fused
+    steps the slab equals what torch.optim.AdamW computes on bf16 parameters fed the same (bf16-rounded) gradients -- bit
+    for bit -- and differs from the default fp32-master trajectory."""
+    from leco_amd.train import StrictReferenceOptimizer
+    m = hip_unet(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0, strict_reference=True)
+    load_lora(net)
+    with torch.no_grad():
+        net.slab.detach().copy_(net.slab.detach().to(bf).float())       # the reference holds bf16 parameters
+    net.mark_updated()
+    emb = _golden_emb()
+    settings = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=2.0,
+                                          batch_size=BS, resolution=128, action="erase")
+    pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["target"], emb["positive"], emb["unconditional"],
+                                        emb["neutral"], settings)
+    opt = StrictReferenceOptimizer(net, torch.optim.AdamW, bf, lr=1e-3)
+    fs = FusedStep(m, net, create_noise_scheduler("ddim"), N_STEPS, lr=1e-3, optimizer=opt)
+    shadow = [torch.nn.Parameter(p.detach().clone()) for p in opt.params]       # an independent bf16 AdamW run
+    ref_opt = torch.optim.AdamW(shadow, lr=1e-3)
+    for it in range(2):
+        fs.step(pair, K, GOLD["latents"].clone())
+        off = 0
+        for p in shadow:
+            p.grad = net.grad[off:off + p.numel()].view(p.shape).to(bf)
+            off += p.numel()
+        ref_opt.step()
+        flat_ref = torch.cat([p.detach().float().reshape(-1) for p in shadow])
+        assert torch.equal(net.slab.detach()[:net.numel].cpu(), flat_ref.cpu()), it
+    assert torch.equal(net.slab.detach()[:net.numel], net.slab.detach()[:net.numel].to(bf).float())   # bf16-representable

@@ -11,4 +11,6 @@ if __name__ == "__main__":
     parser.add_argument("--config_file", required=True, help="Config file for training.")
     parser.add_argument("--save_state", action="store_true", help="also write {save.name}_state.pt (resumable state)")
     parser.add_argument("--resume", default=None, help="continue from a {save.name}_state.pt of the same config")
+    parser.add_argument("--strict_reference", action="store_true",
+                        help="LoRA parameters and optimizer state in train.precision, like the reference (default: fp32 masters)")
     main(parser.parse_args(), xl=True)
