@@ -443,11 +443,22 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             for (int j = 0; j < FN; ++j) acc[i][j] = mfma16(wf[j], af[i], acc[i][j]);
     }
 
-    // ---- epilogue through LDS: the accumulators (lane = one row x 4 consecutive n) are staged as fp32,
-    // 64 tile rows at a time, so that the global side of the epilogue (residual / bias reads, bf16 or
-    // fp32-partial stores) moves whole 16..32-byte row segments per lane with full-line coalescing.
+    // ---- epilogue through LDS: the accumulators (lane = one row x 4 consecutive n) are staged as fp32 -- the whole tile at
+    // once where the ring's LDS holds it (RR rows per round, else 64) -- so that the global side of the epilogue (residual /
+    // bias reads, bf16 or fp32-partial stores) moves whole 16..32-byte row segments per lane with full-line coalescing.
+    // Every thread owns ITEMS (row, 8-column) items of a round; their residual loads are all issued before the first is
+    // used: one exposed global latency per round instead of one per item (the short-K projections spend a third of their
+    // time here).
     constexpr int SROW = BN + 4;                 // padded fp32 row (bank spread for the f32x4 writes)
     constexpr int NC8 = BN / 8;
+    constexpr int LDSB = NS * (BM + BN + 16 * TF) * BK * 2;
+#ifdef LECO_GEMM_EPI64      // A/B aid (tools/_ablate builds): the round-2 form, 64 rows per round
+    constexpr int RR = 64;
+#else
+    constexpr int RR = ((BM * SROW + 2 * BN) * 4 <= LDSB && (BM * NC8) % NT == 0) ? BM : 64;
+#endif
+    constexpr bool EVEN = (RR * NC8) % NT == 0;
+    constexpr int ITEMS = (RR * NC8 + NT - 1) / NT;
     float* stg = (float*)dyn_lds();
     bf16_t* cp = (bf16_t*)p.c;
     const bf16_t* res = (const bf16_t*)p.residual;
@@ -462,12 +473,12 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         return;
     }
 #pragma unroll
-    for (int h = 0; h < BM / 64; ++h) {
-        barrier_keep_dma();                      // ring buffers / previous half no longer read
-        if (BM == 64 || (wave_m * WM) / 64 == h) {
+    for (int h = 0; h < BM / RR; ++h) {
+        barrier_keep_dma();                      // ring buffers / previous round no longer read
+        if (RR == BM || (wave_m * WM) / RR == h) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int rl = (wave_m * WM) % 64 + i * 16 + fr;   // row inside this 64-row half
+                const int rl = (wave_m * WM) % RR + i * 16 + fr;   // row inside this round
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
                     *(f32x4*)(stg + rl * SROW + wave_n * WN + j * 16 + 4 * fg) = acc[i][j];
@@ -477,9 +488,9 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         if (BN == 128 && p.act == LECO_ACT_GEGLU) {
             // columns [0, 64) of the tile: value block, [64, 128): its gate block (interleaved weight rows); every
             // thread owns 8 value columns of one row and their 8 gates
-            for (int e = tid; e < 64 * 8; e += NT) {
+            for (int e = tid; e < RR * 8; e += NT) {
                 const int rl = e >> 3, cc = e & 7;
-                const int m = m0 + h * 64 + rl, n = n0 + cc * 8;
+                const int m = m0 + h * RR + rl, n = n0 + cc * 8;
                 if (m >= M) continue;                    // (N % 128 == 0 is validated: the tile is inside the problem)
                 const float* sr = stg + rl * SROW + cc * 8;
                 const f32x4 v0 = *(const f32x4*)sr, v1 = *(const f32x4*)(sr + 4);
@@ -499,9 +510,23 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             }
             continue;
         }
-        for (int e = tid; e < 64 * NC8; e += NT) {
+        u32x4 rres[ITEMS];
+        if (res && !wsp) {
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const int e = tid + it * NT;
+                const int rl = e / NC8, cc = e - rl * NC8;
+                const int m = m0 + h * RR + rl, n = n0 + cc * 8;
+                rres[it] = u32x4{0u, 0u, 0u, 0u};
+                if ((EVEN || e < RR * NC8) && m < M && n < N) rres[it] = *(const u32x4*)(res + (int64_t)m * p.ldr + n);
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int e = tid + it * NT;
+            if (!EVEN && e >= RR * NC8) break;
             const int rl = e / NC8, cc = e - rl * NC8;
-            const int m = m0 + h * 64 + rl, n = n0 + cc * 8;
+            const int m = m0 + h * RR + rl, n = n0 + cc * 8;
             if (m >= M || n >= N) continue;
             const f32x4 v0 = *(const f32x4*)(stg + rl * SROW + cc * 8);
             const f32x4 v1 = *(const f32x4*)(stg + rl * SROW + cc * 8 + 4);
@@ -523,7 +548,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
                 for (int r = 0; r < 4; ++r) { v[r] += b0[r]; v[4 + r] += b1[r]; }
             }
             if (res) {
-                const u32x4 rr = *(const u32x4*)(res + (int64_t)m * p.ldr + n);
+                const u32x4 rr = rres[it];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[2 * r] += bf2f((bf16_t)(rr[r] & 0xffffu));
@@ -559,8 +584,8 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             // -- the small levels -- sends one pair per column and sample instead).
             barrier_keep_dma();
             const int A = p.stats_atom, NA = N / A;
-            const int mlo = m0 + h * 64, mhi = (mlo + 64 < M ? mlo + 64 : M);
-            float* csum = stg + 64 * SROW;                      // [BN][2], behind the staging rows
+            const int mlo = m0 + h * RR, mhi = (mlo + RR < M ? mlo + RR : M);
+            float* csum = stg + RR * SROW;                      // [BN][2], behind the staging rows
             const bool single = mhi > mlo && mlo / p.stats_rows == (mhi - 1) / p.stats_rows;
             for (int col = tid; col < BN; col += NT) {
                 const int n = n0 + col;

@@ -103,8 +103,11 @@ def lib() -> C.CDLL:
                 f"leco_amd: HIP extension {LIB_PATH} is missing. Build it with "
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback.")
-        _lib = C.CDLL(LIB_PATH)
-        _lib_path = LIB_PATH
+        # LECO_HIP_LIB: a side build of the SAME sources with a measurement switch (tools/ablate_gemm.py, A/B runs); the
+        # product library is what loads otherwise
+        path = os.environ.get("LECO_HIP_LIB") or LIB_PATH
+        _lib = C.CDLL(path)
+        _lib_path = path
         _declare(_lib)
     return _lib
 
@@ -118,8 +121,10 @@ def _use_library(path: str) -> None:
 
 
 def is_emulated() -> bool:
+    """True when bound to the host emulator build (tests/emu): a library that is neither the product .so nor a side
+    build named by LECO_HIP_LIB."""
     lib()
-    return _lib_path != LIB_PATH
+    return _lib_path != LIB_PATH and _lib_path != os.environ.get("LECO_HIP_LIB")
 
 
 class LecoError(RuntimeError):

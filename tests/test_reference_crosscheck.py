@@ -147,15 +147,15 @@ def test_loss_and_step_primitives_equal_reference(ref):
     assert torch.equal(ref["train_util"].get_add_time_ids(1024, 1024), train_util.get_add_time_ids(1024, 1024))
 
 
-def test_reference_lora_patch_on_the_hip_unet_fails_loudly(ref):
-    """The reference's own LoRANetwork re-assigns leaf.forward (lora.py:97-100); the launch-plan UNet never calls leaf
-    modules, so the patch would be a silent no-op: the drop-in refuses it (boundary row)."""
+def test_non_lora_forward_patch_on_the_hip_unet_fails_loudly():
+    """A leaf whose `forward` was re-assigned by something that is NOT a LoRA module cannot be honoured (the launch plans
+    never call leaf modules): refused loudly rather than silently ignored."""
     from leco_amd import model_util
     from leco_amd.unet import UNet2DConditionModel
     m = UNet2DConditionModel(model_util.tiny_config())
-    with contextlib.redirect_stdout(io.StringIO()):
-        ref["lora"].LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
-    with pytest.raises(RuntimeError, match="leco_amd.lora.LoRANetwork"):
+    leaf = m.down_blocks[0].attentions[0].proj_in
+    leaf.forward = lambda x: x
+    with pytest.raises(RuntimeError, match="not a LoRA module"):
         m(torch.zeros(2, 4, 16, 16), torch.tensor(1), encoder_hidden_states=torch.zeros(2, 77, 64))
 
 
