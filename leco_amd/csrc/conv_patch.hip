@@ -69,7 +69,11 @@ struct PatchCfg {
     static_assert(64 * SROW * 4 <= LDS_BYTES, "epilogue staging does not fit");
 };
 
-template <int BM, int BN, int NSW>
+// UP2: the convolution runs on the nearest-2x UPSAMPLED input (Upsample2D.conv, LECO_A_CONV3_UP2) -- the patch then lives
+// at INPUT resolution ((TH / 2 + 2) x (TW / 2 + 2) entries for a TH x TW output block: a quarter of the stride-1 patch) and
+// tap (kh, kw) of output pixel (y, x) reads input pixel ((y + kh - 1) >> 1, (x + kw - 1) >> 1); -1 and H_in are the same
+// zero separator rows.
+template <int BM, int BN, int NSW, bool UP2>
 __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p, const PatchRt rt) {
     using Cf = PatchCfg<BM, BN, NSW>;
     constexpr int NW = Cf::NW, NT = NW * 64;
@@ -98,12 +102,18 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     const int st_row = lane >> 3, st_pos = lane & 7;
     const int fr = lane & 15, fg = lane >> 4;
 
-    const int TWl = rt.tw_log2, TW = 1 << TWl, TH = BM >> TWl, PW = TW + 2;
+    const int TWl = rt.tw_log2, TW = 1 << TWl, TH = BM >> TWl;
     const int H = p.h_out, W = p.w_out, GROWS = p.batch * H;
     const int g0 = tile_g * TH, x0 = tile_x * TW, n0 = tile_n * BN;
-    const int v0 = g0 + g0 / H;                                  // virtual row of the tile's first output row
     const int g_last = (g0 + TH < GROWS ? g0 + TH : GROWS) - 1;
-    const int PR = (g_last + g_last / H) - v0 + 3;               // patch rows: v0 - 1 .. v(g_last) + 1
+    // patch geometry in the INPUT image: HD x WD pixels per sample, PW columns starting at input column XLO, virtual rows
+    // VLO .. VLO + PR - 1 (virtual row of input row (b, iy) = b (HD + 1) + iy; iy = -1 / HD are the zero separators)
+    const int HD = UP2 ? p.h_in : H, WD = UP2 ? p.w_in : W;
+    const int PW = UP2 ? (TW >> 1) + 2 : TW + 2, XLO = UP2 ? (x0 >> 1) - 1 : x0 - 1;
+    const int b_first = g0 / H, b_last = g_last / H;
+    const int VLO = UP2 ? b_first * (HD + 1) + ((g0 - b_first * H - 1) >> 1) : g0 + b_first - 1;
+    const int VHI = UP2 ? b_last * (HD + 1) + ((g_last - b_last * H + 1) >> 1) : g_last + b_last + 1;
+    const int PR = VHI - VLO + 1;
     const int M = p.m, N = p.n;
     const int cin = p.k / 9, nchunks = cin / BK;
     const int chunk_begin = (int)(((int64_t)nchunks * split) / rt.split_k);
@@ -163,13 +173,23 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
 
     // ---- fragment addressing.  Activation fragment i of this wave = tile rows r = wave_m * WM + 16 i + fr; its tap
     // (0, 0) patch entry is abase[i]; tap (kh, kw) adds kh * PW + kw.  Weight fragment j = tile rows wave_n * WN + 16 j + fr.
-    int abase[FM];
+    // stride 1: entry = abase[i] + kh PW + kw.  UP2: entry = rp[i][kh] + cq[kw] (row part per vertical tap, column part
+    // ((tx + kw - 1) >> 1) + 1 per horizontal tap).
+    int abase[FM], rp[UP2 ? FM : 1][3], cq[3];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int r = wave_m * WM + i * 16 + fr;
         const int ty = r >> TWl, tx = r & (TW - 1);
         const int g = g0 + ty;
-        abase[i] = g < GROWS ? ((g + (int)(((float)g + 0.5f) * (1.0f / (float)H))) - v0) * PW + tx : 0;
+        const int b = (int)(((float)g + 0.5f) * (1.0f / (float)H));
+        abase[i] = g < GROWS ? (g + b - VLO - 1) * PW + tx : 0;
+        if (UP2) {
+            const int y = g - b * H;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) rp[i][kh] = g < GROWS ? (b * (HD + 1) + ((y + kh - 1) >> 1) - VLO) * PW : 0;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) cq[kw] = g < GROWS ? ((tx + kw - 1) >> 1) + 1 : 0;
+        }
     }
     const int wl0 = (wave_n * WN + fr) * (BK * 2) + ((fg ^ (fr & 7)) << 4);       // ks = 0; ks = 1 flips bit 6
 
@@ -181,11 +201,11 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
 
     bf16x8 afA[FM], wfA[FN], afB[FM], wfB[FN];
     int aoff[FM];                                   // byte offset of the ks = 0 read of the current step (ks = 1: ^ 64)
-    auto read_a0 = [&](int pb, int dtap, bf16x8 (&af)[FM]) {
+    auto read_a0 = [&](int pb, int dtap, bf16x8 (&af)[FM]) {     // (prologue: tap (0, 0))
         const unsigned char* base = lds + OFF_A + pb * PBUF;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int P = abase[i] + dtap;
+            const int P = UP2 ? rp[UP2 ? i : 0][0] + cq[0] : abase[i] + dtap;
             aoff[i] = (P << 7) + ((fg ^ (P & 7)) << 4);
             af[i] = lds_read16_async(base + aoff[i]);
         }
@@ -221,16 +241,16 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     if (chunk_begin < chunk_end) {
 #pragma unroll
         for (int s_ = 0; s_ < NSW - 1; ++s_) issue_w(chunk_begin, s_, s_);
-        const float rpw = 1.0f / (float)PW, rh1 = 1.0f / (float)(H + 1);
+        const float rpw = 1.0f / (float)PW, rh1 = 1.0f / (float)(HD + 1);
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
             const int q = (wave + NW * j) * 8 + st_row;
             const int srow = divf(q, rpw), scol = q - srow * PW;
-            const int v = v0 - 1 + srow;
-            const int vb = v >= 0 ? divf(v, rh1) : 0, vy = v - vb * (H + 1);
-            const int xx = x0 - 1 + scol;
-            const bool ok = (srow < PR) & (v >= 0) & (vy < H) & (vb < p.batch) & (xx >= 0) & (xx < W);
-            ppix[j] = ok ? (unsigned)((vb * H + vy) * W + xx) : DMA_OOB;
+            const int v = VLO + srow;
+            const int vb = v >= 0 ? divf(v, rh1) : 0, vy = v - vb * (HD + 1);
+            const int xx = XLO + scol;
+            const bool ok = (srow < PR) & (v >= 0) & (vy < HD) & (vb < p.batch) & (xx >= 0) & (xx < WD);
+            ppix[j] = ok ? (unsigned)((vb * HD + vy) * WD + xx) : DMA_OOB;
             // The halo / separator entries are the same LDS slots for every chunk and each 16-byte slot is only ever
             // written by its own lane: zero them once, so the halo does not depend on whether the hardware writes zeros
             // for an out-of-range LDS-DMA lane or skips the lane
@@ -256,6 +276,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
         // fragments (x 2 patch buffers) out of the loop and spills; recomputing them costs 5 VALU per read beside 2 FN MFMAs
 #pragma unroll
         for (int i = 0; i < FM; ++i) opaque(abase[i]);
+        if (UP2) { opaque(cq[0]); opaque(cq[1]); opaque(cq[2]); }
         // One tap step; everything that depends on `tap` is a compile-time constant.  Step t consumes weight tile t and
         // issues tile t + NSW - 1 into the slot tile t - 1 vacated at the PREVIOUS step's barrier, so its DMA pieces may go
         // out anywhere in the step.  They are spread evenly over the step's 2 FM FN MFMAs: a vector-memory instruction
@@ -291,9 +312,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             read_w(slot, 1, wfB);
             // byte offsets of the NEXT step's activation fragments: VALU work beside the MFMAs of set A, so that the reads
             // themselves can go out right behind the barrier
+            constexpr int khn = (tap + 1) % 9 / 3, kwn = (tap + 1) % 9 % 3;
 #pragma unroll
             for (int q = 0; q < FM; ++q) {
-                const int Pq = abase[q] + dnext;
+                const int Pq = UP2 ? rp[UP2 ? q : 0][khn] + cq[kwn] : abase[q] + dnext;
                 aoff[q] = (Pq << 7) + ((fg ^ (Pq & 7)) << 4);
             }
             lds_wait<FM + FN>();
@@ -505,24 +527,26 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
 struct PatchGeom { int tw_log2, tiles_g, tiles_x; bool fits; };
 
 PatchGeom patch_geometry(const leco_gemm_args& a, int bm, int pcap) {
-    const int H = a.h_out, W = a.w_out, grows = a.batch * H;
+    const bool up2 = a.a_mode == LECO_A_CONV3_UP2;
+    const int H = a.h_out, W = a.w_out, grows = a.batch * H, hd = up2 ? a.h_in : H;
     // TW: the candidate that wastes fewer output columns; ties go to 16 (fragment rows = 16 consecutive patch
     // entries: conflict-free reads, smaller halo)
     auto cols = [&](int tw) { return cdiv(W, tw) * tw; };
     const int tw = cols(16) <= cols(8) ? 16 : 8;
     PatchGeom g{tw == 16 ? 4 : 3, 0, cdiv(W, tw), true};
-    const int th = bm / tw, pw = tw + 2;
+    const int th = bm / tw, pw = up2 ? tw / 2 + 2 : tw + 2;
     g.tiles_g = cdiv(grows, th);
-    for (int t = 0; t < g.tiles_g; ++t) {
-        const int g0 = t * th, gl = (g0 + th < grows ? g0 + th : grows) - 1;
-        const int pr = (gl + gl / H) - (g0 + g0 / H) + 3;
-        if (pr * pw > pcap) g.fits = false;
+    for (int t = 0; t < g.tiles_g; ++t) {      // the kernel's VLO / VHI
+        const int g0 = t * th, gl = (g0 + th < grows ? g0 + th : grows) - 1, bf = g0 / H, bl = gl / H;
+        const int vlo = up2 ? bf * (hd + 1) + ((g0 - bf * H - 1) >> 1) : g0 + bf - 1;
+        const int vhi = up2 ? bl * (hd + 1) + ((gl - bl * H + 1) >> 1) : gl + bl + 1;
+        if ((vhi - vlo + 1) * pw > pcap) g.fits = false;
     }
     return g;
 }
 
-template <int BM, int BN, int NSW>
-int launch_patch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, char* describe, int describe_len) {
+template <int BM, int BN, int NSW, bool UP2>
+int launch_patch_m(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, char* describe, int describe_len) {
     using Cf = PatchCfg<BM, BN, NSW>;
     const PatchGeom g = patch_geometry(a, BM, Cf::PCAP);
     if (!g.fits) return 1;
@@ -539,25 +563,32 @@ int launch_patch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s,
     dim3 grid((unsigned)(g.tiles_g * g.tiles_x * tn), (unsigned)split_k);
     if (describe) {
         const int used = (int)strlen(describe);
-        snprintf(describe + used, describe_len - used, "%sconv_patch_kernel<%d, %d, %d> grid=%u split=%d", used ? " ; " : "",
-                 BM, BN, NSW, grid.x, split_k);
+        snprintf(describe + used, describe_len - used, "%sconv_patch_kernel<%d, %d, %d, %s> grid=%u split=%d", used ? " ; " : "",
+                 BM, BN, NSW, UP2 ? "true" : "false", grid.x, split_k);
         return 0;
     }
     static bool attr_set[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<BM, BN, NSW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<BM, BN, NSW, UP2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
-    hipLaunchKernelGGL((conv_patch_kernel<BM, BN, NSW>), grid, dim3(512), Cf::LDS_BYTES, s, a, rt);
+    hipLaunchKernelGGL((conv_patch_kernel<BM, BN, NSW, UP2>), grid, dim3(512), Cf::LDS_BYTES, s, a, rt);
     return 0;
+}
+template <int BM, int BN, int NSW>
+int launch_patch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, char* describe, int describe_len) {
+    if (a.a_mode == LECO_A_CONV3_UP2) return launch_patch_m<BM, BN, NSW, true>(a, split_k, ws, s, describe, describe_len);
+    return launch_patch_m<BM, BN, NSW, false>(a, split_k, ws, s, describe, describe_len);
 }
 
 bool patch_applicable(const leco_gemm_args& a) {
-    if (a.a_mode != LECO_A_CONV3_S1 || a.a_ext || a.t_w || a.act == LECO_ACT_GEGLU) return false;
-    return a.h_in == a.h_out && a.w_in == a.w_out;
+    if (a.a_ext || a.t_w || a.act == LECO_ACT_GEGLU) return false;
+    if (a.a_mode == LECO_A_CONV3_S1) return a.h_in == a.h_out && a.w_in == a.w_out;
+    if (a.a_mode == LECO_A_CONV3_UP2) return a.h_out == 2 * a.h_in && a.w_out == 2 * a.w_in;
+    return false;
 }
 }  // namespace
 

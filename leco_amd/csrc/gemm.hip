@@ -918,8 +918,9 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         split_k = 1;
     }
     static const bool no_patch = getenv("LECO_NO_CONV_PATCH") != nullptr;      // A/B switch for measurements
-    if (tile == 0 && args->a_mode == LECO_A_CONV3_S1 && !no_patch) {
-        // 3x3 / stride-1 convolutions: the patch-staged kernel (conv_patch.hip) with the launch shape of its cost model
+    if (tile == 0 && (args->a_mode == LECO_A_CONV3_S1 || args->a_mode == LECO_A_CONV3_UP2) && !no_patch) {
+        // 3x3 / stride-1 convolutions (plain or on the 2x upsampled input): the patch-staged kernel (conv_patch.hip) with the
+        // launch shape of its cost model
         int sp = 1;
         const int t = conv_patch_choose(*args, workspace ? workspace_bytes : 0, split_k, &sp);
         if (t) { tile = t; split_k = sp; }

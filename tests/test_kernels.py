@@ -288,6 +288,31 @@ def test_conv3x3_patch_staged(dev, tile, B, H, W_, Ci, Co, ks, split):
     assert rel_err(out.cpu(), ref) < TOLBF
 
 
+@pytest.mark.parametrize("tile,B,Hi,Wi,Ci,Co,split", [(7, 1, 8, 8, 64, 128, 1), (8, 2, 5, 12, 128, 160, 1), (9, 3, 4, 4, 192, 72, 3),
+                                                      (10, 2, 12, 8, 64, 200, 1), (7, 2, 16, 16, 64, 64, 1)])
+def test_conv3x3_patch_staged_on_upsampled_input(dev, tile, B, Hi, Wi, Ci, Co, split):
+    """conv_patch.hip on LECO_A_CONV3_UP2 (Upsample2D: nearest-2x, then 3x3): the patch is staged at INPUT resolution;
+    vs F.conv2d(F.interpolate(x, 2x)) -- tiles over several images, ragged rows / columns, TW = 8 and 16, split-K."""
+    torch.manual_seed(tile * 10 + Hi)
+    H, W_ = 2 * Hi, 2 * Wi
+    x = torch.randn(B, Ci, Hi, Wi).to(bf)
+    wt = (torch.randn(Co, Ci, 3, 3) / (9 * Ci) ** 0.5).to(bf)
+    bias = torch.randn(Co)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wh = wt.permute(0, 2, 3, 1).contiguous().reshape(Co, 9 * Ci).to(dev)
+    M = B * H * W_
+    o32 = torch.zeros(M, Co, device=dev)
+    bias_d = bias.to(dev)
+    g = hip.gemm_args(xh, wh, None, m=M, n=Co, k=9 * Ci, lda=Ci, a_mode=hip.A_CONV3_UP2, conv=(B, H, W_, Hi, Wi), out_f32=o32,
+                      bias=bias_d)
+    assert "conv_patch_kernel" in hip.gemm_describe(g, tile, 1, None, 0) and ", true>" in hip.gemm_describe(g, tile, 1, None, 0)
+    ws = torch.zeros(split * M * Co, device=dev) if split > 1 else None
+    hip.gemm(g, ops.default_stream(), tile=tile, split_k=split, ws=ws)
+    _sync(dev)
+    ref = F.conv2d(F.interpolate(x.float(), scale_factor=2.0, mode="nearest"), wt.float(), padding=1) + bias[None, :, None, None]
+    assert rel_err(o32.cpu(), ref.permute(0, 2, 3, 1).reshape(M, Co)) < TOL32
+
+
 def test_conv3x3_patch_falls_back_when_not_applicable(dev):
     """Tile ids 7..10 on a problem the patch kernel does not cover (stride 2) run the implicit-GEMM kernel instead."""
     g = hip.gemm_args(torch.zeros(2 * 8 * 8, 64, dtype=bf, device=dev), torch.zeros(64, 576, dtype=bf, device=dev),

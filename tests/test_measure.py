@@ -25,9 +25,9 @@ def test_describe_names_the_instantiation_the_dispatcher_would_launch():
     # 3x3 / stride-1 convolutions: the patch-staged kernel, launch shape from its cost model -- the level-0 conv fills the
     # chip in one round of 128x160 tiles; deep K / small M is split over whole channel chunks
     g0 = _args(16384, 320, 2880, a_mode=hip.A_CONV3_S1, conv=(4, 64, 64, 64, 64))
-    assert hip.gemm_describe(g0, 0, 0, wsp, wsb) == "conv_patch_kernel<128, 160, 4> grid=256 split=1"
+    assert hip.gemm_describe(g0, 0, 0, wsp, wsb) == "conv_patch_kernel<128, 160, 4, false> grid=256 split=1"
     d = hip.gemm_describe(_args(1024, 1280, 11520, a_mode=hip.A_CONV3_S1, conv=(4, 16, 16, 16, 16)), 0, 0, wsp, wsb)
-    assert d.startswith("conv_patch_kernel<128, 128, 4> grid=80 split=3"), d
+    assert d.startswith("conv_patch_kernel<128, 128, 4, false> grid=80 split=3"), d
     # tile = -1 pins the implicit-GEMM family (what other gathers, and LoRA-carrying convs, run)
     assert hip.gemm_describe(g0, -1, 0, wsp, wsb).startswith("gemm_kernel<128, 160, true, 4, 4, 0> grid=256 split=1")
     d = hip.gemm_describe(_args(1024, 1280, 11520, a_mode=hip.A_CONV3_S1, conv=(4, 16, 16, 16, 16)), -1, 0, wsp, wsb)
