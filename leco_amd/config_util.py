@@ -23,7 +23,7 @@ class PretrainedModelConfig(BaseModel):
     clip_skip: Optional[int] = None
 
 
-MAX_LORA_RANK = 128        # lierla: stacked q|k|v columns run as chained 64-wide K-extension steps above 64
+MAX_LORA_RANK = 4096        # lierla: stacked q|k|v columns run as chained 64-wide K-extension steps above 64
 MAX_LORA_RANK_C3LIER = 64  # conv LoRA: the low-rank image is one 64-channel tensor
 
 

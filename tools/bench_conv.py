@@ -52,6 +52,10 @@ def main():
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--quick", action="store_true", help="fewer split candidates")
+    ap.add_argument("--blas", action="store_true",
+                    help="also time the vendor library (torch.matmul -> hipBLASLt / rocBLAS) on the plain [M][K] x [K][N] bf16 GEMM "
+                         "of the same size: the 'achievable' denominator for an MFMA contraction of that shape (measurement only; "
+                         "never on the product path)")
     a = ap.parse_args()
     shapes = {"sd15": SD15, "sd21": SD21, "sdxl": SDXL}[a.arch]
     s = ops.default_stream()
@@ -80,6 +84,12 @@ def main():
             rc = fn(C.byref(g), tile, split, ws.data_ptr(), ws.numel() * 4, s)
             assert rc == 0, hip.lib().leco_last_error()
         t_base = timeit(lambda: run(bt, bs_), iters)
+        t_blas = None
+        if a.blas:
+            am = (torch.rand(M, K, device=dev) * 2 - 1).to(bf)
+            wm = w.t().contiguous()
+            t_blas = timeit(lambda: torch.matmul(am, wm), iters)
+            del am, wm
         ref = o32.clone() if a.check else None
         res = {}
         tiles = -(-M // 256)
@@ -105,7 +115,8 @@ def main():
         top = sorted(res.items(), key=lambda kv: kv[1])[:6]
         print(f"{hw:3d}^2 {c0:4d}+{c1:<4d}->{co:4d} x{cnt:2d}  base({bt},{bs_}) {t_base:7.1f} ({flops / t_base / 1e6:5.0f})  "
               f"best p{best[0]}/{best[1]} {tb:7.1f} ({flops / tb / 1e6:5.0f})  x{t_base / tb:4.2f} | "
-              + "  ".join(f"p{t}/{sp} {us:.1f}" for (t, sp), us in top), flush=True)
+              + "  ".join(f"p{t}/{sp} {us:.1f}" for (t, sp), us in top)
+              + (f"  | vendor GEMM {t_blas:.1f} us ({flops / t_blas / 1e6:.0f} TF/s)" if t_blas else ""), flush=True)
     print(f"# conv time per UNet pass: base {total_base / 1e3:.3f} ms -> best-of {total_best / 1e3:.3f} ms")
 
 

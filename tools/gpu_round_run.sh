@@ -1,33 +1,61 @@
 #!/bin/bash
-# Round artefacts in ONE GPU call (profiles/ files are copied from gpurun_out/ afterwards):
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round_run.sh [notests]'
-# 1. kernel trace of the benchmark command  -> r02_step_kernel_stats.txt (its top row names the dominant kernel)
-# 2. counter passes (separate runs, --pmc only) over exactly the dominant kernel's launches of one step
-#    (`bench.py --dominant-only`) -> r02_pmc_dominant_{mfma,fetch}.csv; and over a whole eager step (k = 4)
-# 3. the benchmark itself (reads the files of 1 and 2)  -> r02_bench.json
-# 4. the GPU test tier + smoke                          -> r02_gpu_tests.log, smoke.log
+# Round artefacts on the GPU box (profiles/ files are copied from gpurun_out/ afterwards):
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round_run.sh [measure|tests|configs]'
+# measure: 1. kernel trace of the benchmark command (--no-dominant: the step's own launches only) -> rNN_step_kernel_stats.txt
+#             (its top row names the dominant kernel)
+#          2. counter passes (separate runs, --pmc only) over exactly the dominant kernel's launches of one step
+#             (`bench.py --dominant-only`) -> rNN_pmc_dominant_{mfma,fetch}.csv (headers carry the kernel-source hash that
+#             bench.py checks before quoting them); and over a whole eager step (k = 4)
+#          3. the benchmark itself (reads the files of 1 and 2)  -> rNN_bench.json
+#          4. every launch of the denoising pass in isolation   -> rNN_plan_denoise.txt;  smoke()
+# tests:   the GPU test tier                                    -> rNN_gpu_tests.log
+# configs: BASELINE configs 3-5: launch-shape tuning + bench    -> rNN_bench_*.json, rNN_tune_*.txt
+RN=${ROUND:-r03}
 R=$PWD; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
+what=${1:-measure}
+if [ "$what" = "measure" ]; then
 cd /tmp
-timeout 150 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /tmp/prof.log 2>&1
+timeout 150 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dominant > /tmp/prof.log 2>&1
 DB=$(find /tmp/prof -name "*.db" | head -1)
-{ echo "# cd /tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline   (round 2; tools/gpu_round_run.sh)"
+{ echo "# cd /tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dominant   (tools/gpu_round_run.sh)"
   echo "# SD1.5 bs=2 512^2 rank-4 LECO step; summarised from the rocpd database with tools/rocpd_stats.py"
-  python $R/tools/rocpd_stats.py $DB 60; } > $O/r02_step_kernel_stats.txt 2>&1
-cp $O/r02_step_kernel_stats.txt $R/profiles/r02_step_kernel_stats.txt       # bench.py --dominant-only reads the top row
+  python $R/tools/rocpd_stats.py $DB 60; } > $O/${RN}_step_kernel_stats.txt 2>&1
+cp $O/${RN}_step_kernel_stats.txt $R/profiles/${RN}_step_kernel_stats.txt       # bench.py --dominant-only reads the top row
 timeout 100 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_dm -o dom -- python $R/bench.py --dominant-only --no-cpu-baseline > /tmp/pmc_dm.log 2>&1
-python $R/tools/pmc_summary.py /tmp/pmc_dm > $O/r02_pmc_dominant_mfma.csv 2>&1
+python $R/tools/pmc_summary.py /tmp/pmc_dm > $O/${RN}_pmc_dominant_mfma.csv 2>&1
 timeout 100 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d /tmp/pmc_df -o dom -- python $R/bench.py --dominant-only --no-cpu-baseline > /tmp/pmc_df.log 2>&1
-python $R/tools/pmc_summary.py /tmp/pmc_df > $O/r02_pmc_dominant_fetch.csv 2>&1
-cp $O/r02_pmc_dominant_mfma.csv $O/r02_pmc_dominant_fetch.csv $R/profiles/
-timeout 130 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_mfma -o bench -- python $R/bench.py --steps 1 --warmup 0 --k 4 --no-cpu-baseline --no-graphs > /tmp/pmc1.log 2>&1
-python $R/tools/pmc_summary.py /tmp/pmc_mfma > $O/r02_pmc_mfma_step.csv 2>&1
-timeout 110 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d /tmp/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --k 4 --no-cpu-baseline --no-graphs > /tmp/pmc2.log 2>&1
-python $R/tools/pmc_summary.py /tmp/pmc_fetch > $O/r02_pmc_fetch_step.csv 2>&1
+python $R/tools/pmc_summary.py /tmp/pmc_df > $O/${RN}_pmc_dominant_fetch.csv 2>&1
+cp $O/${RN}_pmc_dominant_mfma.csv $O/${RN}_pmc_dominant_fetch.csv $R/profiles/
+timeout 130 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_mfma -o bench -- python $R/bench.py --steps 1 --warmup 0 --k 4 --no-cpu-baseline --no-graphs --no-dominant > /tmp/pmc1.log 2>&1
+python $R/tools/pmc_summary.py /tmp/pmc_mfma > $O/${RN}_pmc_mfma_step.csv 2>&1
+timeout 110 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d /tmp/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --k 4 --no-cpu-baseline --no-graphs --no-dominant > /tmp/pmc2.log 2>&1
+python $R/tools/pmc_summary.py /tmp/pmc_fetch > $O/${RN}_pmc_fetch_step.csv 2>&1
 cd $R
-( timeout 400 python bench.py 2>/dev/null | tail -1 ) > $O/r02_bench.json
-if [ "$1" != "notests" ]; then
-  ( timeout 900 python -m pytest tests -q -m gpu -s 2>&1 | grep -vE "^W2026|Warn|warn|hipGraph|\^~|^ +[0-9]+ \|" | tail -90 ) > $O/r02_gpu_tests.log 2>&1
-  ( timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ) > $O/smoke.log 2>&1
-  tail -4 $O/r02_gpu_tests.log; cat $O/smoke.log
+( timeout 900 python bench.py 2>/dev/null | tail -1 ) > $O/${RN}_bench.json
+( timeout 150 python tools/plan_profile.py --list denoise --top 45 2>/dev/null ) > $O/${RN}_plan_denoise.txt
+( timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ) > $O/${RN}_smoke.log 2>&1
+cut -c1-1800 $O/${RN}_bench.json; head -14 $O/${RN}_step_kernel_stats.txt; head -4 $O/${RN}_pmc_dominant_mfma.csv; head -4 $O/${RN}_pmc_dominant_fetch.csv; tail -3 /tmp/pmc_dm.log; cat $O/${RN}_smoke.log
 fi
-cut -c1-1500 $O/r02_bench.json; head -12 $O/r02_step_kernel_stats.txt; head -4 $O/r02_pmc_dominant_mfma.csv; head -3 $O/r02_pmc_dominant_fetch.csv; tail -3 /tmp/pmc_dm.log
+if [ "$what" = "tests" ]; then
+  ( timeout 1300 python -m pytest tests -q -m gpu -s 2>&1 | grep -vE "^W2026|Warn|warn|hipGraph|\^~|^ +[0-9]+ \|" | tail -150 ) > $O/${RN}_gpu_tests.log 2>&1
+  tail -5 $O/${RN}_gpu_tests.log
+fi
+if [ "$what" = "configs" ]; then
+T=leco_amd/gemm_tune_gfx950.json
+timeout 200 python tools/tune_report.py --arch sd21 --res 768 --bs 2 --rank 4 --out $T > $O/${RN}_tune_sd21.txt 2>/dev/null; tail -2 $O/${RN}_tune_sd21.txt
+timeout 250 python tools/tune_report.py --arch sdxl --res 1024 --bs 1 --rank 16 --out $T > $O/${RN}_tune_sdxl.txt 2>/dev/null; tail -2 $O/${RN}_tune_sdxl.txt
+timeout 200 python tools/tune_report.py --arch sd15 --res 512 --bs 4 --rank 8 --c3lier --out $T > $O/${RN}_tune_c3lier.txt 2>/dev/null; tail -2 $O/${RN}_tune_c3lier.txt
+timeout 200 python tools/tune_report.py --arch sd15 --res 512 --bs 2 --rank 4 --out $T > $O/${RN}_tune_sd15.txt 2>/dev/null; tail -2 $O/${RN}_tune_sd15.txt
+cp $T $O/gemm_tune_gfx950.json
+( timeout 200 python bench.py --arch sd21 --res 768 --v-pred --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 ) > $O/${RN}_bench_sd21_768.json
+( timeout 300 python bench.py --arch sdxl --res 1024 --bs 1 --rank 16 --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 ) > $O/${RN}_bench_sdxl_1024.json
+( timeout 200 python bench.py --bs 4 --rank 8 --c3lier --steps 6 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 ) > $O/${RN}_bench_sd15_c3lier_bs4.json
+( timeout 200 python bench.py --no-cpu-baseline --no-dominant 2>/dev/null | tail -1 ) > $O/${RN}_bench_after_tune.json
+for f in ${RN}_bench_sd21_768 ${RN}_bench_sdxl_1024 ${RN}_bench_sd15_c3lier_bs4 ${RN}_bench_after_tune; do python - $O/$f.json <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read()); print(sys.argv[1].split('/')[-1], round(d['value'],3),'steps/s', round(d['ms_per_step'],1),'ms k_mean',d['config']['k_mean'],'whole-step frac',round(d['roofline']['whole_step']['frac'],3),'loss',d['config']['loss'], 'dom', d['roofline']['kernel'].get('name'), round(d['roofline'].get('frac',0),3))
+except Exception as e: print(sys.argv[1], 'FAILED', e)
+PY
+done
+fi
