@@ -23,7 +23,7 @@ class PretrainedModelConfig(BaseModel):
     clip_skip: Optional[int] = None
 
 
-MAX_LORA_RANK = 4096        # lierla: stacked q|k|v columns run as chained 64-wide K-extension steps above 64
+MAX_LORA_RANK = None       # lierla: any rank, like the reference (lora.py:49-95): stacked q|k|v columns above 64 run as chained 64-wide K-extension steps
 MAX_LORA_RANK_C3LIER = 64  # conv LoRA: the low-rank image is one 64-channel tensor
 
 
@@ -35,10 +35,11 @@ class NetworkConfig(BaseModel):
 
     @model_validator(mode="after")
     def _rank_fits_the_lora_kernels(self):
-        # the reference accepts any rank; fail at config time, not after the model has loaded (README "Limits")
+        # the reference accepts any rank; the conv LoRA path has a cap: fail at config time, not after the model has
+        # loaded (README "Limits")
         cap = MAX_LORA_RANK_C3LIER if self.type == "c3lier" else MAX_LORA_RANK
-        if not 1 <= self.rank <= cap:
-            raise ValueError(f"network.rank={self.rank}: network.type {self.type} supports ranks 1..{cap}")
+        if self.rank < 1 or (cap is not None and self.rank > cap):
+            raise ValueError(f"network.rank={self.rank}: network.type {self.type} supports ranks 1..{cap or 'any'}")
         return self
 
 

@@ -31,7 +31,7 @@ from typing import List, Optional
 
 import torch
 
-from . import config_util, model_util, ops, prompt_util, train_util
+from . import config_util, model_util, ops, prompt_util, trace, train_util
 from .config_util import RootConfig
 from .lora import DEFAULT_TARGET_REPLACE, UNET_TARGET_REPLACE_MODULE_CONV, LoRANetwork
 from .prompt_util import PromptEmbedsCache, PromptEmbedsPair, PromptSettings
@@ -252,6 +252,7 @@ class FusedStep:
         k = int(timesteps_to)
         n = self.n_steps
         # 1. partial denoising with LoRA on (train_lora.py:179-193)
+        trace.push(f"denoise k={k}")
         net.multiplier = 1.0
         unet.prepare((2 * bs, 4, h, w), lora_on=True)   # re-packs LoRA operands if the slab changed
         x = st["x"]
@@ -278,7 +279,9 @@ class FusedStep:
                 else:
                     st["noise"].normal_()      # fresh ancestral noise (device RNG, like diffusers' randn_tensor)
             self._run(dplan, "denoise")
+        trace.pop()
         # 2. frozen predictions at the "current" timestep (train_lora.py:195-237)
+        trace.push("frozen predictions")
         t_cur = int(self.sched.num_train_timesteps - 1 - int(k * self.sched.num_train_timesteps / n))
         if self.generic:
             # sigma-space schedulers: the UNet input of the remaining passes is x / sqrt(sigma(t_cur)^2 + 1)
@@ -300,23 +303,32 @@ class FusedStep:
         fplan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])
         fplan.t_idx.copy_(self.slot_idx)
         self._run(fplan, "fwd_off")
+        trace.pop()
         # 3. target prediction with LoRA on; activations stay resident for the backward
+        trace.push("target forward")
         net.multiplier = 1.0
         plan.ctx.copy_(self._ctx(pair, "target", bs))
         self._run(plan, "fwd_on")
+        trace.pop()
         # 4. ESD objective + gradient w.r.t. the raw target prediction
+        trace.push("loss + backward")
         ops.esd_loss(plan.pred, st["preds"]["positive"], st["preds"]["neutral"], st["preds"]["unconditional"], 1.0,
                      float(pair.guidance_scale), pair.sign, st["half_n"], self.loss, plan.dpred).run()
         # 5. backward into the flat gradient slab
         net.grad.zero_()
         self._run(plan, "bwd")
         net.multiplier = 0  # the reference leaves the `with network:` block here
+        trace.pop()
         # 6. data parallel: one all-reduce of the LoRA gradient slab
         if self.world > 1:
             import torch.distributed as dist
+            trace.push("all_reduce LoRA gradients")
             dist.all_reduce(net.grad, group=self.pg)
+            trace.pop()
         # 7. optimizer on the fp32 master slab (+ bf16 shadow)
+        trace.push("optimizer")
         self.apply_optimizer(lr)
+        trace.pop()
         return self.loss
 
     def apply_optimizer(self, lr: Optional[float] = None) -> None:

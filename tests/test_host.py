@@ -305,3 +305,35 @@ def test_tuning_switch_variants_stay_correct(env, select):
                         "-m", "not gpu", "-k", select, "-p", "no:cacheprovider"],
                        cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_roctx_ranges_bracket_the_step_phases(monkeypatch):
+    """LECO_ROCTX=1: every push has its pop and the phase names of a step appear in order (leco_amd/trace.py; the library
+    call itself is replaced by a recorder -- librocprofiler-sdk-roctx needs no GPU, but the test should not depend on it)."""
+    from leco_amd import trace
+
+    class Rec:
+        def __init__(self):
+            self.ev = []
+
+        def roctxRangePushA(self, s):
+            self.ev.append(("push", s.decode()))
+            return 0
+
+        def roctxRangePop(self):
+            self.ev.append(("pop", None))
+            return 0
+    rec = Rec()
+    monkeypatch.setattr(trace, "_on", True)
+    monkeypatch.setattr(trace, "_lib", rec)
+    trace.push("denoise k=3")
+    trace.pop()
+    assert rec.ev == [("push", "denoise k=3"), ("pop", None)] and trace.enabled()
+    monkeypatch.setattr(trace, "_on", False)
+    trace.push("x")
+    trace.pop()
+    assert len(rec.ev) == 2                              # disabled: nothing recorded
+    import inspect
+    from leco_amd.train import FusedStep
+    src = inspect.getsource(FusedStep.step)
+    assert src.count("trace.push(") == src.count("trace.pop()") == 6
