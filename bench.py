@@ -157,15 +157,20 @@ def _launch_identity(op):
         names = [p.split(" grid=")[0] for p in parts]
         ext = g.ext_k if (g.a_ext or g.t_w) else 0
         key = (op.name, g.m, g.n, g.k, g.a_mode, ext, bool(g.t_w), bool(g.residual), g.act, g.batch, g.h_in, g.h_out, a[1], a[2])
-        return names, key, 2.0 * g.m * g.n * (g.k + ext)
+        kin = g.k // 9 if g.a_mode else g.k
+        rows_in = g.m if g.a_mode == 0 else g.batch * g.h_in * g.w_in
+        # algorithmic operand bytes: every input / weight / output element once (bf16), + the residual read
+        by = 2.0 * (rows_in * kin + g.n * g.k + g.m * g.n * (0.5 if g.act == 2 else 1.0) + (g.m * g.n if g.residual else 0))
+        return names, key, 2.0 * g.m * g.n * (g.k + ext), by
     if op.name == "leco_attention_fwd":
         B, H, sq, skv, d = a[13], a[14], a[15], a[16], a[17]
         qf = 2 if -(-sq // 128) * H * B >= 1024 else 1
-        return [f"attn_fwd_kernel<{d}, {qf}, {'true' if skv % 64 else 'false'}>"], (op.name, B, H, sq, skv, d), 4.0 * B * H * sq * skv * d
+        return ([f"attn_fwd_kernel<{d}, {qf}, {'true' if skv % 64 else 'false'}>"], (op.name, B, H, sq, skv, d),
+                4.0 * B * H * sq * skv * d, 2.0 * B * H * d * (2 * sq + 2 * skv))
     if op.name == "leco_attention_bwd":
         B, H, sq, skv, d = a[26], a[27], a[28], a[29], a[30]
-        return ["attention_bwd(3 kernels)"], (op.name, B, H, sq, skv, d), 10.0 * B * H * sq * skv * d
-    return [op.name], (op.name,) + tuple(x for x in a if isinstance(x, int) and 0 <= x < (1 << 20)), 0.0
+        return ["attention_bwd(3 kernels)"], (op.name, B, H, sq, skv, d), 10.0 * B * H * sq * skv * d, 2.0 * B * H * d * (4 * sq + 4 * skv)
+    return [op.name], (op.name,) + tuple(x for x in a if isinstance(x, int) and 0 <= x < (1 << 20)), 0.0, 0.0
 
 
 def step_launches(st, k_mean):
@@ -202,6 +207,19 @@ def _pmc_row(path, name):
     return None
 
 
+def _time_launch_us(op, reps=8):
+    """One plan launch in isolation: HIP events on the compute stream around back-to-back repeats (L2-warm)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        op.run()
+    e0.record()
+    for _ in range(reps):
+        op.run()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
 def dominant_kernel_roofline(st, k_mean, only_replay=False):
     """Times every distinct launch of a step in isolation (HIP events on the compute stream, L2-warm repeats), attributes
     each to its kernel instantiation, picks the instantiation with the largest share of the step and reports its
@@ -210,52 +228,68 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False):
     launches = step_launches(st, k_mean)
     groups = {}                                   # shape key -> [op, names, flops, launches per step]
     for op, w in launches:
-        names, key, fl = _launch_identity(op)
-        g = groups.setdefault(key, [op, names, fl, 0.0])
+        names, key, fl, by = _launch_identity(op)
+        g = groups.setdefault(key, [op, names, fl, 0.0, by])
         g[3] += w
     top = _profile_top_row()
     if only_replay:
         # counter pass: replay the dominant instantiation's launches with their per-step multiplicities, nothing else
         want = top["name"] if top else None
         n = 0
-        for op, names, fl, w in groups.values():
+        for op, names, fl, w, _by in groups.values():
             if want is not None and names == [want]:
                 for _ in range(max(1, int(round(w)))):
                     op.run()
                     n += 1
         torch.cuda.synchronize()
         return {"replayed": n, "kernel": want}
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     per_name = {}
-    for key, (op, names, fl, w) in groups.items():
-        for _ in range(2):
-            op.run()
-        e0.record()
-        for _ in range(8):
-            op.run()
-        e1.record()
-        e1.synchronize()
-        us = e0.elapsed_time(e1) / 8 * 1e3
+    for key, (op, names, fl, w, by) in groups.items():
+        us = _time_launch_us(op)
         name = names[0] if len(names) == 1 else " + ".join(names)
-        a = per_name.setdefault(name, [0.0, 0.0, 0.0, {}])
+        a = per_name.setdefault(name, [0.0, 0.0, 0.0, {}, 0.0])
         a[0] += w            # launches per step
         a[1] += w * us       # us per step
         a[2] += w * fl       # flops per step
         a[3][key] = (w, us, fl)
+        a[4] += w * by       # algorithmic operand bytes per step
     total_us = sum(a[1] for a in per_name.values())
-    name, (n, us, fl, shapes) = max(per_name.items(), key=lambda kv: kv[1][1])
-    achieved = fl / us / 1e6 if us else 0.0       # TFLOP/s
-    heavy = max(shapes.items(), key=lambda kv: kv[1][0] * kv[1][1])
-    out = {"name": name, "launches_per_step": n, "us_per_launch": us / n, "flops_per_launch": fl / n,
-           "share_of_step_kernel_time": us / total_us, "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-           "frac": achieved / (PEAK_BF16 / 1e12), "distinct_shapes": len(shapes),
-           "heaviest_shape": {"key": [str(x) for x in heavy[0][1:9]], "launches_per_step": heavy[1][0], "us": heavy[1][1],
-                              "tflops": heavy[1][2] / heavy[1][1] / 1e6 if heavy[1][1] else 0.0},
-           "profile_top_row": top,
-           "agrees_with_profile": bool(top and top["name"] == name)}
+    cur = kernel_sources_hash()
+    ranked = sorted(per_name.items(), key=lambda kv: -kv[1][1])
+    live_name = ranked[0][0]
+    # The dominant kernel is the top row of the committed kernel trace of this very command WHEN that trace was taken on
+    # the kernel sources that are running (hash in its header) -- the trace, the counter passes (`--dominant-only` replays
+    # that row's launches) and this line then describe the same kernel.  Two instantiations within a percent of each other
+    # can swap places between the trace (launches in step order) and the isolated live timing; without a current trace the
+    # live ranking decides.
+    name = top["name"] if (top and top["name"] in per_name and _summary_hash(PROFILE_STATS) == cur) else live_name
+
+    def describe_kernel(nm):
+        n, us, fl, shapes, by = per_name[nm]
+        achieved = fl / us / 1e6 if us else 0.0       # TFLOP/s
+        heavy = max(shapes.items(), key=lambda kv: kv[1][0] * kv[1][1])
+        return {"name": nm, "launches_per_step": n, "us_per_launch": us / n, "flops_per_launch": fl / n,
+                "algorithmic_bytes_per_launch": by / n,
+                "share_of_step_kernel_time": us / total_us, "achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                "frac": achieved / (PEAK_BF16 / 1e12), "distinct_shapes": len(shapes),
+                "heaviest_shape": {"key": [str(x) for x in heavy[0][1:9]], "launches_per_step": heavy[1][0], "us": heavy[1][1],
+                                   "tflops": heavy[1][2] / heavy[1][1] / 1e6 if heavy[1][1] else 0.0}}
+    out = describe_kernel(name)
+    out.update({"profile_top_row": top, "live_top": live_name, "agrees_with_profile": bool(top and top["name"] == name)})
+    # the next instantiations by share of the step (live timing), each with its own fraction of the MFMA peak and -- from the
+    # same counter files, which also hold the launches of the plan-building pass -- its MFMA-busy share
+    out["next_kernels"] = []
+    for nm, _ in ranked[:4]:
+        if nm == name:
+            continue
+        d = describe_kernel(nm)
+        row = _pmc_row(PMC_MFMA, nm) if _summary_hash(PMC_MFMA) == cur else None
+        if row and row.get("GRBM_GUI_ACTIVE"):
+            d["mfma_busy"] = row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (row["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+        d.pop("heaviest_shape")
+        out["next_kernels"].append(d)
     # counter passes are separate rocprofv3 runs (tools/gpu_round_run.sh); their summaries are only quoted when they were
     # taken on THESE kernel sources (hash in the header) and every number names the file it comes from
-    cur = kernel_sources_hash()
     out["kernel_sources"] = cur
     fetch = _pmc_row(PMC_FETCH, name) if _summary_hash(PMC_FETCH) == cur else None
     mfma = _pmc_row(PMC_MFMA, name) if _summary_hash(PMC_MFMA) == cur else None

@@ -69,3 +69,59 @@ def test_bench_attributes_launches_to_kernel_trace_rows(tmp_path, monkeypatch):
     assert row and row["calls"] > 0 and 0.05 < row["SQ_VALU_MFMA_BUSY_CYCLES"] / (row["GRBM_GUI_ACTIVE"] / 8 * 1024) < 1
     assert bench._pmc_row(bench.PMC_FETCH, top["name"])["FETCH_SIZE"] > 0
     assert bench.step_flops(2, 25) == 2 * 2 * 0.8033e12 * (25 + 5 + 0.157)
+
+
+def test_bench_dominant_kernel_accounting_on_a_tiny_step(monkeypatch):
+    """bench.dominant_kernel_roofline over the plans of a real (tiny, emulated) step, with the per-launch clock replaced by a
+    FLOP-proportional fake: every launch of the step is attributed to a kernel instantiation, the dominant one carries
+    launches / FLOPs / algorithmic bytes per launch and the runners-up ride along -- the accounting the GPU run relies on."""
+    import contextlib
+    import io
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    import bench
+    from leco_amd import hip, model_util, prompt_util
+    from leco_amd.lora import LoRANetwork
+    from leco_amd.scheduler import create_noise_scheduler
+    from leco_amd.train import FusedStep
+    from leco_amd.unet import UNet2DConditionModel
+    hip._use_library(build_emu.build())
+    try:
+        _dominant_accounting(bench, monkeypatch)
+    finally:
+        hip._use_library(hip.LIB_PATH)      # the other tests of this file dry-run the real dispatcher
+        hip._lib_path = hip.LIB_PATH
+
+
+def _dominant_accounting(bench, monkeypatch):
+    import contextlib
+    import io
+    from leco_amd import model_util, prompt_util
+    from leco_amd.lora import LoRANetwork
+    from leco_amd.scheduler import create_noise_scheduler
+    from leco_amd.train import FusedStep
+    from leco_amd.unet import UNet2DConditionModel
+    m = model_util.init_synthetic_(UNet2DConditionModel(model_util.tiny_config()), 1234).to(torch.bfloat16)
+    m.requires_grad_(False)
+    m.use_graphs = False
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(m, rank=4)
+    eg = torch.Generator().manual_seed(5)
+    emb = [torch.randn(1, 77, 64, generator=eg) for _ in range(4)]
+    s_ = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=2.0, batch_size=1,
+                                    resolution=128)
+    pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb[0], emb[1], emb[2], emb[3], s_)
+    fs = FusedStep(m, net, create_noise_scheduler("ddim"), 10, lr=1e-3)
+    fs.step(pair, 1, torch.randn(1, 4, 16, 16, generator=eg))
+    st = fs._state[(1, 16, 16)]
+    launches = bench.step_launches(st, 3.0)
+    assert len(launches) > 100 and all(len(bench._launch_identity(op)) == 4 for op, _ in launches[:50])
+    monkeypatch.setattr(bench, "_time_launch_us", lambda op, reps=8: 5.0 + bench._launch_identity(op)[2] / 1e9)
+    monkeypatch.setattr(bench, "PROFILE_STATS", os.path.join(ROOT, "profiles", "does_not_exist.txt"))
+    d = bench.dominant_kernel_roofline(st, 3.0)
+    assert d["name"] == d["live_top"] and d["profile_top_row"] is None and not d["agrees_with_profile"]
+    assert d["launches_per_step"] > 0 and d["flops_per_launch"] > 0 and d["algorithmic_bytes_per_launch"] > 0
+    assert 0 < d["share_of_step_kernel_time"] < 1 and len(d["next_kernels"]) == 3
+    assert all(k["name"] != d["name"] and "frac" in k for k in d["next_kernels"])
+    assert d["traffic"] is None or d["traffic"] > 0

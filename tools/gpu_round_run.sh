@@ -19,6 +19,7 @@ timeout 150 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py 
 DB=$(find /tmp/prof -name "*.db" | head -1)
 { echo "# cd /tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dominant   (tools/gpu_round_run.sh)"
   echo "# SD1.5 bs=2 512^2 rank-4 LECO step; summarised from the rocpd database with tools/rocpd_stats.py"
+  echo "# csrc_sha1=$(cd $R && python -c 'import bench; print(bench.kernel_sources_hash())')"
   python $R/tools/rocpd_stats.py $DB 60; } > $O/${RN}_step_kernel_stats.txt 2>&1
 cp $O/${RN}_step_kernel_stats.txt $R/profiles/${RN}_step_kernel_stats.txt       # bench.py --dominant-only reads the top row
 timeout 100 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_dm -o dom -- python $R/bench.py --dominant-only --no-cpu-baseline > /tmp/pmc_dm.log 2>&1

@@ -64,6 +64,10 @@ def main():
     ap.add_argument("--rank", type=int, default=4)
     ap.add_argument("--top", type=int, default=45)
     ap.add_argument("--iters", type=int, default=12)
+    ap.add_argument("--blas", action="store_true",
+                    help="also time the vendor library (torch.matmul -> hipBLASLt / rocBLAS, bf16) on the bare [M][K] x [K][N] product "
+                         "of every plain GEMM shape: the 'achievable' denominator for a contraction of that size WITHOUT the "
+                         "epilogue work (bias / residual / GEGLU / LoRA) the plan's launch carries -- measurement only")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     tok, te, unet, sched = model_util.load_models(f"synthetic:{args.arch}", "ddim")
@@ -95,7 +99,20 @@ def main():
     for _ in range(20):
         (x @ x).sum().item()      # clock ramp
     groups = OrderedDict()
+    blas = {}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def vendor_us(m, n, k):
+        a_ = (torch.rand(m, k, device=dev) * 2 - 1).to(torch.bfloat16)
+        b_ = (torch.rand(k, n, device=dev) * 2 - 1).to(torch.bfloat16)
+        for _ in range(3):
+            torch.matmul(a_, b_)
+        e0.record()
+        for _ in range(args.iters):
+            torch.matmul(a_, b_)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.iters * 1e3
     for op in ops_:
         for _ in range(3):
             op.run()
@@ -106,6 +123,9 @@ def main():
         torch.cuda.synchronize()
         us = e0.elapsed_time(e1) / args.iters * 1e3
         key, fl, by = describe(op)
+        if args.blas and key.startswith("gemm plain") and key not in blas:
+            g_ = op.keep[0]
+            blas[key] = vendor_us(g_.m, g_.n, g_.k)
         gsum = groups.setdefault(key, [0, 0.0, 0.0, 0.0])
         gsum[0] += 1
         gsum[1] += us
@@ -128,7 +148,13 @@ def main():
           f"list back-to-back (eager) {whole/1e3:.3f} ms, {tfl/1e12:.3f} TFLOP -> {tfl/whole/1e6:.1f} TFLOP/s")
     print(f"{'%':>6} {'n':>4} {'us each':>9} {'TFLOP/s':>8} {'GB/s':>8}  op")
     for key, (n, us, fl, by) in sorted(groups.items(), key=lambda kv: -kv[1][1])[:args.top]:
-        print(f"{100*us/tot:6.2f} {n:4d} {us/n:9.1f} {fl/us/1e6 if fl else 0:8.1f} {by/us/1e3:8.0f}  {key}")
+        print(f"{100*us/tot:6.2f} {n:4d} {us/n:9.1f} {fl/us/1e6 if fl else 0:8.1f} {by/us/1e3:8.0f}  {key}"
+              + (f"   | vendor GEMM {blas[key]:.1f} us (x{us / n / blas[key]:.2f})" if key in blas else ""))
+    if blas:
+        ours = sum(us for key, (n, us, fl, by) in groups.items() if key in blas)
+        theirs = sum(n * blas[key] for key, (n, us, fl, by) in groups.items() if key in blas)
+        print(f"# plain GEMMs of the list: {ours/1e3:.3f} ms here (with their epilogues and fused LoRA) vs {theirs/1e3:.3f} ms for "
+              f"the bare vendor GEMMs of the same M, N, K")
     fam = OrderedDict()
     for key, (n, us, fl, by) in groups.items():
         f = " ".join(key.split()[:2]) if key.startswith("gemm") else key.split()[0]
