@@ -421,8 +421,14 @@ def test_sd15_full_size_forward_vs_oracle_on_gpu():
     m.use_graphs = True
     y2 = m(x, torch.tensor(500), encoder_hidden_states=ctx).sample.float()
     y3 = m(x, torch.tensor(500), encoder_hidden_states=ctx).sample.float()
-    # (not bitwise: GroupNorm statistics are accumulated with fp32 atomics, so a few bf16 roundings flip)
-    assert rel_err(y2, y3) < 5e-3 and rel_err(y2, y) < 5e-3
+    # Not bitwise and not even close to it: the GroupNorm statistics of the 64^2 level come from the producers' epilogues
+    # through fp32 atomics (LECO_GN_FUSED=auto), so two replays round a few normalised values differently, and sixty bf16
+    # layers later the rounding noise of the two runs is decorrelated -- they differ by ~sqrt(2) x their distance from the
+    # oracle.  What must hold: every replay is as close to the oracle as the eager run (LECO_DETERMINISTIC=1 switches the
+    # atomics off; `test_training_state_resume_is_bit_exact` covers that mode).
+    e2, e3 = rel_err(y2, gold), rel_err(y3, gold)
+    print(f"  graph replays: rel {e2:.4g} / {e3:.4g} vs oracle, {rel_err(y2, y3):.4g} between them")
+    assert e2 <= 1.25 * cal and e3 <= 1.25 * cal and rel_err(y2, y3) <= 2.0 * cal and rel_err(y2, y) <= 2.0 * cal
 
 
 def test_training_state_resume_is_bit_exact(dev, tmp_path):
