@@ -50,7 +50,7 @@ def _make(world, pg=None):
 
 
 def _lat(rank):
-    return torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(100 + rank))
+    return torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(100 + rank))
 
 
 def _worker(rank, world, port, q):
@@ -59,7 +59,9 @@ def _worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     fs, net, pair = _make(world)
     fs.step(pair, 1, _lat(rank))
-    q.put((rank, net.slab.detach()[:net.numel].clone(), net.grad[:net.numel].clone()))
+    # numpy, not torch: a tensor travels through the queue as a file descriptor that the parent fetches from THIS
+    # process -- which may have exited by then (FileNotFoundError in resource_sharer); an ndarray is pickled by value
+    q.put((rank, net.slab.detach()[:net.numel].numpy().copy(), net.grad[:net.numel].numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -74,6 +76,7 @@ def test_two_rank_step_equals_gradient_average():
     res = dict()
     for _ in range(2):
         r, slab, grad = q.get(timeout=600)
+        slab, grad = torch.from_numpy(slab), torch.from_numpy(grad)
         res[r] = (slab, grad)
     for p in procs:
         p.join(timeout=120)
@@ -133,7 +136,7 @@ def _train_worker(rank, world, port, q, out_dir):
     with contextlib.redirect_stdout(io.StringIO()):
         net, _ = T.train(cfg, prompts, device=torch.device("cpu"), use_graphs=False, progress=False, save_state=True,
                          stop_after=1)
-    q.put((rank, seen, net.slab.detach()[:net.numel].clone()))
+    q.put((rank, seen, net.slab.detach()[:net.numel].numpy().copy()))      # by value (see _worker)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -150,6 +153,7 @@ def test_train_under_dp_draws_per_rank_data_and_a_shared_k(tmp_path):
     res = {}
     for _ in range(2):
         r, seen, slab = q.get(timeout=900)
+        slab = torch.from_numpy(slab)
         res[r] = (seen, slab)
     for p in procs:
         p.join(timeout=120)
@@ -175,7 +179,7 @@ def test_bench_multi_gpu_launch_path_dry_run():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                        "--arch", "tiny", "--res", "128", "--bs", "1", "--k", "2", "--no-cpu-baseline"],
+                        "--arch", "tiny", "--res", "64", "--bs", "1", "--k", "1", "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -191,11 +191,11 @@ def test_reference_lora_network_applied_to_this_unet_is_adopted(ref):
     opt_r = torch.optim.AdamW(rnet.prepare_optimizer_params(), lr=1e-3)
     opt_f = torch.optim.AdamW(fnet.prepare_optimizer_params(), lr=1e-3)
     g = torch.Generator().manual_seed(9)
-    x, ctx = torch.randn(2, 4, 16, 16, generator=g), torch.randn(2, 77, 64, generator=g)
-    tgt = torch.randn(2, 4, 16, 16, generator=g)
+    x, ctx = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 77, 64, generator=g)       # 8x8 latents: fp32 emulation
+    tgt = torch.randn(2, 4, 8, 8, generator=g)
 
-    def rel(a, b):
-        return ((a.float() - b.float()).norm() / b.float().norm()).item()
+    def rel(a, b):      # (at 8x8 the deepest level is 1x1: its GroupNorm output, hence some gradients, are exactly 0 in both)
+        return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-30)).item()
     for it in range(2):          # second iteration: parameters changed by the FOREIGN optimizer behind the engine's back
         with rnet:
             yr = ru(x, torch.tensor(500), encoder_hidden_states=ctx).sample
