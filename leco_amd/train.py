@@ -143,6 +143,12 @@ class FusedStep:
         # ancestral schedulers (ddpm / euler_a): `noise_fn(i, numel)` supplies the noise of denoising pass i (a replayable
         # stream for parity tests); None = fresh device-RNG noise, like diffusers' randn_tensor on the UNet's device
         self.noise_fn = None
+        # LECO_OVERLAP_FROZEN=1: the batched LoRA-off pass (train_lora.py:202-237) and the LoRA-on target pass (:244-256)
+        # both depend only on the denoised latents; run them on two streams (the frozen plan then owns a split-K
+        # workspace, the only mutable buffer plans share).  Default off: see DESIGN.md section 8.1.
+        self.overlap = (os.environ.get("LECO_OVERLAP_FROZEN", "0") not in ("", "0") and dev.type == "cuda"
+                        and torch.cuda.is_available())
+        self._side = torch.cuda.Stream(device=dev) if self.overlap else None
 
     def _scale_at(self, t_train: int) -> float:
         """scale_model_input factor at train timestep `t_train` of the 1000-step schedule (train_lora.py:195-199)."""
@@ -167,7 +173,7 @@ class FusedStep:
                 self._state.pop(old)
                 eng = self.unet.engine()
                 ob, oh, ow = old
-                for pk in ((2 * ob, oh, ow, True), (2 * ob, oh, ow, False), (6 * ob, oh, ow, False)):
+                for pk in ((2 * ob, oh, ow, True), (2 * ob, oh, ow, False), (6 * ob, oh, ow, False), (6 * ob, oh, ow, False, 1)):
                     eng.drop_plan(pk)
             plan = self.unet.prepare((2 * bs, 4, h, w), lora_on=True)
             eng = self.unet.engine()
@@ -177,7 +183,7 @@ class FusedStep:
             # the three LoRA-off predictions (positive / neutral / unconditional) run as ONE forward-only pass of
             # batch 3 x 2bs: same arithmetic per sample (GroupNorm / attention are per sample), three times
             # the rows per GEMM, a third of the launches
-            fplan = eng.plan(6 * bs, h, w, need_bwd=False)
+            fplan = eng.plan(6 * bs, h, w, need_bwd=False, ws_slot=1 if self.overlap else 0)
             st = dict(plan=plan, dplan=dplan, fplan=fplan,
                       x=torch.zeros(bs, 4, h, w, dtype=torch.float32, device=self.dev),
                       preds={n: fplan.pred[2 * bs * i:2 * bs * (i + 1)]
@@ -302,13 +308,23 @@ class FusedStep:
             fplan.text_embeds.copy_(torch.cat([self._pooled(pair, w_, bs) for w_ in ("positive", "neutral", "unconditional")]))
         fplan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])
         fplan.t_idx.copy_(self.slot_idx)
-        self._run(fplan, "fwd_off")
+        if self.overlap:      # inputs of both passes are in place: fork
+            plan.ctx.copy_(self._ctx(pair, "target", bs))
+            cur = torch.cuda.current_stream()
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                self._run(fplan, "fwd_off")
+        else:
+            self._run(fplan, "fwd_off")
         trace.pop()
         # 3. target prediction with LoRA on; activations stay resident for the backward
         trace.push("target forward")
         net.multiplier = 1.0
-        plan.ctx.copy_(self._ctx(pair, "target", bs))
+        if not self.overlap:
+            plan.ctx.copy_(self._ctx(pair, "target", bs))
         self._run(plan, "fwd_on")
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self._side)      # join before the loss reads the frozen predictions
         trace.pop()
         # 4. ESD objective + gradient w.r.t. the raw target prediction
         trace.push("loss + backward")

@@ -518,14 +518,24 @@ class Engine:
         net._packed_version = net.version
 
     # ---- plan construction ---------------------------------------------------------------------
-    def plan(self, B: int, h: int, w: int, need_bwd: bool = True) -> Plan:
+    def plan(self, B: int, h: int, w: int, need_bwd: bool = True, ws_slot: int = 0) -> Plan:
         """``need_bwd=False`` builds a forward-only plan (no gradient buffers): used for the batched
-        LoRA-off passes, which never run a backward."""
-        key = (B, h, w, need_bwd)
+        LoRA-off passes, which never run a backward.  ``ws_slot`` > 0 gives the plan's split-K launches a workspace of
+        their own (the only mutable buffer plans share), so that its lists may run CONCURRENTLY with another plan's on a
+        second stream (`FusedStep`: the batched frozen pass beside the LoRA-on target pass)."""
+        key = (B, h, w, need_bwd) if ws_slot == 0 else (B, h, w, need_bwd, ws_slot)
         if key not in self.plans:
             with ops.f32_mode(self.f32):
-                self.plans[key] = PlanBuilder(self, B, h, w, need_bwd).build()
+                self.plans[key] = PlanBuilder(self, B, h, w, need_bwd, ws=self.workspace_slot(ws_slot)).build()
         return self.plans[key]
+
+    def workspace_slot(self, slot: int) -> torch.Tensor:
+        if slot == 0:
+            return self.workspace
+        extra = self.__dict__.setdefault("_workspaces", {})
+        if slot not in extra:
+            extra[slot] = torch.empty_like(self.workspace)
+        return extra[slot]
 
     def drop_plan(self, key: tuple) -> None:
         """Release one plan: its captured hipGraphs, then (by dropping the references) its activation buffers.
@@ -551,8 +561,9 @@ class Engine:
 
 
 class PlanBuilder:
-    def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True):
+    def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True, ws: Optional[torch.Tensor] = None):
         self.eng, self.cfg, self.dev = eng, eng.cfg, eng.device
+        self.ws = eng.workspace if ws is None else ws      # split-K slabs of this plan's launches
         self.B, self.h, self.w = B, h, w
         self.need_bwd = need_bwd
         self.plan = Plan()
@@ -659,7 +670,7 @@ class PlanBuilder:
         yptr = y.ptr if y is not None else None
         ldc = y.ld if y is not None else site.n
         g_off = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, **common)
-        self.f_off.append(ops.gemm(g_off, keep=(site, xs, residual, y), ws=self.eng.workspace))
+        self.f_off.append(ops.gemm(g_off, keep=(site, xs, residual, y), ws=self.ws))
         T = None
         self._last_T = None
         if lora is not None:
@@ -668,24 +679,24 @@ class PlanBuilder:
                 # down-projection fused into the main GEMM's K sweep (T is still written: lora_up wgrad)
                 g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, w_ext=lora.up_p, ext_k=32, ld_wext=32,
                                  t_w=lora.dn_s, t_rows=lora.R16, t_out=T.ptr, ld_tout=T.ld, **common)
-                self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y, T), ws=self.eng.workspace))
+                self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y, T), ws=self.ws))
             else:
                 kw = dict(m=rows, n=lora.Rp, k=site.k, a_mode=amode, conv=conv)
                 if len(xs) == 2:
                     kw.update(a1=xs[1].ptr, lda1=xs[1].ld, k_split=xs[0].cols)
                 g_t = gemm_args(a0, lora.dn_s, T.ptr, lda=lda0, ldc=T.ld, **kw)
-                self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T), ws=self.eng.workspace))
+                self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T), ws=self.ws))
                 e0 = min(lora.Rp, 64)
                 g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, a_ext=T.ptr, w_ext=lora.up_p, ext_k=e0,
                                  ld_aext=T.ld, ld_wext=lora.Rp, **common)
-                self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y), ws=self.eng.workspace))
+                self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y), ws=self.ws))
                 for c in range(64, lora.Rp, 64):   # further 64-column slices of T . (scale up)^T, accumulated into y
                     assert y is not None and act == ACT_NONE
                     g_c = gemm_args(T.ptr + self.eng.esz * c, lora.up_p.data_ptr() + self.eng.esz * c, y.ptr, m=rows, n=site.n, k=64, lda=T.ld,
                                     ldw=lora.Rp, ldc=y.ld, residual=y.ptr, ldr=y.ld)
-                    self.f_on.append(ops.gemm(g_c, keep=(lora, T, y), ws=self.eng.workspace))
+                    self.f_on.append(ops.gemm(g_c, keep=(lora, T, y), ws=self.ws))
         else:
-            self.f_on.append(ops.gemm(g_off, ws=self.eng.workspace))
+            self.f_on.append(ops.gemm(g_off, ws=self.ws))
         if y is not None:
             y.rg = rg_in or lora is not None
             if y.rg:
@@ -698,13 +709,13 @@ class PlanBuilder:
         wg, bg = site.w_geglu
         y = self.act(name, rows, site.n // 2)
         common = dict(m=rows, n=site.n, k=site.k, bias=bg, act=ACT_GEGLU, lda=x.ld, ldc=y.ld)
-        self.f_off.append(ops.gemm(gemm_args(x.ptr, wg, y.ptr, **common), keep=(site, x, y, wg, bg), ws=self.eng.workspace))
+        self.f_off.append(ops.gemm(gemm_args(x.ptr, wg, y.ptr, **common), keep=(site, x, y, wg, bg), ws=self.ws))
         lora = site.lora
         if lora is not None and lora.Rp == 32 and lora.up_pg is not None:
             T = self.act(name + ".loraT", rows, 32)
             g_on = gemm_args(x.ptr, wg, y.ptr, w_ext=lora.up_pg, ext_k=32, ld_wext=32, t_w=lora.dn_s, t_rows=lora.R16,
                              t_out=T.ptr, ld_tout=T.ld, **common)
-            self.f_on.append(ops.gemm(g_on, keep=(site, lora, x, y, T, wg, bg), ws=self.eng.workspace))
+            self.f_on.append(ops.gemm(g_on, keep=(site, lora, x, y, T, wg, bg), ws=self.ws))
         elif lora is not None:
             raise RuntimeError("fused GEGLU needs the rank-<=32 fused down-projection path")
         else:
@@ -795,18 +806,18 @@ class PlanBuilder:
             if fuse_u:
                 g = gemm_args(dy.ptr, site.wt, dx.ptr, m=rows, n=kin, k=site.n, lda=dy.ld, ldc=dx.ld, w_ext=lora.dn_p,
                               ext_k=32, ld_wext=lora.Rp, t_w=lora.up_t, t_rows=lora.R16, t_out=U.ptr, ld_tout=U.ld)
-                out.append(ops.gemm(g, keep=(site, lora, dy, dx, U), ws=self.eng.workspace))
+                out.append(ops.gemm(g, keep=(site, lora, dy, dx, U), ws=self.ws))
                 self.lora_wgrads(site, xs, dy, T, U, conv, amode, rows)
             else:
                 g = gemm_args(dy.ptr, site.wt, dx.ptr, m=rows, n=kin, k=site.n, lda=dy.ld, ldc=dx.ld,
                               a_ext=U.ptr if U is not None else None, w_ext=lora.dn_p if lora is not None else None,
                               ext_k=min(lora.Rp, 64) if lora is not None else 0, ld_aext=U.ld if U is not None else 0,
                               ld_wext=lora.Rp if lora is not None else 0)
-                out.append(ops.gemm(g, keep=(site, dy, dx, U), ws=self.eng.workspace))
+                out.append(ops.gemm(g, keep=(site, dy, dx, U), ws=self.ws))
                 for c in range(64, lora.Rp if lora is not None else 0, 64):   # further slices of U . (scale down)
                     g_c = gemm_args(U.ptr + self.eng.esz * c, lora.dn_p.data_ptr() + self.eng.esz * c, dx.ptr, m=rows, n=kin, k=64, lda=U.ld,
                                     ldw=lora.Rp, ldc=dx.ld, residual=dx.ptr, ldr=dx.ld)
-                    out.append(ops.gemm(g_c, keep=(lora, U, dx), ws=self.eng.workspace))
+                    out.append(ops.gemm(g_c, keep=(lora, U, dx), ws=self.ws))
         else:
             B, ho, wo, hi, wi = conv
             if amode == A_CONV3_S1:
@@ -818,13 +829,13 @@ class PlanBuilder:
             dxa = self.act("g." + y.name + ".dx", drows, kin)
             g = gemm_args(dy.ptr, site.wt, dxa.ptr, m=drows, n=kin, k=9 * site.n, lda=dy.ld, ldc=dxa.ld, a_mode=dmode,
                           conv=dconv)
-            out.append(ops.gemm(g, keep=(site, dy, dxa), ws=self.eng.workspace))
+            out.append(ops.gemm(g, keep=(site, dy, dxa), ws=self.ws))
             if lora is not None:
                 # conv LoRA: dX += conv_dgrad(U, scale * lora_down) -- U is a 64-channel image, the packed dn_p is
                 # the flipped / in-out-swapped [Cin][3][3][64] operand; accumulated through the residual epilogue
                 g2 = gemm_args(U.ptr, lora.dn_p, dxa.ptr, m=drows, n=kin, k=9 * lora.Rp, lda=U.ld, ldc=dxa.ld,
                                a_mode=dmode, conv=dconv, residual=dxa.ptr, ldr=dxa.ld)
-                out.append(ops.gemm(g2, keep=(lora, U, dxa), ws=self.eng.workspace))
+                out.append(ops.gemm(g2, keep=(lora, U, dxa), ws=self.ws))
             if amode == A_CONV3_UP2:
                 dx = self.act("g." + y.name + ".dxlo", B * hi * wi, kin)
                 out.append(ops.upsample2x_bwd(dxa.t, dx.t, B, hi, wi, kin))
