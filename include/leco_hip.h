@@ -315,6 +315,71 @@ int leco_graph_end_capture(leco_stream_t stream, leco_graph_t* out);
 int leco_graph_launch(leco_graph_t graph, leco_stream_t stream);
 int leco_graph_destroy(leco_graph_t graph);
 
+/* ---- fp32 compute mode (`train.precision: float32`, config_util.py:75-83; csrc/f32.hip) --------------------------------
+ * One twin per entry point above that touches activations: SAME argument list and meaning, but every tensor the bf16
+ * entry point takes as bf16 (activations, packed weights, LoRA operand images) is fp32 here, strides still in elements.
+ * Contractions run on the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32); a whole SD1.5 UNet pass agrees with the fp32
+ * reference to 3.7e-6.  Written for exactness, not speed. */
+int leco_f32_gemm(const leco_gemm_args* args, leco_stream_t stream);
+int leco_f32_attention_fwd(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk,
+                       int64_t bsk, const void* v, int64_t ldv, int64_t bsv, void* o, int64_t ldo,
+                       int64_t bso, float* lse, int32_t batch, int32_t heads, int32_t sq,
+                       int32_t skv, int32_t head_dim, float scale, leco_stream_t stream);
+int leco_f32_attention_bwd(const void* q, int64_t ldq, int64_t bsq, const void* k, int64_t ldk,
+                       int64_t bsk, const void* v, int64_t ldv, int64_t bsv, const void* o,
+                       int64_t ldo, int64_t bso, const void* d_o, int64_t lddo, int64_t bsdo,
+                       const float* lse, float* delta, void* dq, int64_t lddq,
+                       int64_t bsdq, void* dk, int64_t lddk, int64_t bsdk, void* dv, int64_t lddv,
+                       int64_t bsdv, int32_t batch, int32_t heads, int32_t sq, int32_t skv,
+                       int32_t head_dim, float scale, leco_stream_t stream);
+int leco_f32_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
+                       const float* gamma, const float* beta, int32_t batch, int32_t hw, int32_t c,
+                       int32_t groups, float eps, int32_t act, float* stats, void* y, int64_t ldy,
+                       leco_stream_t stream);
+int leco_f32_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
+                       const void* dy, int64_t lddy, const float* gamma, const float* beta,
+                       const float* stats, int32_t batch, int32_t hw, int32_t c, int32_t groups,
+                       float eps, int32_t act, float* bstats, void* dx, int64_t lddx,
+                       leco_stream_t stream);
+int leco_f32_layernorm_fwd(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                       int32_t m, int32_t c, void* y, int64_t ldy, float* mean, float* rstd,
+                       leco_stream_t stream);
+int leco_f32_layernorm_bwd(const void* x, int64_t ldx, const void* dy, int64_t lddy, const float* gamma,
+                       const float* mean, const float* rstd, const void* dres, int64_t ldres,
+                       int32_t m, int32_t c, void* dx, int64_t lddx, leco_stream_t stream);
+int leco_f32_geglu_fwd(const void* u, int64_t ldu, void* y, int64_t ldy, int32_t m, int32_t f,
+                   leco_stream_t stream);
+int leco_f32_geglu_bwd(const void* u, int64_t ldu, const void* dy, int64_t lddy, void* du, int64_t lddu,
+                   int32_t m, int32_t f, leco_stream_t stream);
+int leco_f32_add(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc,
+             void* out, int64_t ldo, int32_t m, int32_t cols, leco_stream_t stream);
+int leco_f32_upsample2x_bwd(const void* dy, void* dx, int32_t batch, int32_t h, int32_t w, int32_t c,
+                        leco_stream_t stream);
+int leco_f32_conv_in(const void* x, const float* w, const float* bias, void* y, int32_t batch, int32_t h,
+                 int32_t wd, int32_t cin, int32_t cout, leco_stream_t stream);
+int leco_f32_conv_out(const void* x, const void* w, const float* bias, float* y, int32_t batch, int32_t h,
+                  int32_t wd, int32_t c, int32_t cout, leco_stream_t stream);
+int leco_f32_conv_out_bwd(const float* dy, const void* w, void* dx, int32_t batch, int32_t h, int32_t wd,
+                      int32_t c, int32_t cout, leco_stream_t stream);
+int leco_f32_timestep_embedding(const float* t_table, const int32_t* idx, int32_t t_stride, int32_t n,
+                            int32_t dim, void* out, leco_stream_t stream);
+int leco_f32_cfg_ddim_step(const float* pred, float* x, void* x2, const float* coef, const int32_t* step,
+                       float guidance, int64_t half_n, leco_stream_t stream);
+int leco_f32_cfg_sched_step(const float* pred, float* x, void* x2, const float* coef, const int32_t* step,
+                        float guidance, int64_t half_n, const float* noise, float* hist, int32_t n_hist,
+                        leco_stream_t stream);
+int leco_f32_cast_f32_bf16(const float* x, void* y, int64_t n, leco_stream_t stream);
+int leco_f32_rowgroup_sum(const void* x, int64_t ldx, float* out, int64_t ldo, int32_t groups,
+                      int32_t rows_per_group, int32_t cols, leco_stream_t stream);
+int leco_f32_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_stream_t stream);
+int leco_f32_lora_wgrad(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g,
+                    int64_t g_sj, int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale,
+                    float* part, int64_t part_bytes, leco_stream_t stream);
+int leco_f32_lora_wgrad_conv(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj,
+                         int64_t g_sc, int32_t m, int32_t r, int32_t cols, float scale, int32_t a_mode,
+                         int32_t h_out, int32_t w_out, int32_t h_in, int32_t w_in, int32_t kh, int32_t kw,
+                         float* part, int64_t part_bytes, leco_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
