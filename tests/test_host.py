@@ -29,6 +29,10 @@ def test_c_abi_library_builds_loads_and_exports_every_declared_symbol(tmp_path):
         assert hasattr(lib, s), f"{s} declared in include/leco_hip.h but not exported"
     lib.leco_version.restype = ctypes.c_int
     assert lib.leco_version() >= 100
+    # ... and the other way round: nothing is exported that the header does not declare (the boundary IS the header)
+    nm = subprocess.run(["nm", "-D", "--defined-only", hip.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {l.split()[-1] for l in nm.splitlines() if l.split() and l.split()[-1].startswith("leco_")}
+    assert exported and exported <= set(syms), sorted(exported - set(syms))
     # the device code object really targets gfx950
     # (llvm-objdump --offloading unbundles the code objects next to its INPUT: give it a scratch copy)
     import shutil
