@@ -526,6 +526,19 @@ def test_plan_buckets_are_evicted_lru(dev):
     fs._bucket(1, 8, 16)                       # touch: becomes most recent
     fs._bucket(1, 8, 8)                        # evicts (1, 16, 8)
     assert list(fs._state) == [(1, 8, 16), (1, 8, 8)] and (2, 16, 8, True) not in eng.plans
+    # a plan on another workspace slot (LECO_OVERLAP_FROZEN: the frozen pass beside the target pass) is a plan of its own
+    # whose split-K launches never touch the shared workspace, and it is evicted with its bucket
+    p0, p1 = eng.plan(6, 8, 8, need_bwd=False), eng.plan(6, 8, 8, need_bwd=False, ws_slot=1)
+    assert p0 is not p1 and (6, 8, 8, False, 1) in eng.plans
+    ws0, ws1 = eng.workspace.data_ptr(), eng.workspace_slot(1).data_ptr()
+    assert ws0 != ws1 and eng.workspace_slot(1) is eng.workspace_slot(1)
+
+    def ws_args(plan):
+        return {op.args[3] for op in plan.lists["fwd_off"] if op.name.endswith("gemm_ex") and op.args[3]}
+    assert ws_args(p0) <= {ws0} and ws_args(p1) <= {ws1} and ws_args(p1)
+    fs._bucket(1, 16, 16)
+    fs._bucket(1, 16, 8)                       # (1, 8, 8) is the oldest now: gone with BOTH frozen plans
+    assert (6, 8, 8, False) not in eng.plans and (6, 8, 8, False, 1) not in eng.plans
 
 
 def test_infer_xl_script_samples_with_a_trained_lora(dev, tmp_path):
