@@ -306,6 +306,66 @@ int leco_cast_f32_bf16(const float* x, void* y, int64_t n, leco_stream_t stream)
 int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Row-stripe fused transformer-block kernels (csrc/stripe.hip): forward-only, bf16, C = 320 (the 64^2 level of SD1.x /
+ * SD2.x: head dim 40 or 64).  One workgroup owns 64 token rows for a whole chain of Linear / LayerNorm / cross-attention /
+ * GEGLU operations of diffusers' BasicTransformerBlock + Transformer2DModel (call site train_util.py:156-160; LoRA term
+ * lora.py:102-106): the residual stream stays in registers (fp32), GEMM operands in LDS, the block's weights stream once
+ * through an LDS ring.  Replaces 14 of the per-op launches above per transformer block in the LoRA-on denoising passes
+ * (train_util.py:172-193) and the batched LoRA-off predictions (train_lora.py:202-237); the differentiated pass keeps the
+ * per-op kernels (it must save every intermediate).
+ * ---------------------------------------------------------------------- */
+typedef struct leco_xlin {     /* one Linear of a stripe chain: y = x W^T + bias (+ (x down^T) (scale up)^T) */
+    const void* w;             /* bf16 [N][K], K contiguous */
+    int64_t ldw;
+    const float* bias;         /* fp32 [N] or NULL */
+    const void* dn;            /* stacked lora_down rows, bf16 [t_rows][K] (leco_lora_site.dn_s); NULL = LoRA off */
+    int64_t ld_dn;
+    const void* up;            /* scale * lora_up, bf16 [N][32] (leco_lora_site.up_p; columns >= groups*r zero) */
+    int64_t ld_up;
+    int32_t t_rows;            /* 16 or 32: stacked rank rounded up to 16 */
+} leco_xlin;
+
+/* 1 if the stripe kernels cover this shape (else the caller keeps the per-op launches) */
+int leco_xblock_supported(int32_t c, int32_t heads, int32_t skv, int32_t rows_per_sample);
+
+/* K / V of the cross-attention for the stripe kernels, once per step: kv = output of the fused to_k|to_v projection,
+ * bf16 [batch * skv][2 C] (row stride ld_kv).  kp: bf16 [batch][heads][80][64] (zero padded); vt: bf16
+ * [batch][heads][roundup(head_dim, 16)][96], V^T with the key order permuted to the MFMA operand order (+ a row of ones
+ * when head_dim % 16 != 0: the softmax row sum then comes out of the PV product). */
+#define LECO_XATTN_KP_ELEMS(batch, heads) ((int64_t)(batch) * (heads) * 80 * 64)
+#define LECO_XATTN_VT_ELEMS(batch, heads, head_dim) ((int64_t)(batch) * (heads) * (((head_dim) + 15) / 16 * 16) * 96)
+int leco_xattn_prep(const void* kv, int64_t ld_kv, void* kp, void* vt, int32_t batch, int32_t heads, int32_t skv,
+                    int32_t head_dim, leco_stream_t stream);
+
+/* Everything of a BasicTransformerBlock after its self-attention core, + Transformer2DModel.proj_out:
+ *   h1 = to_out1(attn) + h_in;  q2 = to_q2(LN2(h1));  a2 = softmax(q2 K^T scale) V;  h2 = to_out2(a2) + h1;
+ *   h3 = ff2(GEGLU(ff1(LN3(h2)))) + h2;  out = proj_out.w ? proj_out(h3) + res : h3.
+ * ff1 carries the LECO_ACT_GEGLU row interleave (weights, bias and up: blocks of 64 value rows followed by their 64 gate
+ * rows).  col_stats (optional): {sum, sumsq} of the stored bf16 values per sample and atom of stats_atom (even) columns,
+ * like leco_gemm_args.col_stats. */
+typedef struct leco_xblock_tail_args {
+    int32_t m, c, heads, skv, rows_per_sample;
+    const void* attn; int64_t ld_attn;   /* self-attention output, bf16 [m][c] */
+    const void* h_in; int64_t ld_h;      /* residual stream entering the block, bf16 [m][c] */
+    leco_xlin to_out1, to_q2, to_out2, ff1, ff2, proj_out;
+    const float* ln2_g; const float* ln2_b; const float* ln3_g; const float* ln3_b;
+    float ln_eps;
+    const void* kp; const void* vt;      /* leco_xattn_prep */
+    float attn_scale;                    /* head_dim^-0.5 */
+    const void* res; int64_t ld_res;     /* proj_out residual (the Transformer2DModel input), bf16 [m][c] */
+    void* out; int64_t ld_out;           /* bf16 [m][c] */
+    float* col_stats; int32_t stats_atom;
+} leco_xblock_tail_args;
+/* The launch description (operand pointers + the weight-tile sweep table the kernel walks) lives in DEVICE memory and is
+ * read through the scalar cache: leco_xblock_tail_build validates `args` and fills a HOST buffer of
+ * leco_xblock_prog_bytes() bytes; the caller copies it to the device once (per plan) and launches with
+ * leco_xblock_tail_run(dev_prog, m, head_dim).  Nothing else is kept: the program may be re-used for any number of
+ * launches (graph capture included) as long as the operands it points to stay alive. */
+int64_t leco_xblock_prog_bytes(void);
+int leco_xblock_tail_build(const leco_xblock_tail_args* args, void* host_prog, int64_t host_bytes);
+int leco_xblock_tail_run(const void* dev_prog, int32_t m, int32_t head_dim, leco_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * hipGraph capture of a whole UNet pass (the reference issues ~10^4 eager kernel launches
  * per pass from Python; here a pass is one graph launch).
  * ---------------------------------------------------------------------- */

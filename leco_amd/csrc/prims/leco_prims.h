@@ -80,6 +80,19 @@ __device__ __forceinline__ bf16x8 lds_read16_async(const void* lds_ptr) {
     asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(a) : "memory");
     return v;
 }
+// LDS stores the compiler's s_waitcnt insertion does not track (ds_write_b64 / ds_write_b32 through inline asm): with
+// LDS-DMA in flight hipcc puts a vmcnt wait for EVERY outstanding DMA in front of a C++-level LDS access (it cannot
+// tell the DMA's destination from the store's), which drains the weight stream at every phase boundary of the stripe
+// kernels (stripe.hip).  Completion: lgkmcnt (barrier_keep_dma() waits lgkmcnt(0)).  The data registers are read at
+// issue, so they may be overwritten afterwards (64-bit data: no store-data hazard, cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void lds_write8_async(void* lds_ptr, u32x2 v) {
+    const unsigned a = (unsigned)(unsigned long long)lds_ptr;
+    asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+__device__ __forceinline__ void lds_write4_async(void* lds_ptr, float v) {
+    const unsigned a = (unsigned)(unsigned long long)lds_ptr;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
 // Hardware transpose read (ds_read_b64_tr_b16): every lane passes the address of 4 consecutive bf16; inside each
 // group of 16 lanes the 16 x 4 elements are exchanged so that lane c receives element (c & 3) of lanes
 // c/4, 4 + c/4, 8 + c/4, 12 + c/4 -- i.e. with lane i addressing row i/4, columns 4(i%4).. of a [4][16] block,
@@ -108,6 +121,11 @@ __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0
 extern __shared__ __attribute__((aligned(16))) unsigned char leco_dyn_lds_[];
 __device__ __forceinline__ unsigned char* dyn_lds() { return leco_dyn_lds_; }
 
+// Pointer into a read-only table in global memory that is read through the SCALAR data cache (constant address space:
+// s_load, tracked by lgkmcnt).  A by-value kernel argument that is indexed dynamically is copied to scratch by hipcc, and
+// an ordinary global load would be a vector-memory operation -- its wait would drain every LDS-DMA in flight.
+#define LECO_CONST_AS __attribute__((address_space(4)))
+#define LECO_CONST_CAST(T, p) ((const LECO_CONST_AS T*)(unsigned long long)(p))
 // tells the compiler a value is wave-uniform (v_readfirstlane): needed for values derived from
 // threadIdx (e.g. the wave index) that feed scalar operands such as the LDS-DMA base (M0)
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }

@@ -59,6 +59,37 @@ class WgradProblem(C.Structure):     # mirrors `leco_wgrad_problem` in include/l
     ]
 
 
+class XLin(C.Structure):          # mirrors `leco_xlin`
+    _fields_ = [("w", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p), ("dn", C.c_void_p), ("ld_dn", C.c_int64),
+                ("up", C.c_void_p), ("ld_up", C.c_int64), ("t_rows", C.c_int32)]
+
+
+class XBlockTailArgs(C.Structure):     # mirrors `leco_xblock_tail_args`
+    _fields_ = [
+        ("m", C.c_int32), ("c", C.c_int32), ("heads", C.c_int32), ("skv", C.c_int32), ("rows_per_sample", C.c_int32),
+        ("attn", C.c_void_p), ("ld_attn", C.c_int64), ("h_in", C.c_void_p), ("ld_h", C.c_int64),
+        ("to_out1", XLin), ("to_q2", XLin), ("to_out2", XLin), ("ff1", XLin), ("ff2", XLin), ("proj_out", XLin),
+        ("ln2_g", C.c_void_p), ("ln2_b", C.c_void_p), ("ln3_g", C.c_void_p), ("ln3_b", C.c_void_p), ("ln_eps", C.c_float),
+        ("kp", C.c_void_p), ("vt", C.c_void_p), ("attn_scale", C.c_float),
+        ("res", C.c_void_p), ("ld_res", C.c_int64), ("out", C.c_void_p), ("ld_out", C.c_int64),
+        ("col_stats", C.c_void_p), ("stats_atom", C.c_int32),
+    ]
+
+
+def xlin(w, bias=None, dn=None, up=None, t_rows: int = 0, ldw: Optional[int] = None, ld_dn: Optional[int] = None,
+         ld_up: int = 32) -> XLin:
+    """One Linear of a stripe chain (include/leco_hip.h `leco_xlin`): ``w`` [N][K] bf16, ``dn`` / ``up`` = the packed LoRA
+    operand images `dn_s` / `up_p` of the site (None: LoRA off)."""
+    x = XLin()
+    x.w, x.ldw = ptr(w), (w.shape[-1] if ldw is None else ldw)
+    x.bias = ptr(bias)
+    x.dn = ptr(dn)
+    x.ld_dn = 0 if dn is None else (dn.shape[-1] if ld_dn is None else ld_dn)
+    x.up, x.ld_up = ptr(up), ld_up
+    x.t_rows = t_rows
+    return x
+
+
 _lib: Optional[C.CDLL] = None
 _lib_path: Optional[str] = None
 

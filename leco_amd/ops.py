@@ -51,6 +51,8 @@ _SIGS = {
     "leco_rowgroup_sum": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp],
     "leco_lora_wgrad_grouped": [_vp, _i32, _i32, _i32, _vp],
     "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp],
+    "leco_xattn_prep": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
+    "leco_xblock_tail_run": [_vp, _i32, _i32, _vp],
 }
 # fp32 compute mode (csrc/f32.hip): the same argument lists behind `leco_f32_` entry points; activations / weights /
 # LoRA operand images are float.  While `f32_mode(True)` is active (the plan builder of an fp32 engine), every Op that
@@ -284,6 +286,41 @@ def lora_wgrad_grouped(problems: list, device) -> Optional[Op]:
         start += d.blocks_x * -(-pr["m"] // 128)
     raw = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(device)
     return Op("leco_lora_wgrad_grouped", (raw.data_ptr(), len(problems), start, max(pr["r"] for pr in problems)), keep=(raw,))
+
+
+# ---- row-stripe fused transformer-block kernels (csrc/stripe.hip; bf16, forward-only plans) ---------------------------------
+def xblock_supported(c: int, heads: int, skv: int, rows_per_sample: int) -> bool:
+    f = hip.declare("leco_xblock_supported", [_i32, _i32, _i32, _i32])
+    return bool(f(c, heads, skv, rows_per_sample))
+
+
+def xattn_prep(kv_ptr: int, ld_kv: int, kp: torch.Tensor, vt: torch.Tensor, batch: int, heads: int, skv: int, head_dim: int) -> Op:
+    """Cross-attention K / V^T operand images for `xblock_tail` (once per step: they depend only on the prompt)."""
+    return Op("leco_xattn_prep", (kv_ptr, ld_kv, ptr(kp), ptr(vt), batch, heads, skv, head_dim), keep=(kp, vt))
+
+
+def xattn_buffers(batch: int, heads: int, head_dim: int, device) -> tuple:
+    dv = (head_dim + 15) // 16 * 16
+    return (torch.zeros(batch * heads * 80 * 64, dtype=torch.bfloat16, device=device),
+            torch.zeros(batch * heads * dv * 96, dtype=torch.bfloat16, device=device))
+
+
+def _upload_program(build_fn: str, args, device) -> torch.Tensor:
+    """Runs a `leco_*_build` entry point into a host buffer and returns the program as a device tensor."""
+    lib = hip.lib()
+    nbytes_f = lib.leco_xblock_prog_bytes
+    nbytes_f.restype = C.c_int64
+    n = int(nbytes_f())
+    host = (C.c_uint8 * n)()
+    f = hip.declare(build_fn, [_vp, _vp, _i64])
+    hip.check(f(C.cast(C.byref(args), _vp), C.cast(host, _vp), n), build_fn)
+    return torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(device)
+
+
+def xblock_tail(args: "hip.XBlockTailArgs", device, keep=None) -> Op:
+    """Tail of a BasicTransformerBlock (+ proj_out) as ONE launch (include/leco_hip.h `leco_xblock_tail_args`)."""
+    prog = _upload_program("leco_xblock_tail_build", args, device)
+    return Op("leco_xblock_tail_run", (prog.data_ptr(), args.m, args.c // args.heads), keep=(prog, args, keep))
 
 
 def deterministic_default() -> bool:

@@ -119,6 +119,8 @@ static inline void wait_vmcnt() { if (emu_dma::late()) emu_dma::complete_all_but
 #define __syncthreads() (emu_dma::complete_all_but(0), emu::sync_block())
 #define LECO_MIN_WAVES_PER_SIMD(n)
 static inline bf16x8 lds_read16_async(const void* lds_ptr) { return *(const bf16x8*)lds_ptr; }
+static inline void lds_write8_async(void* lds_ptr, u32x2 v) { memcpy(lds_ptr, &v, 8); }
+static inline void lds_write4_async(void* lds_ptr, float v) { memcpy(lds_ptr, &v, 4); }
 static inline u32x2 lds_read_tr16(const void* lds_ptr) {
     unsigned long long mine;
     memcpy(&mine, lds_ptr, 8);
@@ -141,6 +143,8 @@ static inline unsigned char* dyn_lds() {
     static thread_local __attribute__((aligned(16))) unsigned char buf[160 * 1024];
     return buf;
 }
+#define LECO_CONST_AS
+#define LECO_CONST_CAST(T, p) ((const T*)(p))
 static inline int uniform(int v) { return v; }
 static inline unsigned mul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int lane_id() { return emu::lane(); }

@@ -1,0 +1,170 @@
+"""Row-stripe fused transformer-block kernels (csrc/stripe.hip) vs a plain fp32 PyTorch statement of the same chain of
+diffusers operations (BasicTransformerBlock after its self-attention core + Transformer2DModel.proj_out; the head: GroupNorm,
+proj_in, LayerNorm, q|k|v) on the same bf16-rounded operands.  Runs on the host emulator of the kernel sources (CPU tier,
+both LDS-DMA landing models) and on gfx950 (`-m gpu`).
+
+Tolerance: the kernel rounds the GEMM operands it hands from phase to phase (LayerNorm outputs, q2, a2, the GEGLU chunk, h3)
+to bf16 exactly where the per-op kernels round their stored outputs; the reference rounds at the same points, so what is left
+is accumulation order and the bf16 rounding of P inside the cross-attention: 3e-3 relative L2 on the bf16 output."""
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from leco_amd import hip, ops
+
+bf = torch.bfloat16
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _sync(dev):
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def _r(t):       # bf16 rounding, back in fp32
+    return t.to(bf).float()
+
+
+def geglu_perm(n):
+    i = torch.arange(n)
+    j, r = i // 128, i % 128
+    return torch.where(r < 64, j * 64 + r, n // 2 + j * 64 + (r - 64))
+
+
+class Lin:
+    """A Linear with an optional rank-R LoRA in the packed form the kernels consume (dn_s [t_rows][K], up_p [N][32])."""
+
+    def __init__(self, n, k, rank, dev, bias=True, wscale=1.0):
+        self.w = (torch.randn(n, k) * wscale / k ** 0.5).to(bf)
+        self.b = torch.randn(n) * 0.1 if bias else None
+        self.rank = rank
+        if rank:
+            self.t_rows = 16 if rank <= 16 else 32
+            dn = torch.zeros(self.t_rows, k)
+            dn[:rank] = torch.randn(rank, k) / k ** 0.5
+            up = torch.zeros(n, 32)
+            up[:, :rank] = torch.randn(n, rank) * 0.05
+            self.dn, self.up = dn.to(bf), up.to(bf)
+        self.dev = dev
+
+    def ref(self, x):
+        y = x @ self.w.float().T
+        if self.rank:
+            y = y + _r(x @ self.dn.float().T) @ self.up.float().T[:self.t_rows]
+        if self.b is not None:
+            y = y + self.b
+        return y
+
+    def xlin(self, perm=None):
+        w, b = self.w, self.b
+        up = self.up if self.rank else None
+        if perm is not None:
+            w, b = w[perm], (None if b is None else b[perm])
+            up = None if up is None else up[perm]
+        self._keep = (w.contiguous().to(self.dev), None if b is None else b.contiguous().to(self.dev),
+                      self.dn.to(self.dev) if self.rank else None, None if up is None else up.contiguous().to(self.dev))
+        w, b, dn, up = self._keep
+        return hip.xlin(w, b, dn, up, self.t_rows if self.rank else 0)
+
+
+def _ln(x, g, b, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), g, b, eps)
+
+
+@pytest.mark.parametrize("heads,rank,proj_out,stats,B,hw", [
+    (8, 4, True, True, 2, 64),       # SD1.x level 0 (d = 40), rank 4, Transformer2DModel tail incl. proj_out + GN statistics
+    (8, 0, True, False, 1, 128),     # LoRA off (the frozen passes)
+    (5, 24, True, True, 1, 64),      # SD2.x (d = 64); a 24-row LoRA stack (32 lora_down rows ride in the tiles)
+    (8, 8, False, False, 3, 64),     # a block that is not the last of its Transformer2DModel: h3 is the output
+])
+def test_xblock_tail_matches_the_per_op_chain(dev, heads, rank, proj_out, stats, B, hw):
+    torch.manual_seed(100 + heads + rank)
+    C, skv = 320, 77
+    D = C // heads
+    M = B * hw
+    to_out1, to_q2, to_out2 = Lin(C, C, rank, dev), Lin(C, C, rank, dev, bias=False), Lin(C, C, rank, dev)
+    ff1, ff2, po = Lin(8 * C, C, rank, dev), Lin(C, 4 * C, rank, dev), Lin(C, C, rank, dev)
+    a1 = torch.randn(M, C).to(bf); h0 = torch.randn(M, C).to(bf); x = torch.randn(M, C).to(bf)
+    kv = torch.randn(B * skv, 2 * C).to(bf)
+    g2, b2, g3, b3 = (1 + 0.2 * torch.randn(C)), 0.1 * torch.randn(C), (1 + 0.2 * torch.randn(C)), 0.1 * torch.randn(C)
+
+    # ---- reference (fp32, rounding where the chain stores bf16 operands)
+    h1 = to_out1.ref(a1.float()) + h0.float()
+    q2 = _r(to_q2.ref(_r(_ln(h1, g2, b2))))
+    kf, vf = kv.float()[:, :C].reshape(B, skv, heads, D), kv.float()[:, C:].reshape(B, skv, heads, D)
+    qh = q2.reshape(B, hw, heads, D)
+    s = torch.einsum("bqhd,bkhd->bhqk", qh, kf) * D ** -0.5
+    a2 = _r(torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), vf).reshape(M, C))
+    h2 = to_out2.ref(a2) + h1
+    u = ff1.ref(_r(_ln(h2, g3, b3)))
+    gg = _r(u[:, :4 * C] * F.gelu(u[:, 4 * C:]))
+    h3 = ff2.ref(gg) + h2
+    ref = po.ref(_r(h3)) + x.float() if proj_out else h3
+
+    # ---- kernel
+    d = lambda t: t.to(dev)
+    a1d, h0d, xd, kvd = d(a1), d(h0), d(x), d(kv)
+    kp, vt = ops.xattn_buffers(B, heads, D, dev)
+    ops.xattn_prep(kvd.data_ptr(), 2 * C, kp, vt, B, heads, skv, D).run()
+    out = torch.zeros(M, C, dtype=bf, device=dev)
+    cst = torch.zeros(B, C // 10, 2, device=dev)
+    A = hip.XBlockTailArgs()
+    A.m, A.c, A.heads, A.skv, A.rows_per_sample = M, C, heads, skv, hw
+    A.attn, A.ld_attn, A.h_in, A.ld_h = a1d.data_ptr(), C, h0d.data_ptr(), C
+    A.to_out1, A.to_q2, A.to_out2 = to_out1.xlin(), to_q2.xlin(), to_out2.xlin()
+    A.ff1, A.ff2 = ff1.xlin(geglu_perm(8 * C)), ff2.xlin()
+    if proj_out:
+        A.proj_out = po.xlin()
+        A.res, A.ld_res = xd.data_ptr(), C
+    lnp = [d(t.float().contiguous()) for t in (g2, b2, g3, b3)]
+    A.ln2_g, A.ln2_b, A.ln3_g, A.ln3_b = [t.data_ptr() for t in lnp]
+    A.ln_eps = 1e-5
+    A.kp, A.vt, A.attn_scale = kp.data_ptr(), vt.data_ptr(), D ** -0.5
+    A.out, A.ld_out = out.data_ptr(), C
+    if stats:
+        A.col_stats, A.stats_atom = cst.data_ptr(), 10
+    op = ops.xblock_tail(A, dev)
+    op.run()
+    _sync(dev)
+    assert torch.isfinite(out.float()).all()
+    assert rel_err(out, ref) < 3e-3, rel_err(out, ref)
+    if stats:
+        o = out.float().cpu().reshape(B, hw, C // 10, 10)
+        want = torch.stack([o.sum((1, 3)), (o * o).sum((1, 3))], -1)
+        assert rel_err(cst.cpu(), want) < 1e-5
+
+
+def test_xattn_prep_layout(dev):
+    """kp / vt are what the tail kernel's fragment loads expect: zero padding, the permuted key order, the row of ones."""
+    torch.manual_seed(3)
+    B, heads, D, skv, C = 2, 8, 40, 77, 320
+    kv = torch.randn(B * skv, 2 * C).to(bf).to(dev)
+    kp, vt = ops.xattn_buffers(B, heads, D, dev)
+    ops.xattn_prep(kv.data_ptr(), 2 * C, kp, vt, B, heads, skv, D).run()
+    _sync(dev)
+    kp = kp.float().cpu().reshape(B, heads, 80, 64); vt = vt.float().cpu().reshape(B, heads, 48, 96)
+    kvc = kv.float().cpu()
+    K = kvc[:, :C].reshape(B, skv, heads, D).permute(0, 2, 1, 3); V = kvc[:, C:].reshape(B, skv, heads, D).permute(0, 2, 1, 3)
+    assert torch.equal(kp[:, :, :skv, :D], K) and kp[:, :, skv:].abs().max() == 0 and kp[:, :, :, D:].abs().max() == 0
+    pos = torch.arange(96)
+    s_, g_, t_ = pos >> 5, (pos >> 3) & 3, pos & 7
+    key = 32 * s_ + 16 * (t_ >> 2) + 4 * g_ + (t_ & 3)
+    ok = key < skv
+    assert torch.equal(vt[:, :, :D][..., ok], V.permute(0, 1, 3, 2)[..., key[ok]])
+    assert vt[..., ~ok].abs().max() == 0
+    assert torch.equal(vt[:, :, D][..., ok], torch.ones(B, heads, int(ok.sum()))) and vt[:, :, D + 1:].abs().max() == 0
+
+
+def test_stripe_dma_protocol_under_late_completion():
+    """The weight-tile ring of the stripe kernels with the emulator's LATE LDS-DMA model (a copy lands only at the issuing
+    lane's counted s_waitcnt vmcnt or a draining barrier): a mis-counted wait reads a stale ring slot and fails parity."""
+    env = dict(os.environ, LECO_EMU_DMA="late")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-k",
+                        "matches_the_per_op_chain and emu and 8-4-True"], env=env, capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
