@@ -50,25 +50,28 @@ namespace {
 constexpr int XBM = 64;      // token rows per stripe
 constexpr int XKT = 32;      // k per weight tile
 constexpr int XNS = 3;       // ring slots
-constexpr int XMAXSW = 30;   // sweeps per program
+constexpr int XMAXSW = 44;   // sweeps per program (K-extension tiles included)
 constexpr int XNKEY = 80;    // padded prompt keys of K (5 fragments)
 constexpr int XNPOS = 96;    // padded (permuted) key positions of V^T
 
-struct XLin {       // device view of one streamed Linear
-    const void* w; const void* dn; const void* up; const float* bias;
-    unsigned w_bytes, dn_bytes, up_bytes;
-    unsigned ldw_b, lddn_b, ldup_b;     // row strides in bytes
+struct XLin {       // per-Linear constants the consumer side needs
+    const float* bias;
     int tf;                             // 0: LoRA off; 1 / 2: 16 / 32 stacked lora_down rows
+    int pad;
 };
-struct XSweep {     // one pass of the tile stream over weight rows [n0, n0 + nt) and k = k0 + 32 [0, ksteps)
-    int lin;
-    int n0, nt;
-    int k0, ksteps;
-    int tf;         // lora_down rows riding in the main tiles of this sweep (0 / 1 / 2)
-    int ext;        // 1: a K-extension tile (scale*up rows [n0, n0 + nt), 32 columns) follows
+// One pass of the tile stream over `nt` rows of a row-major bf16 matrix and k = k0 + 32 [0, ksteps): self-contained for the
+// DMA issuer (no second table look-up on its critical path).  Both sources are pre-offset to the sweep's first row:
+//   w: the weight rows themselves (a K-extension tile is a sweep of its own: w = rows of scale*up, one k-step);
+//   x: the stacked lora_down rows riding in the tiles (16 tf of them, appended behind the nt weight rows).
+struct XSweep {
+    const void* w; const void* x;
+    unsigned w_bytes, x_bytes;
+    unsigned ldw_b, ldx_b;       // row strides in bytes
+    int nt, k0, ksteps, tf;
 };
 struct XProg {
     int nsweeps;
+    int pad;
     XLin lin[7];
     XSweep sw[XMAXSW];
 };
@@ -133,7 +136,14 @@ struct Stripe {
     int w_ofs24;       // byte offset of tile row wn * WN + fr (+ swizzled k-group)
     int lrow;          // DMA: tile row inside a 16-row piece
     unsigned csrc16;   // DMA: source byte offset of the 16-byte chunk this lane fetches
-    // weight stream
+    // weight stream: the sweep being issued lives in registers (`cur`), the one after it is prefetched (`nxt`) when `cur`
+    // is entered, so the scalar loads of the table never sit on the issue path
+    struct SweepRegs {
+        buf_rsrc rw, rx;
+        unsigned ldw_b, ldx_b;
+        int npm, k0, ksteps, tf;
+    };
+    SweepRegs cur, nxt;
     int s_si = 0, s_kt = 0, s_islot = 0, s_cslot = 0, c_next = 0;
 
     __device__ __forceinline__ Stripe(const LECO_CONST_AS XProg* pg) : prog(pg) {
@@ -154,49 +164,46 @@ struct Stripe {
         csrc16 = (unsigned)(((lane & 3) ^ ((4 - ((lrow >> 2) & 3)) & 3)) << 4);
     }
 
-    // ---- weight-tile stream ------------------------------------------------------------------------------------------
-    // issues the next tile of the program (if any) into the next ring slot; returns this wave's DMA piece count
+    __device__ __forceinline__ void load_sweep(SweepRegs& r, int si) const {
+        const int i = si < prog->nsweeps ? si : 0;       // (past the end: any valid entry; never issued)
+        const LECO_CONST_AS XSweep* sw = &prog->sw[i];
+        const void* x = sw->x;
+        r.rw = make_rsrc(sw->w, sw->w_bytes);
+        r.rx = make_rsrc(x ? x : sw->w, x ? sw->x_bytes : sw->w_bytes);
+        r.ldw_b = sw->ldw_b; r.ldx_b = sw->ldx_b;
+        r.npm = sw->nt >> 4; r.k0 = sw->k0; r.ksteps = sw->ksteps; r.tf = sw->tf;
+    }
+    // issues the next tile of the program (if any) into the next ring slot; returns this wave's DMA piece count.
+    // Piece pc (16 tile rows, 1 KB): lane l fetches 16 bytes of row 16 pc + l / 4; the row / k part of the address is
+    // scalar (soffset), the lane part (row-in-piece x stride + swizzled chunk) a per-lane constant.
     __device__ __forceinline__ int issue_tile() {
         if (s_si >= prog->nsweeps) return 0;
-        const LECO_CONST_AS XSweep* sw = &prog->sw[s_si];
-        const int ksteps = sw->ksteps, n0 = sw->n0;
-        const LECO_CONST_AS XLin* L = &prog->lin[sw->lin];
-        const bool ext = s_kt == ksteps;
-        const int npm = sw->nt >> 4, np = ext ? npm : npm + sw->tf;
+        const int npm = cur.npm, np = npm + cur.tf;
         unsigned char* dst = ring + s_islot * SLOT;
         int cnt = 0;
-        if (!ext) {
-            const void* dn = L->dn;
-            const buf_rsrc rw = make_rsrc(L->w, L->w_bytes);
-            const buf_rsrc rd = make_rsrc(dn ? dn : L->w, dn ? L->dn_bytes : L->w_bytes);
-            const unsigned soff = (unsigned)(sw->k0 + XKT * s_kt) * 2u;
-            const unsigned ldw_b = L->ldw_b, lddn_b = L->lddn_b;
+        const unsigned kb = (unsigned)(cur.k0 + XKT * s_kt) * 2u;
+        const unsigned vw = (unsigned)lrow * cur.ldw_b + csrc16, vx = (unsigned)lrow * cur.ldx_b + csrc16;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int pc = wave + 8 * i;
-                if (pc < np) {
-                    if (pc < npm) glds16_buf(rw, (unsigned)(n0 + 16 * pc + lrow) * ldw_b + csrc16, soff, dst + pc * 1024);
-                    else glds16_buf(rd, (unsigned)(16 * (pc - npm) + lrow) * lddn_b + csrc16, soff, dst + pc * 1024);
-                    ++cnt;
-                }
-            }
-        } else {
-            const buf_rsrc ru = make_rsrc(L->up, L->up_bytes);
-            const unsigned ldup_b = L->ldup_b;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int pc = wave + 8 * i;
-                if (pc < np) {
-                    glds16_buf(ru, (unsigned)(n0 + 16 * pc + lrow) * ldup_b + csrc16, 0u, dst + pc * 1024);
-                    ++cnt;
-                }
+        for (int i = 0; i < 3; ++i) {
+            const int pc = wave + 8 * i;
+            if (pc < np) {
+                if (pc < npm) glds16_buf(cur.rw, vw, kb + (unsigned)(16 * pc) * cur.ldw_b, dst + pc * 1024);
+                else glds16_buf(cur.rx, vx, kb + (unsigned)(16 * (pc - npm)) * cur.ldx_b, dst + pc * 1024);
+                ++cnt;
             }
         }
-        if (++s_kt == ksteps + sw->ext) { ++s_si; s_kt = 0; }
+        if (++s_kt == cur.ksteps) {
+            ++s_si;
+            s_kt = 0;
+            cur = nxt;
+            load_sweep(nxt, s_si + 1);
+        }
         s_islot = s_islot == XNS - 1 ? 0 : s_islot + 1;
         return cnt;
     }
     __device__ __forceinline__ void start_stream() {
+        load_sweep(cur, 0);
+        load_sweep(nxt, 1);
         (void)issue_tile();
         c_next = issue_tile();
     }
@@ -212,12 +219,17 @@ struct Stripe {
         barrier_keep_dma();
         const unsigned char* s = ring + s_cslot * SLOT;
         s_cslot = s_cslot == XNS - 1 ? 0 : s_cslot + 1;
-        c_next = issue_tile();
         return s;
     }
+    // refill of the slot the last acquire() freed: called once after every acquire(), behind the fragment reads and the
+    // MFMAs the caller had ready (the DMA instructions occupy the wave for ~100 cycles each)
+    __device__ __forceinline__ void refill() { c_next = issue_tile(); }
 
     // ---- activation buffers ------------------------------------------------------------------------------------------
     __device__ __forceinline__ int a_chunk(int chunk) const { return (chunk ^ a_sw) << 4; }
+    // re-derives the lane's chunk swizzle behind an optimisation barrier: the per-k-step chunk offsets are the same in every
+    // sweep, and hipcc otherwise keeps all of them live through the whole kernel (and spills)
+    __device__ __forceinline__ void fresh_swizzle() { opaque(a_sw); }
     // lane's 4 consecutive columns n .. n + 3 (n % 4 == 0) of row-offset `rowb` as bf16
     __device__ __forceinline__ void put4(unsigned char* buf, int rowb, int n, float v0, float v1, float v2, float v3) const {
         const u32x2 w = {pack_bf2(v0, v1), pack_bf2(v2, v3)};
@@ -277,12 +289,14 @@ struct Stripe {
         const int t_ofs = (nt + 16 * tq + fr) * 64 + swz4;
         F24 f[2];
         f[0].t = f[1].t = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        fresh_swizzle();
 #pragma unroll
         for (int kt = 0; kt < NK; ++kt) {
             const unsigned char* s = acquire();       // (its barrier completed the previous tile's fragment reads)
             if (kt > 0) tie24(f[(kt - 1) & 1], has_t);
             read24(f[kt & 1], abuf, ka0 + kt, s, t_ofs, has_t);
             if (kt > 0) mma24(acc, acct, f[(kt - 1) & 1], has_t, ti);
+            refill();
         }
         lds_wait<0>();
         tie24(f[(NK - 1) & 1], has_t);
@@ -311,6 +325,7 @@ struct Stripe {
         tie24(f, false);
         f32x4 dummy = {0.f, 0.f, 0.f, 0.f};
         mma24(acc, dummy, f, false, 0);
+        refill();
     }
     // a whole Linear on the 2 x 4 layout: K = C, A = abuf, accumulated into acc (bias NOT added)
     __device__ __forceinline__ void linear24(f32x4 (&acc)[2][FNC], const unsigned char* abuf, int lin) {
@@ -680,6 +695,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
             for (int i = 0; i < 4; ++i) { u[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; u[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
             f32x4 acct1 = {0.f, 0.f, 0.f, 0.f};
             const bool with_t = has_t1 && c == 0;        // the lora_down rows ride in the first chunk's tiles only
+            st.fresh_swizzle();
             auto mma18 = [&](const typename St::F18& f) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -697,6 +713,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
                 if (kt > 0) tie18(f1[(kt - 1) & 1], with_t);
                 read18(f1[kt & 1], kt, s, with_t);
                 if (kt > 0) mma18(f1[(kt - 1) & 1]);
+                st.refill();
             }
             lds_wait<0>();
             tie18(f1[(KS - 1) & 1], with_t);
@@ -716,6 +733,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
                     u[i][0] = mfma16(f.w[0], f.a[i], u[i][0]);
                     u[i][1] = mfma16(f.w[1], f.a[i], u[i][1]);
                 }
+                st.refill();
             }
             // GEGLU: value * gelu(gate) -> bf16 chunk [64][128] in bufB (columns 0 .. 127)
             {
@@ -744,12 +762,14 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
             {
                 typename St::F24 f2[2];
                 f2[0].t = f2[1].t = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                st.fresh_swizzle();
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
                     const unsigned char* s = st.acquire();
                     if (kt > 0) st.tie24(f2[(kt - 1) & 1], has_t2);
                     st.read24(f2[kt & 1], st.bufB, kt, s, t2_ofs, has_t2);
                     if (kt > 0) st.mma24(h, acct2, f2[(kt - 1) & 1], has_t2, ti2);
+                    st.refill();
                 }
                 lds_wait<0>();
                 st.tie24(f2[1], has_t2);
@@ -810,20 +830,30 @@ __global__ __launch_bounds__(256) void xattn_prep_kernel(const bf16_t* kv, int64
     }
 }
 
-int fill_lin(XLin& L, const leco_xlin& a, int n, int k, const char* what) {
+struct HostLin { const leco_xlin* a; int n, tf; };
+int check_lin(HostLin& L, const leco_xlin& a, int n, const char* what) {
     if (!a.w) return fail(-EINVAL, "%s: null weight", what);
     if (a.ldw % 8 || (a.dn && (a.ld_dn % 8 || a.ld_up % 8))) return fail(-EINVAL, "%s: operand strides must be multiples of 8 elements", what);
     if (a.dn && (!a.up || (a.t_rows != 16 && a.t_rows != 32))) return fail(-EINVAL, "%s: LoRA needs up and t_rows in {16, 32}", what);
-    const int64_t wb = (int64_t)n * a.ldw * 2;
-    if (wb >= ((int64_t)1 << 31)) return fail(-EINVAL, "%s: weight too large for a buffer descriptor", what);
-    L.w = a.w; L.w_bytes = (unsigned)wb; L.ldw_b = (unsigned)(a.ldw * 2);
-    L.bias = a.bias;
-    L.dn = a.dn; L.up = a.dn ? a.up : nullptr;
-    L.tf = a.dn ? a.t_rows / 16 : 0;
-    L.dn_bytes = a.dn ? (unsigned)((int64_t)a.t_rows * a.ld_dn * 2) : 0u; L.lddn_b = (unsigned)(a.ld_dn * 2);
-    L.up_bytes = a.dn ? (unsigned)((int64_t)n * a.ld_up * 2) : 0u; L.ldup_b = (unsigned)(a.ld_up * 2);
-    (void)k;
+    if ((int64_t)n * a.ldw * 2 >= ((int64_t)1 << 31)) return fail(-EINVAL, "%s: weight too large for a buffer descriptor", what);
+    L.a = &a; L.n = n; L.tf = a.dn ? a.t_rows / 16 : 0;
     return 0;
+}
+// sweep over weight rows [n0, n0 + nt) and k = k0 + 32 [0, ksteps) of Linear `L`; with_dn: its lora_down rows ride in the
+// tiles; ext: the K-extension tile (rows [n0, n0 + nt) of scale*up, one k-step) follows as a sweep of its own
+void fill_sweep(XProg& pg, int& ns, const HostLin& L, int n0, int nt, int k0, int ksteps, bool with_dn, bool ext) {
+    const leco_xlin& a = *L.a;
+    XSweep& s = pg.sw[ns++];
+    memset(&s, 0, sizeof(s));
+    s.w = (const char*)a.w + (int64_t)n0 * a.ldw * 2; s.w_bytes = (unsigned)((int64_t)nt * a.ldw * 2); s.ldw_b = (unsigned)(a.ldw * 2);
+    if (with_dn && L.tf) { s.x = a.dn; s.x_bytes = (unsigned)((int64_t)a.t_rows * a.ld_dn * 2); s.ldx_b = (unsigned)(a.ld_dn * 2); s.tf = L.tf; }
+    s.nt = nt; s.k0 = k0; s.ksteps = ksteps;
+    if (ext && L.tf) {
+        XSweep& e = pg.sw[ns++];
+        memset(&e, 0, sizeof(e));
+        e.w = (const char*)a.up + (int64_t)n0 * a.ld_up * 2; e.w_bytes = (unsigned)((int64_t)nt * a.ld_up * 2); e.ldw_b = (unsigned)(a.ld_up * 2);
+        e.nt = nt; e.k0 = 0; e.ksteps = 1;
+    }
 }
 
 // > 64 KB of dynamic LDS needs the opt-in attribute: once per kernel (ID) AND device
@@ -889,25 +919,24 @@ extern "C" int leco_xblock_tail_build(const leco_xblock_tail_args* a, void* host
     memset(blob, 0, sizeof(*blob));
     XProg& pg = blob->prog;
     int rc;
-    if ((rc = fill_lin(pg.lin[0], a->to_out1, C, C, "leco_xblock_tail.to_out1"))) return rc;
-    if ((rc = fill_lin(pg.lin[1], a->to_q2, C, C, "leco_xblock_tail.to_q2"))) return rc;
-    if ((rc = fill_lin(pg.lin[2], a->to_out2, C, C, "leco_xblock_tail.to_out2"))) return rc;
-    if ((rc = fill_lin(pg.lin[3], a->ff1, 2 * F, C, "leco_xblock_tail.ff1"))) return rc;
-    if ((rc = fill_lin(pg.lin[4], a->ff2, C, F, "leco_xblock_tail.ff2"))) return rc;
+    HostLin L[6];
+    if ((rc = check_lin(L[0], a->to_out1, C, "leco_xblock_tail.to_out1"))) return rc;
+    if ((rc = check_lin(L[1], a->to_q2, C, "leco_xblock_tail.to_q2"))) return rc;
+    if ((rc = check_lin(L[2], a->to_out2, C, "leco_xblock_tail.to_out2"))) return rc;
+    if ((rc = check_lin(L[3], a->ff1, 2 * F, "leco_xblock_tail.ff1"))) return rc;
+    if ((rc = check_lin(L[4], a->ff2, C, "leco_xblock_tail.ff2"))) return rc;
     const bool has_po = a->proj_out.w != nullptr;
-    if (has_po && (rc = fill_lin(pg.lin[5], a->proj_out, C, C, "leco_xblock_tail.proj_out"))) return rc;
+    if (has_po && (rc = check_lin(L[5], a->proj_out, C, "leco_xblock_tail.proj_out"))) return rc;
+    for (int l = 0; l < (has_po ? 6 : 5); ++l) { pg.lin[l].bias = L[l].a->bias; pg.lin[l].tf = L[l].tf; }
     int ns = 0;
-    auto sweep = [&](int lin, int n0, int nt, int k0, int ksteps, int tf, int ext) {
-        XSweep& s = pg.sw[ns++];
-        s.lin = lin; s.n0 = n0; s.nt = nt; s.k0 = k0; s.ksteps = ksteps; s.tf = tf; s.ext = ext;
-    };
-    for (int l = 0; l < 3; ++l) sweep(l, 0, C, 0, C / XKT, pg.lin[l].tf, pg.lin[l].tf ? 1 : 0);
+    for (int l = 0; l < 3; ++l) fill_sweep(pg, ns, L[l], 0, C, 0, C / XKT, true, true);
     const int nchunk = F / 128;
     for (int c = 0; c < nchunk; ++c) {
-        sweep(3, 256 * c, 256, 0, C / XKT, c == 0 ? pg.lin[3].tf : 0, pg.lin[3].tf ? 1 : 0);
-        sweep(4, 0, C, 128 * c, 4, pg.lin[4].tf, (pg.lin[4].tf && c == nchunk - 1) ? 1 : 0);
+        fill_sweep(pg, ns, L[3], 256 * c, 256, 0, C / XKT, c == 0, true);
+        fill_sweep(pg, ns, L[4], 0, C, 128 * c, 4, true, c == nchunk - 1);
     }
-    if (has_po) sweep(5, 0, C, 0, C / XKT, pg.lin[5].tf, pg.lin[5].tf ? 1 : 0);
+    if (has_po) fill_sweep(pg, ns, L[5], 0, C, 0, C / XKT, true, true);
+    if (ns > XMAXSW) return fail(-EINVAL, "leco_xblock_tail: sweep table overflow");
     pg.nsweeps = ns;
     XTailArgs& p = blob->p;
     p.m = a->m; p.heads = a->heads; p.skv = a->skv; p.rows_per_sample = a->rows_per_sample;

@@ -998,13 +998,87 @@ class PlanBuilder:
         return self.gemm_fwd(eng.sites[rname + ".conv2"], n2, rname + ".out", conv=conv, amode=A_CONV3_S1, rows=rows,
                              residual=sc, stats_hw=hw)
 
-    def basic_block(self, bname: str, hcur: TRef, ctx: TRef, heads: int, hw: int) -> TRef:
+    def stripe_ok(self, bname: str, tname: str, Cc: int, heads: int, hw: int, skv: int) -> bool:
+        """The row-stripe fused kernels (csrc/stripe.hip) cover this block: forward-only bf16 plan, a supported shape, and
+        LoRA operands (if any) in the 32-column packed form.  LECO_STRIPE=0 keeps the per-op launches (A/B measurements)."""
+        import os
+        if self.need_bwd or self.eng.f32 or os.environ.get("LECO_STRIPE", "1") == "0":
+            return False
+        if not ops.xblock_supported(Cc, heads, skv, hw):
+            return False
+        S = self.eng.sites
+        names = [bname + n for n in (".attn1.to_out.0", ".attn2.to_q", ".attn2.to_out.0", ".ff.net.0.proj", ".ff.net.2")]
+        names += [tname + ".proj_out", tname + ".proj_in", bname + ".attn1.qkv"]
+        for nm in names:
+            lo = S[nm].lora
+            if lo is not None and (lo.Rp != 32 or (nm.endswith("ff.net.0.proj") and lo.up_pg is None)):
+                return False
+        return S[bname + ".ff.net.0.proj"].geglu_ok
+
+    def _xlin(self, site: GemmSite, lora_on: bool, geglu: bool = False):
+        w, b = site.w_geglu if geglu else (site.w, site.bias)
+        lo = site.lora if lora_on else None
+        if lo is None:
+            return hip.xlin(w, b), (site, w, b)
+        up = lo.up_pg if geglu else lo.up_p
+        return hip.xlin(w, b, lo.dn_s, up, lo.R16, ld_up=lo.Rp), (site, w, b, lo)
+
+    def block_tail_fused(self, bname: str, tname: str, a1: TRef, hcur: TRef, kv: TRef, heads: int, hw: int, last: bool,
+                         x_res: Optional[TRef]) -> TRef:
+        """Everything of the block after its self-attention core (+ proj_out and the Transformer2DModel residual when the
+        block is the last one) as ONE launch per list (LoRA on / off): `leco_xblock_tail`."""
+        eng, S = self.eng, self.eng.sites
+        rows, Cc = hcur.rows, hcur.cols
+        skv = kv.rows // self.B
+        d = Cc // heads
+        kp, vt = ops.xattn_buffers(self.B, heads, d, self.dev)
+        self.plan.bufs[bname + ".xattn_kp"], self.plan.bufs[bname + ".xattn_vt"] = kp, vt
+        prep = ops.xattn_prep(kv.ptr, kv.ld, kp, vt, self.B, heads, skv, d)
+        prep.tag = "ctx"
+        self.both(prep)
+        out = self.act((tname + ".out") if last else (bname + ".h3"), rows, Cc)
+        if last:
+            out.cstats = self.stat_slice(Cc, hw) if self.stat_atom % 2 == 0 else None
+        g2, b2 = eng.norm_p[bname + ".norm2"]
+        g3, b3 = eng.norm_p[bname + ".norm3"]
+        for lora_on, lst in ((True, self.f_on), (False, self.f_off)):
+            A = hip.XBlockTailArgs()
+            keep = [a1, hcur, kv, out, kp, vt, g2, b2, g3, b3, x_res, self.stat_arena]
+            A.m, A.c, A.heads, A.skv, A.rows_per_sample = rows, Cc, heads, skv, hw
+            A.attn, A.ld_attn, A.h_in, A.ld_h = a1.ptr, a1.ld, hcur.ptr, hcur.ld
+            for fld, nm, gg in (("to_out1", bname + ".attn1.to_out.0", False), ("to_q2", bname + ".attn2.to_q", False),
+                                ("to_out2", bname + ".attn2.to_out.0", False), ("ff1", bname + ".ff.net.0.proj", True),
+                                ("ff2", bname + ".ff.net.2", False)) + ((("proj_out", tname + ".proj_out", False),) if last else ()):
+                xl, kp_ = self._xlin(S[nm], lora_on, gg)
+                setattr(A, fld, xl)
+                keep.append(kp_)
+            A.ln2_g, A.ln2_b, A.ln3_g, A.ln3_b, A.ln_eps = g2.data_ptr(), b2.data_ptr(), g3.data_ptr(), b3.data_ptr(), 1e-5
+            A.kp, A.vt, A.attn_scale = kp.data_ptr(), vt.data_ptr(), d ** -0.5
+            if last:
+                A.res, A.ld_res = x_res.ptr, x_res.ld
+            A.out, A.ld_out = out.ptr, out.ld
+            if out.cstats is not None:
+                A.col_stats, A.stats_atom = out.cstats, self.stat_atom
+            lst.append(ops.xblock_tail(A, self.dev, keep=keep))
+        return out
+
+    def basic_block(self, bname: str, hcur: TRef, ctx: TRef, heads: int, hw: int, tname: str = "", last: bool = False,
+                    x_res: Optional[TRef] = None) -> Tuple[TRef, bool]:
+        """Returns (output, done): `done` = the output already is the Transformer2DModel's (proj_out + residual applied by the
+        fused tail kernel)."""
         eng = self.eng
         rows, Cc = hcur.rows, hcur.cols
         S = eng.sites
+        fused = bool(tname) and self.stripe_ok(bname, tname, Cc, heads, hw, ctx.rows // self.B)
         l1 = self.layernorm(bname + ".norm1", hcur, bname + ".l1")
         qkv = self.gemm_fwd(S[bname + ".attn1.qkv"], l1, bname + ".qkv", rows=rows)
         a1 = self.attention(qkv, qkv, heads, hw, hw, bname + ".a1")
+        if fused:
+            n_on, n_off = len(self.f_on), len(self.f_off)
+            kv = self.gemm_fwd(S[bname + ".attn2.kv"], ctx, bname + ".kv", rows=ctx.rows)
+            for op in self.f_on[n_on:] + self.f_off[n_off:]:
+                op.tag = "ctx"
+            return self.block_tail_fused(bname, tname, a1, hcur, kv, heads, hw, last, x_res), last
         h1 = self.gemm_fwd(S[bname + ".attn1.to_out.0"], a1, bname + ".h1", rows=rows, residual=hcur)
         l2 = self.layernorm(bname + ".norm2", h1, bname + ".l2")
         q2 = self.gemm_fwd(S[bname + ".attn2.to_q"], l2, bname + ".q2", rows=rows)
@@ -1020,7 +1094,7 @@ class PlanBuilder:
         ff1 = S[bname + ".ff.net.0.proj"]
         if not self.need_bwd and not eng.f32 and ff1.geglu_ok and (ff1.lora is None or (ff1.lora.Rp == 32 and ff1.lora.up_pg is not None)):
             gg = self.gemm_fwd(ff1, l3, bname + ".geglu", rows=rows, geglu=True)
-            return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2)
+            return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2), False
         u = self.gemm_fwd(ff1, l3, bname + ".u", rows=rows)
         gg = self.act(bname + ".geglu", rows, 4 * Cc, rg=u.rg)
         self.both(ops.Op("leco_geglu_fwd", (u.ptr, u.ld, gg.ptr, gg.ld, rows, 4 * Cc), keep=(u, gg)))
@@ -1035,15 +1109,19 @@ class PlanBuilder:
                                   keep=(u, dg, du)))
                 u.gparts.append(du)
             self.tape.append(bwd)
-        return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2)
+        return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2), False
 
     def transformer(self, tname: str, x: TRef, ctx: TRef, level: int, hs: int, ws: int) -> TRef:
         eng, m = self.eng, self.eng.named[tname]
         hw, rows = hs * ws, self.B * hs * ws
         n = self.groupnorm(tname + ".norm", x, hw, ACT_NONE, 1e-6, tname + ".n")
         p = self.gemm_fwd(eng.sites[tname + ".proj_in"], n, tname + ".pin", rows=rows)
-        for i in range(len(m.transformer_blocks)):
-            p = self.basic_block(f"{tname}.transformer_blocks.{i}", p, ctx, self.cfg.heads(level), hw)
+        nb = len(m.transformer_blocks)
+        for i in range(nb):
+            p, done = self.basic_block(f"{tname}.transformer_blocks.{i}", p, ctx, self.cfg.heads(level), hw, tname=tname,
+                                       last=i == nb - 1, x_res=x)
+            if done:
+                return p
         return self.gemm_fwd(eng.sites[tname + ".proj_out"], p, tname + ".out", rows=rows, residual=x, stats_hw=hw)
 
     # ---- whole network ---------------------------------------------------------------------------

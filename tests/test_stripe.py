@@ -168,3 +168,67 @@ def test_stripe_dma_protocol_under_late_completion():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", os.path.abspath(__file__), "-k",
                         "matches_the_per_op_chain and emu and 8-4-True"], env=env, capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _stripe_unet(dev, heads=8):
+    from leco_amd import model_util
+    from leco_amd.unet import UNet2DConditionModel, UNetConfig
+    cfg = UNetConfig(block_out_channels=(320, 320), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                     up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), layers_per_block=1, attention_head_dim=heads,
+                     cross_attention_dim=64, sample_size=8)
+    m = model_util.init_synthetic_(UNet2DConditionModel(cfg), seed=7).to(dev, bf)
+    m.requires_grad_(False)
+    return m
+
+
+def _run_plan(m, plan, which, x, ctx, t=500.0):
+    plan.x_in.copy_(x)
+    plan.ctx.copy_(ctx)
+    plan.t_table[:1].fill_(t)
+    plan.t_idx.zero_()
+    m._run(plan, which)
+    return plan.pred.float().cpu().clone()
+
+
+@pytest.mark.parametrize("heads,rank", [(8, 4), (5, 0)])
+def test_forward_only_plans_run_the_stripe_kernels_and_match_the_per_op_plan(dev, heads, rank, monkeypatch):
+    """A UNet whose 64-pixel level has 320 channels: the forward-only plan (what the denoising passes and the batched
+    frozen pass replay) runs each transformer block's tail as `leco_xblock_tail`; its prediction equals the per-op plan's
+    (LECO_STRIPE=0) to bf16 rounding -- LoRA on and off."""
+    import contextlib
+    import io
+    from leco_amd.lora import LoRANetwork
+    torch.manual_seed(5)
+    m = _stripe_unet(dev, heads)
+    if rank:
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = LoRANetwork(m, rank=rank, multiplier=1.0, alpha=1.0)
+        with torch.no_grad():
+            for l in net.unet_loras:
+                l.lora_up.weight.normal_(0, 0.02)
+        net.mark_updated()
+    B, h, w = 2, 8, 8
+    x = torch.randn(B, 4, h, w).to(dev, bf); ctx = torch.randn(B, 77, 64).to(dev, bf)
+    eng = m.engine()
+    if rank:
+        net.multiplier = 1.0
+        m.prepare((B, 4, h, w), lora_on=True)
+    fused = eng.plan(B, h, w, need_bwd=False)
+    names = [op.name for op in fused.lists["fwd_on"]]
+    assert names.count("leco_xblock_tail_run") == 3 and names.count("leco_xattn_prep") == 3
+    # norm1 of the 3 fused blocks (norm2 / norm3 live in the stripe kernel) + the mid block (16 pixels: per-op launches)
+    assert names.count("leco_layernorm_fwd") == 3 + 3
+    y_on = _run_plan(m, fused, "fwd_on", x, ctx)
+    y_off = _run_plan(m, fused, "fwd_off", x, ctx)
+    monkeypatch.setenv("LECO_STRIPE", "0")
+    eng.plans.clear()
+    plain = eng.plan(B, h, w, need_bwd=False)
+    assert "leco_xblock_tail_run" not in [op.name for op in plain.lists["fwd_on"]]
+    p_on = _run_plan(m, plain, "fwd_on", x, ctx)
+    p_off = _run_plan(m, plain, "fwd_off", x, ctx)
+    _sync(dev)
+    e_on, e_off = rel_err(y_on, p_on), rel_err(y_off, p_off)
+    print(f"stripe vs per-op plan: LoRA on {e_on:.3g}, off {e_off:.3g}; on-vs-off {rel_err(p_on, p_off):.3g}")
+    assert e_on < 1e-2 and e_off < 1e-2
+    if rank:
+        assert rel_err(p_on, p_off) > 1e-3 and rel_err(y_on, y_off) > 1e-3     # the LoRA term is really there

@@ -52,6 +52,11 @@ def describe(op):
         return f"layernorm_bwd M={a[9]} C={a[10]}", 0.0, 8.0 * a[9] * a[10]
     if op.name in ("leco_geglu_fwd", "leco_geglu_bwd"):
         return f"{op.name[5:]} M={a[-2]} F={a[-1]}", 0.0, 6.0 * a[-2] * a[-1]
+    if op.name == "leco_xblock_tail_run":
+        m, c = a[1], op.keep[1].c
+        po = 1 if op.keep[1].proj_out.w else 0
+        return (f"xblock_tail M={m} C={c} d={a[2]}" + (" +proj_out" if po else ""),
+                m * (2.0 * c * c * (15 + po) + 4.0 * op.keep[1].skv * c), 2.0 * m * c * (3 + po))
     return op.name[5:], 0.0, 0.0
 
 
