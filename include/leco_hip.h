@@ -365,6 +365,23 @@ int64_t leco_xblock_prog_bytes(void);
 int leco_xblock_tail_build(const leco_xblock_tail_args* args, void* host_prog, int64_t host_bytes);
 int leco_xblock_tail_run(const void* dev_prog, int32_t m, int32_t head_dim, leco_stream_t stream);
 
+/* Everything of a Transformer2DModel BEFORE the self-attention core of its first BasicTransformerBlock:
+ *   n = GroupNorm(x) from the statistics the producer of x left (gn_cstats: fp32 [batch][c / stats_atom][2] {sum, sumsq},
+ *       leco_gemm_args.col_stats; NULL: x is already normalised);  h_out = proj_in(n);  qkv_out = to_q|to_k|to_v(LN1(h_out)).
+ * qkv is the fused [3 c][c] projection (its stacked lora_down rows are shared by the three 320-column sweeps). */
+typedef struct leco_xblock_head_args {
+    int32_t m, c, rows_per_sample;
+    const void* x; int64_t ld_x;                 /* bf16 [m][c] */
+    const float* gn_cstats; int32_t stats_atom; int32_t groups;
+    const float* gn_g; const float* gn_b; float gn_eps;
+    leco_xlin proj_in, qkv;
+    const float* ln1_g; const float* ln1_b; float ln_eps;
+    void* h_out; int64_t ld_hout;                /* bf16 [m][c]: the residual stream entering the block */
+    void* qkv_out; int64_t ld_qkv;               /* bf16 [m][3 c] */
+} leco_xblock_head_args;
+int leco_xblock_head_build(const leco_xblock_head_args* args, void* host_prog, int64_t host_bytes);
+int leco_xblock_head_run(const void* dev_prog, int32_t m, leco_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * hipGraph capture of a whole UNet pass (the reference issues ~10^4 eager kernel launches
  * per pass from Python; here a pass is one graph launch).

@@ -47,6 +47,20 @@
 namespace leco {
 namespace {
 
+// Tuning aids (tools/ablate_stripe.py builds side libraries): LECO_STRIPE_ABLATE bit mask -- 1 = no MFMA, 2 = no weight DMA,
+// 4 = no fragment reads, 8 = no cross-attention, 16 = no waits / barriers in the tile stream; results are garbage with any bit
+// set, only the time means something.  LECO_STRIPE_TIMING: workgroup 0 stamps the shader clock at every phase boundary
+// into a device array (leco_xblock_debug_times).  Both 0 / undefined in the product build.
+#ifndef LECO_STRIPE_ABLATE
+#define LECO_STRIPE_ABLATE 0
+#endif
+#ifdef LECO_STRIPE_TIMING
+__device__ unsigned long long g_xtimes[32];
+#define XSTAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_xtimes[i] = clock64(); } while (0)
+#else
+#define XSTAMP(i) do { } while (0)
+#endif
+
 constexpr int XBM = 64;      // token rows per stripe
 constexpr int XKT = 32;      // k per weight tile
 constexpr int XNS = 3;       // ring slots
@@ -113,6 +127,7 @@ struct XHeadArgs {
     bf16_t* h_out; int64_t ld_hout;
     bf16_t* qkv_out; int64_t ld_qkv;
 };
+struct XHeadBlob { XHeadArgs p; XProg prog; };
 
 // ------------------------------------------------------------------------------------------------------------------
 // Shared machinery of the stripe kernels: lane constants, the weight-tile stream, the two GEMM wave layouts, LayerNorm
@@ -187,9 +202,11 @@ struct Stripe {
         for (int i = 0; i < 3; ++i) {
             const int pc = wave + 8 * i;
             if (pc < np) {
-                if (pc < npm) glds16_buf(cur.rw, vw, kb + (unsigned)(16 * pc) * cur.ldw_b, dst + pc * 1024);
-                else glds16_buf(cur.rx, vx, kb + (unsigned)(16 * (pc - npm)) * cur.ldx_b, dst + pc * 1024);
-                ++cnt;
+                if (!(LECO_STRIPE_ABLATE & 2)) {
+                    if (pc < npm) glds16_buf(cur.rw, vw, kb + (unsigned)(16 * pc) * cur.ldw_b, dst + pc * 1024);
+                    else glds16_buf(cur.rx, vx, kb + (unsigned)(16 * (pc - npm)) * cur.ldx_b, dst + pc * 1024);
+                    ++cnt;
+                }
             }
         }
         if (++s_kt == cur.ksteps) {
@@ -212,11 +229,13 @@ struct Stripe {
     // outstanding" implies the older pieces of the tile about to be read are complete; other vector-memory operations in
     // between only make the wait stronger.)
     __device__ __forceinline__ const unsigned char* acquire() {
-        if (c_next >= 3) wait_vmcnt<3>();
-        else if (c_next == 2) wait_vmcnt<2>();
-        else if (c_next == 1) wait_vmcnt<1>();
-        else wait_vmcnt<0>();
-        barrier_keep_dma();
+        if (!(LECO_STRIPE_ABLATE & 16)) {
+            if (c_next >= 3) wait_vmcnt<3>();
+            else if (c_next == 2) wait_vmcnt<2>();
+            else if (c_next == 1) wait_vmcnt<1>();
+            else wait_vmcnt<0>();
+            barrier_keep_dma();
+        }
         const unsigned char* s = ring + s_cslot * SLOT;
         s_cslot = s_cslot == XNS - 1 ? 0 : s_cslot + 1;
         return s;
@@ -243,6 +262,20 @@ struct Stripe {
             for (int j = 0; j < FNC; ++j)
                 put4(buf, a_rows24 + 16 * i * ARS, wn * WN + 16 * j + 4 * fg, v[i][j][0], v[i][j][1], v[i][j][2], v[i][j][3]);
     }
+    // a [64][C] accumulator set (2 x 4 layout) as bf16 to global memory: columns col0 .. col0 + C of out (8-byte stores)
+    __device__ __forceinline__ void store_global24(const f32x4 (&v)[2][FNC], bf16_t* out, int64_t ld, int col0, int m0, int m) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + wm * 32 + 16 * i + fr;
+            if (row < m) {
+#pragma unroll
+                for (int j = 0; j < FNC; ++j) {
+                    const u32x2 w = {pack_bf2(v[i][j][0], v[i][j][1]), pack_bf2(v[i][j][2], v[i][j][3])};
+                    *(u32x2*)(out + (int64_t)row * ld + col0 + wn * WN + 16 * j + 4 * fg) = w;
+                }
+            }
+        }
+    }
     // DMA of a [64][C] bf16 stripe (rows m0 .. m0 + 63 of a row-major matrix; rows >= m: zeros) into an activation buffer
     __device__ __forceinline__ void load_stripe(unsigned char* buf, const void* base, unsigned bytes, unsigned ld_b, int m0, int m) {
         const buf_rsrc r = make_rsrc(base, bytes);
@@ -261,6 +294,7 @@ struct Stripe {
 
     // ---- 2 x 4 layout: wave (wm, wn) owns rows wm * 32 .. + 32, tile rows wn * WN .. + WN ---------------------------------
     __device__ __forceinline__ void read24(F24& f, const unsigned char* abuf, int ka, const unsigned char* s, int t_ofs, bool has_t) const {
+        if (LECO_STRIPE_ABLATE & 4) return;
         const int ao = a_chunk(4 * ka + fg);
         f.a[0] = lds_read16_async(abuf + a_rows24 + ao);
         f.a[1] = lds_read16_async(abuf + a_rows24 + 16 * ARS + ao);
@@ -275,6 +309,13 @@ struct Stripe {
         if (has_t) lds_tie(f.t);
     }
     __device__ __forceinline__ void mma24(f32x4 (&acc)[2][FNC], f32x4& acct, const F24& f, bool has_t, int ti) const {
+        if (LECO_STRIPE_ABLATE & 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < FNC; ++j) acc[i][j][0] += __uint_as_float((unsigned)(f.w[j][0] ^ f.a[i][0]));
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -548,10 +589,13 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
     }
 
     // ---- 1. h1 = a1 Wo1^T + bo1 + h0
+    XSTAMP(0);
     st.linear24(h, st.bufA, 0);
+    XSTAMP(1);
     st.add_bias24(h, prog->lin[0].bias, 0);
     // ---- 2. l2 = LN2(h1) -> bufB
     st.layernorm24(h, p.ln2_g, p.ln2_b, p.ln_eps, st.bufB);
+    XSTAMP(2);
     // ---- 3. q2 = l2 Wq2^T -> bufA (bf16)
     {
         f32x4 q[2][FNC];
@@ -564,9 +608,11 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
         st.store24(st.bufA, q);     // (bufA: last read by sweep 0, many barriers ago)
     }
     barrier_keep_dma();             // q2 complete; every wave is done reading l2 (bufB is free)
+    XSTAMP(3);
 
     // ---- 4. cross-attention: one wave per head; S^T = K Q^T and O^T = V^T P^T (swapped, a lane owns one query row)
-    {
+    XSTAMP(4);
+    if (!(LECO_STRIPE_ABLATE & 8)) {
         const int b = m0 / p.rows_per_sample;
         for (int hd = wave; hd < p.heads; hd += 8) {
             const bf16_t* kp = p.kp + (int64_t)(b * p.heads + hd) * (XNKEY * 64);
@@ -650,11 +696,14 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
         }
     }
     // ---- 5. h2 = a2 Wo2^T + bo2 + h1   (the first acquire's barrier publishes a2)
+    XSTAMP(5);
     st.linear24(h, st.bufB, 2);
+    XSTAMP(6);
     st.add_bias24(h, prog->lin[2].bias, 0);
     // ---- 6. l3 = LN3(h2) -> bufA  (bufA: q2, last read before sweep 2's first barrier)
     st.layernorm24(h, p.ln3_g, p.ln3_b, p.ln_eps, st.bufA);
     st.add_bias24(h, prog->lin[4].bias, 0);          // ff.net.2 bias: h becomes the accumulator of h3
+    XSTAMP(7);
 
     // ---- 7. feed-forward in chunks of 128 hidden units.  FF1 chunk: 1 x 8 layout, wave w owns all 64 rows of hidden columns
     // 16 w .. + 16 of the chunk: tile rows vb + fr (value) and vb + 64 + fr (gate) of the 64-interleaved GEGLU weight image.
@@ -674,6 +723,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
         typename St::F18 f1[2];
         f1[0].t = f1[1].t = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         auto read18 = [&](typename St::F18& f, int ka, const unsigned char* s, bool with_t) {
+            if (LECO_STRIPE_ABLATE & 4) return;
             const int ao = st.a_chunk(4 * ka + fg);
 #pragma unroll
             for (int i = 0; i < 4; ++i) f.a[i] = lds_read16_async(st.bufA + a_rows18 + 16 * i * ARS + ao);
@@ -697,6 +747,11 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
             const bool with_t = has_t1 && c == 0;        // the lora_down rows ride in the first chunk's tiles only
             st.fresh_swizzle();
             auto mma18 = [&](const typename St::F18& f) {
+                if (LECO_STRIPE_ABLATE & 1) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) u[i][0][0] += __uint_as_float((unsigned)(f.w[0][0] ^ f.w[1][0] ^ f.a[i][0]));
+                    return;
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     u[i][0] = mfma16(f.w[0], f.a[i], u[i][0]);
@@ -735,6 +790,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
                 }
                 st.refill();
             }
+            if (c == 0) XSTAMP(11);
             // GEGLU: value * gelu(gate) -> bf16 chunk [64][128] in bufB (columns 0 .. 127)
             {
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
@@ -758,6 +814,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
                     st.put4(st.bufB, (16 * i + fr) * ARS, 16 * wave + 4 * fg, g[0], g[1], g[2], g[3]);
                 }
             }
+            if (c == 0) XSTAMP(12);
             // FF2 partial sums: h += g[:, chunk] W2[:, 128 c .. + 128]^T   (the first acquire's barrier publishes the chunk)
             {
                 typename St::F24 f2[2];
@@ -775,6 +832,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
                 st.tie24(f2[1], has_t2);
                 st.mma24(h, acct2, f2[1], has_t2, ti2);
             }
+            if (c == 0) XSTAMP(13);
         }
         if (tf2) {
             st.write_t24(acct2, tf2);
@@ -783,6 +841,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
     }
 
     // ---- 8. out = proj_out(h3) + x   (or h3 itself when the Transformer2DModel goes on with another block)
+    XSTAMP(8);
     if (p.has_po) {
         barrier_keep_dma();                     // every wave is done with the last FF1 reads of l3 (bufA)
         st.store24(st.bufA, h);
@@ -792,9 +851,129 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const void* blob) {
 #pragma unroll
             for (int j = 0; j < FNC; ++j) y[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         st.linear24(y, st.bufA, 5);
+        XSTAMP(9);
         st.store_out(y, prog->lin[5].bias, p.res, p.ld_res, p.out, p.ld_out, m0, M, p.col_stats, p.stats_atom, p.rows_per_sample);
+        XSTAMP(10);
     } else {
         st.store_out(h, nullptr, nullptr, 0, p.out, p.ld_out, m0, M, p.col_stats, p.stats_atom, p.rows_per_sample);
+    }
+}
+
+// ======================================================================================================================
+// Head of a Transformer2DModel + its first BasicTransformerBlock up to the self-attention core:
+//   n = GroupNorm(x) (from the statistics the producer of x left: leco_gemm_args.col_stats) ;  p = proj_in(n) -> h_out ;
+//   qkv = attn1.to_q|to_k|to_v(LN1(p)) -> qkv_out   (three 320-column sweeps sharing one lora_down projection)
+// ======================================================================================================================
+template <int C>
+__global__ __launch_bounds__(512) void xblock_head_kernel(const void* blob) {
+    using St = Stripe<C>;
+    using Cf = XCfg<C>;
+    constexpr int FNC = Cf::FNC, ARS = Cf::ARS, KS = Cf::KS;
+    const LECO_CONST_AS XHeadBlob* B = LECO_CONST_CAST(XHeadBlob, blob);
+    const LECO_CONST_AS XHeadArgs& p = B->p;
+    const LECO_CONST_AS XProg* prog = &B->prog;
+    St st(prog);
+    const int m0 = (int)blockIdx.x * XBM, M = p.m;
+    const int tid = (int)threadIdx.x;
+
+    // (the stripe's DMA pieces must be OLDER than the weight tiles: the first acquire's counted wait then covers them)
+    if (!p.gn_cstats) st.load_stripe(st.bufA, p.x, p.x_bytes, (unsigned)(p.ld_x * 2), m0, M);
+    st.start_stream();
+    {
+        const u32x2 z = {0u, 0u};
+        lds_write8_async(st.tbuf + tid * 8, z);
+    }
+    if (p.gn_cstats) {
+        // ---- GroupNorm apply: per-channel {mean, rstd * gamma, beta} of this stripe's sample in LDS, then one pass over the
+        // stripe (16-byte chunks, coalesced rows) -> bf16 into bufA
+        float* cmean = st.scr;              // [C]
+        float* cscale = st.scr + C;         // [C]
+        float* cbeta = st.scr + 2 * C;      // [C]
+        const int b = m0 / p.rows_per_sample, A = p.stats_atom, cg = C / p.groups, ag = cg / A, natom = C / A;
+        for (int c = tid; c < C; c += 512) {
+            const int g = c / cg;
+            float a0 = 0.f, a1 = 0.f;
+            for (int a = g * ag; a < (g + 1) * ag; ++a) {
+                a0 += p.gn_cstats[((int64_t)b * natom + a) * 2];
+                a1 += p.gn_cstats[((int64_t)b * natom + a) * 2 + 1];
+            }
+            const float inv_n = 1.f / ((float)p.rows_per_sample * (float)cg);
+            const float mu = a0 * inv_n, var = a1 * inv_n - mu * mu;
+            lds_write4_async(cmean + c, mu);
+            lds_write4_async(cscale + c, rsqrtf(fmaxf(var, 0.f) + p.gn_eps) * p.gn_g[c]);
+            lds_write4_async(cbeta + c, p.gn_b[c]);
+        }
+        barrier_keep_dma();
+        constexpr int NCH = C / 8, NIT = (XBM * NCH + 511) / 512;
+        u32x4 raw[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + 512 * it, row = e / NCH, ch = e - row * NCH;
+            raw[it] = u32x4{0u, 0u, 0u, 0u};
+            if (e < XBM * NCH && m0 + row < M) raw[it] = *(const u32x4*)(p.x + (int64_t)(m0 + row) * p.ld_x + ch * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + 512 * it, row = e / NCH, ch = e - row * NCH;
+            if (e >= XBM * NCH) break;
+            bf16x8 q[6];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                q[k] = lds_read16_async(cmean + ch * 8 + 4 * k);
+                q[2 + k] = lds_read16_async(cscale + ch * 8 + 4 * k);
+                q[4 + k] = lds_read16_async(cbeta + ch * 8 + 4 * k);
+            }
+            lds_wait<0>();
+#pragma unroll
+            for (int k = 0; k < 6; ++k) lds_tie(q[k]);
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const f32x4 mu = __builtin_bit_cast(f32x4, q[k]), sc = __builtin_bit_cast(f32x4, q[2 + k]), be = __builtin_bit_cast(f32x4, q[4 + k]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned w = raw[it][2 * k + (r >> 1)];
+                    const float xv = bf2f((bf16_t)((r & 1) ? (w >> 16) : (w & 0xffffu)));
+                    o[4 * k + r] = (xv - mu[r]) * sc[r] + be[r];
+                }
+            }
+            unsigned char* d = st.bufA + row * ARS + ((ch ^ (row & 7)) << 4);
+            const u32x2 lo = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])}, hi = {pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+            lds_write8_async(d, lo);
+            lds_write8_async(d + 8, hi);
+        }
+    }
+    // ---- p = proj_in(n) + bias -> h_out (the residual stream the tail kernel starts from)
+    f32x4 h[2][FNC];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < FNC; ++j) h[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    st.linear24(h, st.bufA, 0);
+    st.add_bias24(h, prog->lin[0].bias, 0);
+    st.store_global24(h, p.h_out, p.ld_hout, 0, m0, M);
+    // ---- l1 = LN1(p) -> bufB
+    st.layernorm24(h, p.ln1_g, p.ln1_b, p.ln_eps, st.bufB);
+    // ---- q | k | v: three sweeps over 320 weight rows each; the stacked lora_down rows ride in the first one only
+    {
+        const int tf = prog->lin[1].tf;
+        const float* bias = prog->lin[1].bias;
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            f32x4 y[2][FNC];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < FNC; ++j) y[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acct = {0.f, 0.f, 0.f, 0.f};
+            st.template sweep24<KS>(y, acct, st.bufB, 0, C, c == 0 ? tf : 0);
+            if (tf) {
+                if (c == 0) st.write_t24(acct, tf);
+                st.ext24(y);
+            }
+            st.add_bias24(y, bias, C * c);
+            st.store_global24(y, p.qkv_out, p.ld_qkv, C * c, m0, M);
+        }
     }
 }
 
@@ -894,7 +1073,7 @@ extern "C" int leco_xblock_supported(int32_t c, int32_t heads, int32_t skv, int3
 }
 
 extern "C" int64_t leco_xblock_prog_bytes(void) {
-    const size_t a = sizeof(leco::XTailBlob);
+    const size_t a = sizeof(leco::XTailBlob) > sizeof(leco::XHeadBlob) ? sizeof(leco::XTailBlob) : sizeof(leco::XHeadBlob);
     return (int64_t)((a + 255) / 256 * 256);
 }
 
@@ -967,3 +1146,57 @@ extern "C" int leco_xblock_tail_run(const void* dev_prog, int32_t m, int32_t hea
     }
     return check_launch("leco_xblock_tail");
 }
+
+// Validates `a` and writes the launch description of the head kernel into `host_prog` (see leco_xblock_tail_build).
+extern "C" int leco_xblock_head_build(const leco_xblock_head_args* a, void* host_prog, int64_t host_bytes) {
+    using namespace leco;
+    if (!a || !host_prog) return fail(-EINVAL, "leco_xblock_head_build: null args");
+    if (host_bytes < (int64_t)sizeof(XHeadBlob)) return fail(-EINVAL, "leco_xblock_head_build: program buffer too small");
+    if (a->c != 320 || a->rows_per_sample <= 0 || a->rows_per_sample % XBM)
+        return fail(-EINVAL, "leco_xblock_head: unsupported shape c=%d rows_per_sample=%d", a->c, a->rows_per_sample);
+    if (a->m <= 0 || !a->x || !a->h_out || !a->qkv_out || !a->ln1_g || !a->ln1_b) return fail(-EINVAL, "leco_xblock_head: null operand");
+    if (a->ld_x % 8 || a->ld_hout % 4 || a->ld_qkv % 4) return fail(-EINVAL, "leco_xblock_head: activation strides must keep 8-byte alignment");
+    if ((int64_t)a->m * a->ld_x * 2 >= ((int64_t)1 << 31)) return fail(-EINVAL, "leco_xblock_head: activation too large");
+    if (a->gn_cstats) {
+        if (!a->gn_g || !a->gn_b || a->groups <= 0 || a->c % a->groups || a->stats_atom <= 0 || (a->c / a->groups) % a->stats_atom)
+            return fail(-EINVAL, "leco_xblock_head: GroupNorm needs gamma / beta, groups | c and stats_atom | c / groups");
+    }
+    const int C = a->c;
+    XHeadBlob* blob = (XHeadBlob*)host_prog;
+    memset(blob, 0, sizeof(*blob));
+    XProg& pg = blob->prog;
+    int rc;
+    HostLin L[2];
+    if ((rc = check_lin(L[0], a->proj_in, C, "leco_xblock_head.proj_in"))) return rc;
+    if ((rc = check_lin(L[1], a->qkv, 3 * C, "leco_xblock_head.qkv"))) return rc;
+    for (int l = 0; l < 2; ++l) { pg.lin[l].bias = L[l].a->bias; pg.lin[l].tf = L[l].tf; }
+    int ns = 0;
+    fill_sweep(pg, ns, L[0], 0, C, 0, C / XKT, true, true);
+    for (int c = 0; c < 3; ++c) fill_sweep(pg, ns, L[1], C * c, C, 0, C / XKT, c == 0, true);
+    pg.nsweeps = ns;
+    XHeadArgs& p = blob->p;
+    p.m = a->m; p.rows_per_sample = a->rows_per_sample;
+    p.x = (const bf16_t*)a->x; p.ld_x = a->ld_x; p.x_bytes = (unsigned)((int64_t)a->m * a->ld_x * 2);
+    p.gn_cstats = a->gn_cstats; p.stats_atom = a->stats_atom; p.groups = a->groups; p.gn_g = a->gn_g; p.gn_b = a->gn_b; p.gn_eps = a->gn_eps;
+    p.ln1_g = a->ln1_g; p.ln1_b = a->ln1_b; p.ln_eps = a->ln_eps;
+    p.h_out = (bf16_t*)a->h_out; p.ld_hout = a->ld_hout;
+    p.qkv_out = (bf16_t*)a->qkv_out; p.ld_qkv = a->ld_qkv;
+    return 0;
+}
+
+extern "C" int leco_xblock_head_run(const void* dev_prog, int32_t m, leco_stream_t stream) {
+    using namespace leco;
+    if (!dev_prog || m <= 0) return fail(-EINVAL, "leco_xblock_head_run: bad arguments");
+    constexpr int lds_bytes = XCfg<320>::LDS_BYTES;
+    set_lds<2>(&xblock_head_kernel<320>, lds_bytes);
+    hipLaunchKernelGGL((xblock_head_kernel<320>), dim3((unsigned)cdiv(m, XBM)), dim3(512), lds_bytes, (hipStream_t)stream, dev_prog);
+    return check_launch("leco_xblock_head");
+}
+
+#ifdef LECO_STRIPE_TIMING
+// side builds only (tools/ablate_stripe.py): the phase stamps of workgroup 0 of the last tail launch
+extern "C" int leco_xblock_debug_times(unsigned long long* out, int n) {
+    if (n > 32) n = 32;
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(leco::g_xtimes), sizeof(unsigned long long) * n);
+}
+#endif

@@ -76,6 +76,18 @@ class XBlockTailArgs(C.Structure):     # mirrors `leco_xblock_tail_args`
     ]
 
 
+class XBlockHeadArgs(C.Structure):     # mirrors `leco_xblock_head_args`
+    _fields_ = [
+        ("m", C.c_int32), ("c", C.c_int32), ("rows_per_sample", C.c_int32),
+        ("x", C.c_void_p), ("ld_x", C.c_int64),
+        ("gn_cstats", C.c_void_p), ("stats_atom", C.c_int32), ("groups", C.c_int32),
+        ("gn_g", C.c_void_p), ("gn_b", C.c_void_p), ("gn_eps", C.c_float),
+        ("proj_in", XLin), ("qkv", XLin),
+        ("ln1_g", C.c_void_p), ("ln1_b", C.c_void_p), ("ln_eps", C.c_float),
+        ("h_out", C.c_void_p), ("ld_hout", C.c_int64), ("qkv_out", C.c_void_p), ("ld_qkv", C.c_int64),
+    ]
+
+
 def xlin(w, bias=None, dn=None, up=None, t_rows: int = 0, ldw: Optional[int] = None, ld_dn: Optional[int] = None,
          ld_up: int = 32) -> XLin:
     """One Linear of a stripe chain (include/leco_hip.h `leco_xlin`): ``w`` [N][K] bf16, ``dn`` / ``up`` = the packed LoRA

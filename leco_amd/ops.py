@@ -53,6 +53,7 @@ _SIGS = {
     "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp],
     "leco_xattn_prep": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "leco_xblock_tail_run": [_vp, _i32, _i32, _vp],
+    "leco_xblock_head_run": [_vp, _i32, _vp],
 }
 # fp32 compute mode (csrc/f32.hip): the same argument lists behind `leco_f32_` entry points; activations / weights /
 # LoRA operand images are float.  While `f32_mode(True)` is active (the plan builder of an fp32 engine), every Op that
@@ -321,6 +322,12 @@ def xblock_tail(args: "hip.XBlockTailArgs", device, keep=None) -> Op:
     """Tail of a BasicTransformerBlock (+ proj_out) as ONE launch (include/leco_hip.h `leco_xblock_tail_args`)."""
     prog = _upload_program("leco_xblock_tail_build", args, device)
     return Op("leco_xblock_tail_run", (prog.data_ptr(), args.m, args.c // args.heads), keep=(prog, args, keep))
+
+
+def xblock_head(args: "hip.XBlockHeadArgs", device, keep=None) -> Op:
+    """GroupNorm apply + proj_in + LayerNorm + q|k|v of a Transformer2DModel's first block as ONE launch (`leco_xblock_head_args`)."""
+    prog = _upload_program("leco_xblock_head_build", args, device)
+    return Op("leco_xblock_head_run", (prog.data_ptr(), args.m), keep=(prog, args, keep))
 
 
 def deterministic_default() -> bool:

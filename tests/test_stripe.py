@@ -133,7 +133,7 @@ def test_xblock_tail_matches_the_per_op_chain(dev, heads, rank, proj_out, stats,
     op.run()
     _sync(dev)
     assert torch.isfinite(out.float()).all()
-    assert rel_err(out, ref) < 3e-3, rel_err(out, ref)
+    assert rel_err(out.cpu(), ref) < 3e-3, rel_err(out.cpu(), ref)
     if stats:
         o = out.float().cpu().reshape(B, hw, C // 10, 10)
         want = torch.stack([o.sum((1, 3)), (o * o).sum((1, 3))], -1)
@@ -232,3 +232,42 @@ def test_forward_only_plans_run_the_stripe_kernels_and_match_the_per_op_plan(dev
     assert e_on < 1e-2 and e_off < 1e-2
     if rank:
         assert rel_err(p_on, p_off) > 1e-3 and rel_err(y_on, y_off) > 1e-3     # the LoRA term is really there
+
+
+@pytest.mark.parametrize("rank,gn,B,hw", [(4, True, 2, 64), (0, False, 1, 128), (8, True, 1, 64)])
+def test_xblock_head_matches_the_per_op_chain(dev, rank, gn, B, hw):
+    """GroupNorm (from producer statistics) -> proj_in -> LayerNorm -> q|k|v: h_out and qkv_out vs the fp32 chain."""
+    torch.manual_seed(200 + rank)
+    C, G = 320, 32
+    M = B * hw
+    pin = Lin(C, C, rank, dev)
+    qkv = Lin(3 * C, C, 3 * rank, dev, bias=False)        # 3 groups of rank `rank`, stacked (block structure irrelevant here)
+    x = (torch.randn(M, C) * 1.5 + 0.3).to(bf)
+    gg, gb = 1 + 0.2 * torch.randn(C), 0.1 * torch.randn(C)
+    lg, lb = 1 + 0.2 * torch.randn(C), 0.1 * torch.randn(C)
+    xf = x.float()
+    if gn:
+        n = _r(F.group_norm(xf.reshape(B, hw, C).permute(0, 2, 1), G, gg, gb, 1e-6).permute(0, 2, 1).reshape(M, C))
+    else:
+        n = xf
+    p = pin.ref(n)
+    q = qkv.ref(_r(_ln(p, lg, lb)))
+    d = lambda t: t.to(dev)
+    xd = d(x)
+    h_out = torch.zeros(M, C, dtype=bf, device=dev); qkv_out = torch.zeros(M, 3 * C, dtype=bf, device=dev)
+    A = hip.XBlockHeadArgs()
+    A.m, A.c, A.rows_per_sample = M, C, hw
+    A.x, A.ld_x = xd.data_ptr(), C
+    keep = [d(t.float().contiguous()) for t in (gg, gb, lg, lb)]
+    if gn:
+        xs = xf.reshape(B, hw, C // 10, 10)
+        cst = d(torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], -1).contiguous())
+        A.gn_cstats, A.stats_atom, A.groups = cst.data_ptr(), 10, G
+        A.gn_g, A.gn_b, A.gn_eps = keep[0].data_ptr(), keep[1].data_ptr(), 1e-6
+    A.proj_in, A.qkv = pin.xlin(), qkv.xlin()
+    A.ln1_g, A.ln1_b, A.ln_eps = keep[2].data_ptr(), keep[3].data_ptr(), 1e-5
+    A.h_out, A.ld_hout, A.qkv_out, A.ld_qkv = h_out.data_ptr(), C, qkv_out.data_ptr(), 3 * C
+    ops.xblock_head(A, dev).run()
+    _sync(dev)
+    e_h, e_q = rel_err(h_out.cpu(), p), rel_err(qkv_out.cpu(), q)
+    assert e_h < 3e-3 and e_q < 3e-3, (e_h, e_q)
