@@ -93,6 +93,22 @@ __device__ __forceinline__ void lds_write4_async(void* lds_ptr, float v) {
     const unsigned a = (unsigned)(unsigned long long)lds_ptr;
     asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
 }
+// The same by LDS byte ADDRESS (what the ds_* instructions take) with a compile-time displacement in the instruction's
+// 16-bit offset field: one base register serves every fragment of a tile (no per-read address arithmetic).
+__device__ __forceinline__ unsigned lds_addr(const void* lds_ptr) { return (unsigned)(unsigned long long)lds_ptr; }
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read16_at(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write8_at(unsigned addr, u32x2 v) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void lds_write4_at(unsigned addr, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
 // Hardware transpose read (ds_read_b64_tr_b16): every lane passes the address of 4 consecutive bf16; inside each
 // group of 16 lanes the 16 x 4 elements are exchanged so that lane c receives element (c & 3) of lanes
 // c/4, 4 + c/4, 8 + c/4, 12 + c/4 -- i.e. with lane i addressing row i/4, columns 4(i%4).. of a [4][16] block,

@@ -121,6 +121,13 @@ static inline void wait_vmcnt() { if (emu_dma::late()) emu_dma::complete_all_but
 static inline bf16x8 lds_read16_async(const void* lds_ptr) { return *(const bf16x8*)lds_ptr; }
 static inline void lds_write8_async(void* lds_ptr, u32x2 v) { memcpy(lds_ptr, &v, 8); }
 static inline void lds_write4_async(void* lds_ptr, float v) { memcpy(lds_ptr, &v, 4); }
+static inline unsigned char* dyn_lds();
+static inline unsigned lds_addr(const void* lds_ptr) { return (unsigned)((const unsigned char*)lds_ptr - dyn_lds()); }
+template <int OFF>
+static inline bf16x8 lds_read16_at(unsigned addr) { return *(const bf16x8*)(dyn_lds() + addr + OFF); }
+template <int OFF>
+static inline void lds_write8_at(unsigned addr, u32x2 v) { memcpy(dyn_lds() + addr + OFF, &v, 8); }
+static inline void lds_write4_at(unsigned addr, float v) { memcpy(dyn_lds() + addr, &v, 4); }
 static inline u32x2 lds_read_tr16(const void* lds_ptr) {
     unsigned long long mine;
     memcpy(&mine, lds_ptr, 8);
