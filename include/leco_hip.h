@@ -309,8 +309,8 @@ int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream);
  * Row-stripe fused transformer-block kernels (csrc/stripe.hip): forward-only, bf16, C = 320 (the 64^2 level of SD1.x /
  * SD2.x: head dim 40 or 64).  One workgroup owns 64 token rows for a whole chain of Linear / LayerNorm / cross-attention /
  * GEGLU operations of diffusers' BasicTransformerBlock + Transformer2DModel (call site train_util.py:156-160; LoRA term
- * lora.py:102-106): the residual stream stays in registers (fp32), GEMM operands in LDS, the block's weights stream once
- * through an LDS ring.  Replaces 14 of the per-op launches above per transformer block in the LoRA-on denoising passes
+ * lora.py:102-106): the residual stream stays in registers (fp32), the activation operand of every GEMM in LDS, the block's
+ * weights stream once through registers in MFMA operand layout.  Replaces 14 of the per-op launches above per transformer block in the LoRA-on denoising passes
  * (train_util.py:172-193) and the batched LoRA-off predictions (train_lora.py:202-237); the differentiated pass keeps the
  * per-op kernels (it must save every intermediate).
  * ---------------------------------------------------------------------- */
@@ -323,6 +323,10 @@ typedef struct leco_xlin {     /* one Linear of a stripe chain: y = x W^T + bias
     const void* up;            /* scale * lora_up, bf16 [N][32] (leco_lora_site.up_p; columns >= groups*r zero) */
     int64_t ld_up;
     int32_t t_rows;            /* 16 or 32: stacked rank rounded up to 16 */
+    int32_t packed;            /* 1: w is stored in MFMA fragment order instead of row-major (frozen weights, re-laid once):
+                                  element (n, k) at ((n / 16 * (K / 32) + k / 32) * 64 + (k % 32 / 8) * 16 + n % 16) * 8 + k % 8,
+                                  i.e. the 16 rows x 32 columns a wave loads per k-step are ONE contiguous 1 KB block (8 whole
+                                  cache lines per load instead of 16 half lines); needs ldw == K */
 } leco_xlin;
 
 /* 1 if the stripe kernels cover this shape (else the caller keeps the per-op launches) */
@@ -356,14 +360,7 @@ typedef struct leco_xblock_tail_args {
     void* out; int64_t ld_out;           /* bf16 [m][c] */
     float* col_stats; int32_t stats_atom;
 } leco_xblock_tail_args;
-/* The launch description (operand pointers + the weight-tile sweep table the kernel walks) lives in DEVICE memory and is
- * read through the scalar cache: leco_xblock_tail_build validates `args` and fills a HOST buffer of
- * leco_xblock_prog_bytes() bytes; the caller copies it to the device once (per plan) and launches with
- * leco_xblock_tail_run(dev_prog, m, head_dim).  Nothing else is kept: the program may be re-used for any number of
- * launches (graph capture included) as long as the operands it points to stay alive. */
-int64_t leco_xblock_prog_bytes(void);
-int leco_xblock_tail_build(const leco_xblock_tail_args* args, void* host_prog, int64_t host_bytes);
-int leco_xblock_tail_run(const void* dev_prog, int32_t m, int32_t head_dim, leco_stream_t stream);
+int leco_xblock_tail(const leco_xblock_tail_args* args, leco_stream_t stream);
 
 /* Everything of a Transformer2DModel BEFORE the self-attention core of its first BasicTransformerBlock:
  *   n = GroupNorm(x) from the statistics the producer of x left (gn_cstats: fp32 [batch][c / stats_atom][2] {sum, sumsq},
@@ -379,8 +376,7 @@ typedef struct leco_xblock_head_args {
     void* h_out; int64_t ld_hout;                /* bf16 [m][c]: the residual stream entering the block */
     void* qkv_out; int64_t ld_qkv;               /* bf16 [m][3 c] */
 } leco_xblock_head_args;
-int leco_xblock_head_build(const leco_xblock_head_args* args, void* host_prog, int64_t host_bytes);
-int leco_xblock_head_run(const void* dev_prog, int32_t m, leco_stream_t stream);
+int leco_xblock_head(const leco_xblock_head_args* args, leco_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * hipGraph capture of a whole UNet pass (the reference issues ~10^4 eager kernel launches

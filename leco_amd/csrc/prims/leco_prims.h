@@ -59,6 +59,12 @@ __device__ __forceinline__ buf_rsrc make_rsrc(const void* base, unsigned bytes) 
 __device__ __forceinline__ void glds16_buf(buf_rsrc r, unsigned voff, unsigned soff, void* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
+// 16-byte load through a buffer descriptor into registers (buffer_load_dwordx4 ... offen): per-lane byte offset + a
+// wave-uniform byte offset; counted by the compiler's own s_waitcnt vmcnt bookkeeping (unlike the LDS-DMA forms above it has
+// a register destination the compiler tracks), so a software-pipelined prefetch array needs no hand-written waits.
+__device__ __forceinline__ bf16x8 buf_load16(buf_rsrc r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
 // Counted wait on this wave's outstanding global/LDS-DMA operations (s_waitcnt vmcnt(N)): the N most
 // recently issued may still be in flight.  Lets several tile DMAs span a barrier.
 template <int N>

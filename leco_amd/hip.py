@@ -61,7 +61,7 @@ class WgradProblem(C.Structure):     # mirrors `leco_wgrad_problem` in include/l
 
 class XLin(C.Structure):          # mirrors `leco_xlin`
     _fields_ = [("w", C.c_void_p), ("ldw", C.c_int64), ("bias", C.c_void_p), ("dn", C.c_void_p), ("ld_dn", C.c_int64),
-                ("up", C.c_void_p), ("ld_up", C.c_int64), ("t_rows", C.c_int32)]
+                ("up", C.c_void_p), ("ld_up", C.c_int64), ("t_rows", C.c_int32), ("packed", C.c_int32)]
 
 
 class XBlockTailArgs(C.Structure):     # mirrors `leco_xblock_tail_args`
@@ -88,8 +88,14 @@ class XBlockHeadArgs(C.Structure):     # mirrors `leco_xblock_head_args`
     ]
 
 
+def pack_fragments(w: torch.Tensor) -> torch.Tensor:
+    """[N][K] -> the MFMA fragment order of `leco_xlin.packed` (same numel): [N / 16][K / 32][k-group 4][row 16][8]."""
+    n, k = w.shape
+    return w.reshape(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().reshape(n, k)
+
+
 def xlin(w, bias=None, dn=None, up=None, t_rows: int = 0, ldw: Optional[int] = None, ld_dn: Optional[int] = None,
-         ld_up: int = 32) -> XLin:
+         ld_up: int = 32, packed: bool = False) -> XLin:
     """One Linear of a stripe chain (include/leco_hip.h `leco_xlin`): ``w`` [N][K] bf16, ``dn`` / ``up`` = the packed LoRA
     operand images `dn_s` / `up_p` of the site (None: LoRA off)."""
     x = XLin()
@@ -99,6 +105,7 @@ def xlin(w, bias=None, dn=None, up=None, t_rows: int = 0, ldw: Optional[int] = N
     x.ld_dn = 0 if dn is None else (dn.shape[-1] if ld_dn is None else ld_dn)
     x.up, x.ld_up = ptr(up), ld_up
     x.t_rows = t_rows
+    x.packed = 1 if packed else 0
     return x
 
 

@@ -52,8 +52,8 @@ _SIGS = {
     "leco_lora_wgrad_grouped": [_vp, _i32, _i32, _i32, _vp],
     "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp],
     "leco_xattn_prep": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
-    "leco_xblock_tail_run": [_vp, _i32, _i32, _vp],
-    "leco_xblock_head_run": [_vp, _i32, _vp],
+    "leco_xblock_tail": [_vp, _vp],
+    "leco_xblock_head": [_vp, _vp],
 }
 # fp32 compute mode (csrc/f32.hip): the same argument lists behind `leco_f32_` entry points; activations / weights /
 # LoRA operand images are float.  While `f32_mode(True)` is active (the plan builder of an fp32 engine), every Op that
@@ -306,28 +306,14 @@ def xattn_buffers(batch: int, heads: int, head_dim: int, device) -> tuple:
             torch.zeros(batch * heads * dv * 96, dtype=torch.bfloat16, device=device))
 
 
-def _upload_program(build_fn: str, args, device) -> torch.Tensor:
-    """Runs a `leco_*_build` entry point into a host buffer and returns the program as a device tensor."""
-    lib = hip.lib()
-    nbytes_f = lib.leco_xblock_prog_bytes
-    nbytes_f.restype = C.c_int64
-    n = int(nbytes_f())
-    host = (C.c_uint8 * n)()
-    f = hip.declare(build_fn, [_vp, _vp, _i64])
-    hip.check(f(C.cast(C.byref(args), _vp), C.cast(host, _vp), n), build_fn)
-    return torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(device)
-
-
-def xblock_tail(args: "hip.XBlockTailArgs", device, keep=None) -> Op:
+def xblock_tail(args: "hip.XBlockTailArgs", keep=None) -> Op:
     """Tail of a BasicTransformerBlock (+ proj_out) as ONE launch (include/leco_hip.h `leco_xblock_tail_args`)."""
-    prog = _upload_program("leco_xblock_tail_build", args, device)
-    return Op("leco_xblock_tail_run", (prog.data_ptr(), args.m, args.c // args.heads), keep=(prog, args, keep))
+    return Op("leco_xblock_tail", (C.cast(C.pointer(args), _vp),), keep=(args, keep))
 
 
-def xblock_head(args: "hip.XBlockHeadArgs", device, keep=None) -> Op:
+def xblock_head(args: "hip.XBlockHeadArgs", keep=None) -> Op:
     """GroupNorm apply + proj_in + LayerNorm + q|k|v of a Transformer2DModel's first block as ONE launch (`leco_xblock_head_args`)."""
-    prog = _upload_program("leco_xblock_head_build", args, device)
-    return Op("leco_xblock_head_run", (prog.data_ptr(), args.m), keep=(prog, args, keep))
+    return Op("leco_xblock_head", (C.cast(C.pointer(args), _vp),), keep=(args, keep))
 
 
 def deterministic_default() -> bool:

@@ -1016,12 +1016,18 @@ class PlanBuilder:
         return S[bname + ".ff.net.0.proj"].geglu_ok
 
     def _xlin(self, site: GemmSite, lora_on: bool, geglu: bool = False):
-        w, b = site.w_geglu if geglu else (site.w, site.bias)
+        """`leco_xlin` of a site for the stripe kernels: the frozen weight in MFMA fragment order (re-laid once per site),
+        the LoRA operand images as `leco_lora_pack` leaves them."""
+        key = "_xw_g" if geglu else "_xw"
+        if not hasattr(site, key):
+            w, b = site.w_geglu if geglu else (site.w, site.bias)
+            setattr(site, key, (hip.pack_fragments(w), b))
+        w, b = getattr(site, key)
         lo = site.lora if lora_on else None
         if lo is None:
-            return hip.xlin(w, b), (site, w, b)
+            return hip.xlin(w, b, packed=True), (site, w, b)
         up = lo.up_pg if geglu else lo.up_p
-        return hip.xlin(w, b, lo.dn_s, up, lo.R16, ld_up=lo.Rp), (site, w, b, lo)
+        return hip.xlin(w, b, lo.dn_s, up, lo.R16, ld_up=lo.Rp, packed=True), (site, w, b, lo)
 
     def block_tail_fused(self, bname: str, tname: str, a1: TRef, hcur: TRef, kv: TRef, heads: int, hw: int, last: bool,
                          x_res: Optional[TRef]) -> TRef:
@@ -1059,7 +1065,7 @@ class PlanBuilder:
             A.out, A.ld_out = out.ptr, out.ld
             if out.cstats is not None:
                 A.col_stats, A.stats_atom = out.cstats, self.stat_atom
-            lst.append(ops.xblock_tail(A, self.dev, keep=keep))
+            lst.append(ops.xblock_tail(A, keep=keep))
         return out
 
     def basic_block(self, bname: str, hcur: TRef, ctx: TRef, heads: int, hw: int, tname: str = "", last: bool = False,

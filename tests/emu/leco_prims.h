@@ -113,6 +113,12 @@ static inline void glds16_buf(buf_rsrc r, unsigned voff, unsigned soff, void* ld
     const bool oob = voff >= r.bytes || (unsigned long long)voff + soff + 16 > r.bytes;
     glds16(oob ? (const void*)zeros : (const void*)(r.base + voff + soff), lds_wave_base);
 }
+static inline bf16x8 buf_load16(buf_rsrc r, unsigned voff, unsigned soff) {
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool oob = voff >= r.bytes || (unsigned long long)voff + soff + 16 > r.bytes;
+    if (!oob) memcpy(&v, r.base + voff + soff, 16);
+    return v;
+}
 template <int N>
 static inline void wait_vmcnt() { if (emu_dma::late()) emu_dma::complete_all_but(N); }
 #undef __syncthreads

@@ -61,16 +61,18 @@ class Lin:
             y = y + self.b
         return y
 
-    def xlin(self, perm=None):
+    def xlin(self, perm=None, packed=True):
         w, b = self.w, self.b
         up = self.up if self.rank else None
         if perm is not None:
             w, b = w[perm], (None if b is None else b[perm])
             up = None if up is None else up[perm]
+        if packed:          # frozen weights in MFMA fragment order (what the plan builder hands the kernels)
+            w = hip.pack_fragments(w)
         self._keep = (w.contiguous().to(self.dev), None if b is None else b.contiguous().to(self.dev),
                       self.dn.to(self.dev) if self.rank else None, None if up is None else up.contiguous().to(self.dev))
         w, b, dn, up = self._keep
-        return hip.xlin(w, b, dn, up, self.t_rows if self.rank else 0)
+        return hip.xlin(w, b, dn, up, self.t_rows if self.rank else 0, packed=packed)
 
 
 def _ln(x, g, b, eps=1e-5):
@@ -117,10 +119,11 @@ def test_xblock_tail_matches_the_per_op_chain(dev, heads, rank, proj_out, stats,
     A = hip.XBlockTailArgs()
     A.m, A.c, A.heads, A.skv, A.rows_per_sample = M, C, heads, skv, hw
     A.attn, A.ld_attn, A.h_in, A.ld_h = a1d.data_ptr(), C, h0d.data_ptr(), C
-    A.to_out1, A.to_q2, A.to_out2 = to_out1.xlin(), to_q2.xlin(), to_out2.xlin()
-    A.ff1, A.ff2 = ff1.xlin(geglu_perm(8 * C)), ff2.xlin()
+    pk = rank != 8           # (one case keeps row-major weights: both layouts are part of the ABI)
+    A.to_out1, A.to_q2, A.to_out2 = to_out1.xlin(packed=pk), to_q2.xlin(packed=pk), to_out2.xlin(packed=pk)
+    A.ff1, A.ff2 = ff1.xlin(geglu_perm(8 * C), packed=pk), ff2.xlin(packed=pk)
     if proj_out:
-        A.proj_out = po.xlin()
+        A.proj_out = po.xlin(packed=pk)
         A.res, A.ld_res = xd.data_ptr(), C
     lnp = [d(t.float().contiguous()) for t in (g2, b2, g3, b3)]
     A.ln2_g, A.ln2_b, A.ln3_g, A.ln3_b = [t.data_ptr() for t in lnp]
@@ -129,7 +132,7 @@ def test_xblock_tail_matches_the_per_op_chain(dev, heads, rank, proj_out, stats,
     A.out, A.ld_out = out.data_ptr(), C
     if stats:
         A.col_stats, A.stats_atom = cst.data_ptr(), 10
-    op = ops.xblock_tail(A, dev)
+    op = ops.xblock_tail(A)
     op.run()
     _sync(dev)
     assert torch.isfinite(out.float()).all()
@@ -215,7 +218,7 @@ def test_forward_only_plans_run_the_stripe_kernels_and_match_the_per_op_plan(dev
         m.prepare((B, 4, h, w), lora_on=True)
     fused = eng.plan(B, h, w, need_bwd=False)
     names = [op.name for op in fused.lists["fwd_on"]]
-    assert names.count("leco_xblock_tail_run") == 3 and names.count("leco_xattn_prep") == 3
+    assert names.count("leco_xblock_tail") == 3 and names.count("leco_xattn_prep") == 3
     # norm1 of the 3 fused blocks (norm2 / norm3 live in the stripe kernel) + the mid block (16 pixels: per-op launches)
     assert names.count("leco_layernorm_fwd") == 3 + 3
     y_on = _run_plan(m, fused, "fwd_on", x, ctx)
@@ -223,7 +226,7 @@ def test_forward_only_plans_run_the_stripe_kernels_and_match_the_per_op_plan(dev
     monkeypatch.setenv("LECO_STRIPE", "0")
     eng.plans.clear()
     plain = eng.plan(B, h, w, need_bwd=False)
-    assert "leco_xblock_tail_run" not in [op.name for op in plain.lists["fwd_on"]]
+    assert "leco_xblock_tail" not in [op.name for op in plain.lists["fwd_on"]]
     p_on = _run_plan(m, plain, "fwd_on", x, ctx)
     p_off = _run_plan(m, plain, "fwd_off", x, ctx)
     _sync(dev)
@@ -264,10 +267,10 @@ def test_xblock_head_matches_the_per_op_chain(dev, rank, gn, B, hw):
         cst = d(torch.stack([xs.sum((1, 3)), (xs * xs).sum((1, 3))], -1).contiguous())
         A.gn_cstats, A.stats_atom, A.groups = cst.data_ptr(), 10, G
         A.gn_g, A.gn_b, A.gn_eps = keep[0].data_ptr(), keep[1].data_ptr(), 1e-6
-    A.proj_in, A.qkv = pin.xlin(), qkv.xlin()
+    A.proj_in, A.qkv = pin.xlin(packed=rank != 8), qkv.xlin(packed=rank != 8)
     A.ln1_g, A.ln1_b, A.ln_eps = keep[2].data_ptr(), keep[3].data_ptr(), 1e-5
     A.h_out, A.ld_hout, A.qkv_out, A.ld_qkv = h_out.data_ptr(), C, qkv_out.data_ptr(), 3 * C
-    ops.xblock_head(A, dev).run()
+    ops.xblock_head(A).run()
     _sync(dev)
     e_h, e_q = rel_err(h_out.cpu(), p), rel_err(qkv_out.cpu(), q)
     assert e_h < 3e-3 and e_q < 3e-3, (e_h, e_q)

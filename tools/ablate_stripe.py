@@ -4,7 +4,7 @@
     python tools/ablate_stripe.py [variants...]                  (GPU box)
 
 Variants: `t` = product kernel + phase stamps of workgroup 0 (LECO_STRIPE_TIMING); an integer = LECO_STRIPE_ABLATE bit mask
-(1 no MFMA, 2 no weight DMA, 4 no fragment reads, 8 no cross-attention, 16 no waits / barriers in the tile stream)."""
+(1 no MFMA, 2 no weight loads, 4 no activation-fragment reads, 8 no cross-attention)."""
 import ctypes as C
 import os
 import subprocess
@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 from leco_amd import build as B, hip, ops  # noqa: E402
 
 bf = torch.bfloat16
+PACKED = os.environ.get("STRIPE_ROWMAJOR", "0") == "0"     # (timing only: the values are random either way)
 PHASES = ["to_out1", "LN2", "to_q2 + store", "(stamp)", "cross-attn", "to_out2", "LN3", "FF (10 chunks)", "proj_out", "store_out"]
 
 
@@ -47,8 +48,9 @@ def make_case(dev, M=16384, hw=4096, heads=8, rank=4, C=320, skv=77):
         if rank:
             dn = torch.zeros(16, k, device=dev); dn[:rank] = torch.randn(rank, k, device=dev) / k ** 0.5
             up = torch.zeros(n, 32, device=dev); up[:, :rank] = torch.randn(n, rank, device=dev) * 0.02
-            return hip.xlin(w, b, dn.to(bf), up.to(bf), 16), (w, b, dn, up)
-        return hip.xlin(w, b), (w, b)
+            dn, up = dn.to(bf), up.to(bf)
+            return hip.xlin(w, b, dn, up, 16, packed=PACKED), (w, b, dn, up)
+        return hip.xlin(w, b, packed=PACKED), (w, b)
     keep = []
     A = hip.XBlockTailArgs()
     A.m, A.c, A.heads, A.skv, A.rows_per_sample = M, C, heads, skv, hw
@@ -73,7 +75,7 @@ def make_case(dev, M=16384, hw=4096, heads=8, rank=4, C=320, skv=77):
 
 
 def main():
-    variants = [a for a in sys.argv[1:] if not a.startswith("--")] or ["t", "1", "2", "4", "16", "3", "7", "23"]
+    variants = [a for a in sys.argv[1:] if not a.startswith("--")] or ["t", "1", "2", "4", "7"]
     if "--build-only" in sys.argv:
         for v in variants:
             print(build_variant(v))
@@ -86,7 +88,7 @@ def main():
         for v in ["prod"] + variants:
             hip._use_library(hip.LIB_PATH if v == "prod" else build_variant(v))
             A, keep = make_case(dev, M=M)
-            op = ops.xblock_tail(A, dev)
+            op = ops.xblock_tail(A)
             for _ in range(5):
                 op.run()
             torch.cuda.synchronize()

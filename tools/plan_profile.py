@@ -52,11 +52,14 @@ def describe(op):
         return f"layernorm_bwd M={a[9]} C={a[10]}", 0.0, 8.0 * a[9] * a[10]
     if op.name in ("leco_geglu_fwd", "leco_geglu_bwd"):
         return f"{op.name[5:]} M={a[-2]} F={a[-1]}", 0.0, 6.0 * a[-2] * a[-1]
-    if op.name == "leco_xblock_tail_run":
-        m, c = a[1], op.keep[1].c
-        po = 1 if op.keep[1].proj_out.w else 0
-        return (f"xblock_tail M={m} C={c} d={a[2]}" + (" +proj_out" if po else ""),
-                m * (2.0 * c * c * (15 + po) + 4.0 * op.keep[1].skv * c), 2.0 * m * c * (3 + po))
+    if op.name == "leco_xblock_tail":
+        A = op.keep[0]
+        m, c, po = A.m, A.c, 1 if A.proj_out.w else 0
+        return (f"xblock_tail M={m} C={c} d={c // A.heads}" + (" +proj_out" if po else ""),
+                m * (2.0 * c * c * (15 + po) + 4.0 * A.skv * c), 2.0 * m * c * (3 + po))
+    if op.name == "leco_xblock_head":
+        A = op.keep[0]
+        return f"xblock_head M={A.m} C={A.c}" + (" +gn" if A.gn_cstats else ""), A.m * 2.0 * A.c * A.c * 4, 2.0 * A.m * A.c * 5
     return op.name[5:], 0.0, 0.0
 
 
