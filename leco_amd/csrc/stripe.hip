@@ -65,7 +65,7 @@ __device__ unsigned long long g_xtimes[32];
 
 constexpr int XBM = 64;      // token rows per stripe
 constexpr int XKT = 32;      // k per step
-constexpr int XPF = 3;       // weight fragments are fetched this many k-steps ahead
+constexpr int XPF = 4;       // weight fragments are fetched this many k-steps ahead
 constexpr int XNKEY = 80;    // padded prompt keys of K (5 fragments)
 constexpr int XNPOS = 96;    // padded (permuted) key positions of V^T
 
@@ -211,19 +211,26 @@ struct Stripe {
     // kinc / kinc2: bytes from one k-step to the next (row-major: 64; fragment order: 1024 -- a fragment's k-steps are
     // consecutive 1 KB blocks, each lane's 16 bytes at lane * 16: one load = 8 whole cache lines)
     struct Src { buf_rsrc rw, r2; unsigned vw, v2; unsigned s0, s1, s2; unsigned kinc, kinc2; bool has2; };
-    template <int NK, int RS, bool G16>
-    __device__ __forceinline__ void kloop(Acc& acc, const unsigned char* abuf, int ka0, const Src& S) const {
-        bf16x8 wf[XPF][3];
-        auto fetch = [&](int slot, int kt) {
-            if (LECO_STRIPE_ABLATE & 2) return;
-            const unsigned kb = (unsigned)kt * S.kinc;
-            wf[slot][0] = buf_load16(S.rw, S.vw, S.s0 + kb);
-            wf[slot][1] = buf_load16(S.rw, S.vw, S.s1 + kb);
-            if (S.has2) wf[slot][2] = buf_load16(S.r2, S.v2, S.s2 + (unsigned)kt * S.kinc2);
-        };
+    typedef bf16x8 WF[XPF][3];       // weight fragments in flight: [k-step % XPF][fragment]
+    __device__ __forceinline__ void fetch(WF& wf, int slot, int kt, const Src& S) const {
+        if (LECO_STRIPE_ABLATE & 2) return;
+        const unsigned kb = (unsigned)kt * S.kinc;
+        wf[slot][0] = buf_load16(S.rw, S.vw, S.s0 + kb);
+        wf[slot][1] = buf_load16(S.rw, S.vw, S.s1 + kb);
+        if (S.has2) wf[slot][2] = buf_load16(S.r2, S.v2, S.s2 + (unsigned)kt * S.kinc2);
+    }
+    // the first XPF k-steps of a K loop: issued by the caller AHEAD of the phase boundary in front of the loop (LayerNorm,
+    // GEGLU, a barrier ...), so the loop does not start with an exposed load latency
+    template <int NK, int PF = XPF>
+    __device__ __forceinline__ void prefetch(WF& wf, const Src& S) const {
 #pragma unroll
-        for (int pf = 0; pf < XPF; ++pf)
-            if (pf < NK) fetch(pf, pf);
+        for (int pf = 0; pf < PF; ++pf)
+            if (pf < NK) fetch(wf, pf, pf, S);
+    }
+    // (PF: depth of the fragment ring of this loop; must match the prefetch<NK, PF> that fed it)
+    template <int NK, int RS, bool G16, int PF = XPF>
+    __device__ __forceinline__ void kloop(Acc& acc, const unsigned char* abuf, int ka0, const Src& S, WF& wf) const {
+        static_assert(PF <= XPF, "fragment ring depth");
         const unsigned char* arow = abuf + fr * RS;
         bf16x8 a[4];
 #pragma unroll
@@ -234,7 +241,7 @@ struct Stripe {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[i] = *(const bf16x8*)(ap + 16 * i * RS);
             }
-            const int slot = kt % XPF;
+            const int slot = kt % PF;
             if (LECO_STRIPE_ABLATE & 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i][0][0] += __uint_as_float((unsigned)(wf[slot][0][0] ^ wf[slot][1][0] ^ a[i][0]));
@@ -249,7 +256,7 @@ struct Stripe {
                     for (int i = 0; i < 4; ++i) acc[i][2] = mfma16(wf[slot][2], a[i], acc[i][2]);
                 }
             }
-            if (kt + XPF < NK) fetch(slot, kt + XPF);
+            if (kt + PF < NK) fetch(wf, slot, kt + PF, S);
         }
     }
     // weight-fragment sources of this wave for rows [n0, n0 + C) of Linear L at k offset k0 (elements); `t_here`: the stacked
@@ -297,15 +304,18 @@ struct Stripe {
             }
         }
     }
-    // K-extension: acc += T (scale up)^T for rows [n0, n0 + C) of up.  T must be visible (barrier) before the call.
-    __device__ __forceinline__ void ext(Acc& acc, const XLin& L, int n0) const {
+    // K-extension: acc += T (scale up)^T for rows [n0, n0 + C) of up.  The up fragments are loaded ahead (ext_load, before
+    // the K loop); T must be visible (barrier) before ext_apply.
+    __device__ __forceinline__ void ext_load(bf16x8 (&uf)[NFW], const XLin& L, int n0) const {
+        if (!L.tf) return;
         const buf_rsrc ru = make_rsrc(L.up, L.up_bytes);
         const unsigned vu = (unsigned)fr * L.ldup_b + (unsigned)(fg << 4);
         const unsigned s0 = (unsigned)uniform((int)((unsigned)(n0 + 16 * f0) * L.ldup_b));
-        bf16x8 uf[NFW];
 #pragma unroll
         for (int j = 0; j < NFW; ++j)
             if (j < nf) uf[j] = buf_load16(ru, vu, s0 + (unsigned)(16 * j) * L.ldup_b);
+    }
+    __device__ __forceinline__ void ext_apply(Acc& acc, const bf16x8 (&uf)[NFW]) const {
         const unsigned char* tp = bufT + fr * 64 + ((fg ^ t_sw) << 4);
         bf16x8 a[4];
 #pragma unroll
@@ -317,17 +327,19 @@ struct Stripe {
                 for (int i = 0; i < 4; ++i) acc[i][j] = mfma16(uf[j], a[i], acc[i][j]);
             }
     }
-    // a whole Linear with N = K = C on the activation image, accumulated into acc (+ bias).  Contains one barrier when the
-    // Linear carries a LoRA (all waves have then finished reading the image).
-    __device__ __forceinline__ void linear(Acc& acc, const XLin& L) const {
-        const Src S = src_c(L, 0, 0, true);
+    // a whole Linear with N = K = C on the activation image, accumulated into acc (+ bias).  `wf` holds the first k-steps
+    // (prefetch<KS>(wf, S) by the caller, ahead of whatever precedes the Linear).  Contains one barrier when the Linear carries
+    // a LoRA (all waves have then finished reading the image).
+    __device__ __forceinline__ void linear(Acc& acc, const XLin& L, const Src& S, WF& wf) const {
         f32x4 b[NFW];
-        load_bias(b, L.bias, 0);             // (issued ahead of the K loop: its latency hides behind it)
-        kloop<KS, ARS, false>(acc, bufA, 0, S);
+        bf16x8 uf[NFW];
+        load_bias(b, L.bias, 0);             // (issued ahead of the K loop: their latency hides behind it)
+        ext_load(uf, L, 0);
+        kloop<KS, ARS, false>(acc, bufA, 0, S, wf);
         if (L.tf) {
             write_t(acc, L.tf);
             barrier_keep_dma();
-            ext(acc, L, 0);
+            ext_apply(acc, uf);
         }
         add_bias(acc, b);
     }
@@ -359,15 +371,21 @@ struct Stripe {
 
     // ---- LayerNorm of the register-resident stream -> bf16 activation image.  Every wave must have finished reading the
     // image's previous contents when it calls this (the first barrier in here then makes that true for all of them).
-    __device__ __forceinline__ void layernorm(const Acc& h, const float* gamma, const float* beta, float eps) const {
-        float mean[4], rstd[4];
-        f32x4 g[NFW], b[NFW];
+    // (gamma / beta of the lane's columns: loaded by the caller AHEAD of the weight prefetch that precedes the LayerNorm --
+    // vector-memory operations complete in order, behind a prefetch they would arrive last)
+    __device__ __forceinline__ void ln_params(f32x4 (&g)[NFW], f32x4 (&b)[NFW], const float* gamma, const float* beta) const {
 #pragma unroll
-        for (int j = 0; j < NFW; ++j)
+        for (int j = 0; j < NFW; ++j) {
+            g[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            b[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (j < nf) {
                 g[j] = *(const f32x4*)(gamma + 16 * (f0 + j) + 4 * fg);
                 b[j] = *(const f32x4*)(beta + 16 * (f0 + j) + 4 * fg);
             }
+        }
+    }
+    __device__ __forceinline__ void layernorm(const Acc& h, const f32x4 (&g)[NFW], const f32x4 (&b)[NFW], float eps) const {
+        float mean[4], rstd[4];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
             float* part = scr + pass * (XBM * 8);              // [64][8]
@@ -528,8 +546,11 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
     const int wave = st.wave, fr = st.fr, fg = st.fg, f0 = st.f0, nf = st.nf;
     const int m0 = (int)blockIdx.x * XBM, M = p.m;
 
-    // ---- prologue: the self-attention output stripe -> activation image; the T image zeroed (its columns 16 .. 31 are only
-    // written by rank-stacks > 16); the residual stream h0 -> registers
+    // ---- prologue: the first weight fragments of sweep 1; the self-attention output stripe -> activation image; the T image
+    // zeroed (its columns 16 .. 31 are only written by rank-stacks > 16); the residual stream h0 -> registers
+    typename St::WF wf;
+    typename St::Src S = st.src_c(p.lin[0], 0, 0, true);
+    st.template prefetch<KS>(wf, S);
     st.load_stripe(p.attn, p.ld_attn, m0, M);
     *(u32x2*)(st.bufT + (int)threadIdx.x * 8) = u32x2{0u, 0u};
     Acc h;
@@ -549,17 +570,38 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
 
     // ---- 1. h1 = a1 Wo1^T + bo1 + h0
     XSTAMP(0);
-    st.linear(h, p.lin[0]);
+    st.linear(h, p.lin[0], S, wf);
     XSTAMP(1);
-    // ---- 2. l2 = LN2(h1) -> activation image (a1 is dead behind LN's first barrier)
-    st.layernorm(h, p.ln2_g, p.ln2_b, p.ln_eps);
+    // ---- 2. l2 = LN2(h1) -> activation image (a1 is dead behind LN's first barrier); sweep 2's first fragments fly meanwhile
+    f32x4 lg[NFW], lb[NFW];
+    st.ln_params(lg, lb, p.ln2_g, p.ln2_b);
+    S = st.src_c(p.lin[1], 0, 0, true);
+    st.template prefetch<KS>(wf, S);
+    st.layernorm(h, lg, lb, p.ln_eps);
     barrier_keep_dma();
     XSTAMP(2);
-    // ---- 3. q2 = l2 Wq2^T -> activation image (bf16), in place of l2
+    // ---- 3. q2 = l2 Wq2^T -> activation image (bf16), in place of l2.  K / V^T fragments of the wave's first head are fetched
+    // behind the K loop, ahead of the barriers in front of the cross-attention.
+    constexpr int DVc = (D + 15) / 16 * 16, NFDc = DVc / 16;
+    bf16x8 kf[5][2], vf[NFDc][3];
+    auto load_kv = [&](int hd) {
+        const int b = m0 / p.rows_per_sample;
+        const bf16_t* kp = p.kp + (int64_t)(b * p.heads + hd) * (XNKEY * 64);
+        const bf16_t* vt = p.vt + (int64_t)(b * p.heads + hd) * (DVc * XNPOS);
+#pragma unroll
+        for (int f = 0; f < 5; ++f)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kf[f][ks] = *(const bf16x8*)(kp + (16 * f + fr) * 64 + 32 * ks + 8 * fg);
+#pragma unroll
+        for (int fd = 0; fd < NFDc; ++fd)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) vf[fd][s] = *(const bf16x8*)(vt + (16 * fd + fr) * XNPOS + 32 * s + 8 * fg);
+    };
     {
         Acc q;
         St::zero(q);
-        st.linear(q, p.lin[1]);
+        st.linear(q, p.lin[1], S, wf);
+        if (wave < p.heads && !(LECO_STRIPE_ABLATE & 8)) load_kv(wave);
         if (!p.lin[1].tf) barrier_keep_dma();       // (with a LoRA, linear()'s own barrier already follows every wave's K loop)
         st.store_a(q);
     }
@@ -570,19 +612,8 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
     // S^T = K Q^T and O^T = V^T P^T (swapped: a lane owns one query row)
     XSTAMP(4);
     if (!(LECO_STRIPE_ABLATE & 8)) {
-        const int b = m0 / p.rows_per_sample;
         for (int hd = wave; hd < p.heads; hd += 8) {
-            const bf16_t* kp = p.kp + (int64_t)(b * p.heads + hd) * (XNKEY * 64);
-            const bf16_t* vt = p.vt + (int64_t)(b * p.heads + hd) * (DV * XNPOS);
-            bf16x8 kf[5][2], vf[NFD][3];
-#pragma unroll
-            for (int f = 0; f < 5; ++f)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) kf[f][ks] = *(const bf16x8*)(kp + (16 * f + fr) * 64 + 32 * ks + 8 * fg);
-#pragma unroll
-            for (int fd = 0; fd < NFD; ++fd)
-#pragma unroll
-                for (int s = 0; s < 3; ++s) vf[fd][s] = *(const bf16x8*)(vt + (16 * fd + fr) * XNPOS + 32 * s + 8 * fg);
+            if (hd != wave) load_kv(hd);
 #pragma unroll 1
             for (int u = 0; u < 4; ++u) {
                 // Q fragments (MFMA B operand: column = query row, k = head dim); k-groups beyond D are zero
@@ -647,22 +678,20 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
             }
         }
     }
+    S = st.src_c(p.lin[2], 0, 0, true);
+    st.template prefetch<KS>(wf, S);
     barrier_keep_dma();             // a2 complete
     // ---- 5. h2 = a2 Wo2^T + bo2 + h1
     XSTAMP(5);
-    st.linear(h, p.lin[2]);
+    st.linear(h, p.lin[2], S, wf);
     XSTAMP(6);
-    // ---- 6. l3 = LN3(h2) -> activation image
-    st.layernorm(h, p.ln3_g, p.ln3_b, p.ln_eps);
-    st.add_bias(h, p.lin[4].bias, 0);          // ff.net.2 bias: h becomes the accumulator of h3
-    barrier_keep_dma();
-    XSTAMP(7);
 
-    // ---- 7. feed-forward in chunks of 128 hidden units.  FF1 chunk: wave w owns hidden columns 16 w .. + 16 of the chunk:
-    // weight rows vb + fr (value) and vb + 64 + fr (gate) of the 64-interleaved GEGLU weight image; the stacked lora_down
-    // rows ride in the first chunk as a third fragment of waves 0 / 1.  The bf16 chunk goes to one of two LDS images
-    // ([64][128], chunk c of row r at position c ^ (r & 15)); FF2 reads it from there (its lora_down projection accumulates
-    // over the chunks in the spare third fragment of waves 4 / 5).
+    // ---- 6 + 7. l3 = LN3(h2) -> activation image, then the feed-forward in chunks of 128 hidden units.  FF1 chunk: wave w
+    // owns hidden columns 16 w .. + 16 of the chunk: weight rows vb + fr (value) and vb + 64 + fr (gate) of the 64-interleaved
+    // GEGLU weight image; the stacked lora_down rows ride in the first chunk as a third fragment of waves 0 / 1.  The bf16
+    // chunk goes to one of two LDS images ([64][128], chunk c of row r at position c ^ (r & 15)); FF2 reads it from there (its
+    // lora_down projection accumulates over the chunks in the spare third fragment of waves 4 / 5).  Weight fragments of the
+    // NEXT K loop are always in flight across the phase boundary in front of it.
     {
         const XLin& L1 = p.lin[3];
         const XLin& L2 = p.lin[4];
@@ -678,6 +707,21 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
         S1.r2 = make_rsrc(duty1 ? L1.dn : L1.w, duty1 ? L1.dn_bytes : L1.w_bytes);
         S1.v2 = (unsigned)fr * L1.lddn_b + (unsigned)(fg << 4);
         S1.s2 = (unsigned)uniform((int)((unsigned)(16 * wave) * L1.lddn_b));
+        auto s1_chunk = [&](int c) {
+            S1.s0 = (unsigned)uniform((int)((unsigned)((256 * c + vb) / 16) * fstride1));
+            S1.s1 = (unsigned)uniform((int)(S1.s0 + 4u * fstride1));
+            S1.has2 = duty1 && c == 0;
+        };
+        typename St::WF wf2;
+        s1_chunk(0);
+        f32x4 b2[NFW];
+        st.ln_params(lg, lb, p.ln3_g, p.ln3_b);
+        st.load_bias(b2, L2.bias, 0);
+        st.template prefetch<KS>(wf, S1);           // (flies during LayerNorm)
+        st.layernorm(h, lg, lb, p.ln_eps);
+        st.add_bias(h, b2);                         // ff.net.2 bias: h becomes the accumulator of h3
+        barrier_keep_dma();
+        XSTAMP(7);
         typename St::Src S2 = st.src_c(L2, 0, 0, true);
         const unsigned s2_0 = S2.s0, s2_1 = S2.s1, s2_2 = S2.s2;
         const unsigned cinc = 4u * S2.kinc, cinc2 = 4u * S2.kinc2;       // a chunk = 4 k-steps
@@ -687,15 +731,23 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
         for (int c = 0; c < NCHUNK; ++c) {
             Acc u;
             St::zero(u);
-            S1.s0 = (unsigned)uniform((int)((unsigned)((256 * c + vb) / 16) * fstride1));
-            S1.s1 = (unsigned)uniform((int)(S1.s0 + 4u * fstride1));
-            S1.has2 = duty1 && c == 0;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f}, bg = {0.f, 0.f, 0.f, 0.f};
             if (L1.bias) {
                 bv = *(const f32x4*)(L1.bias + 256 * c + vb + 4 * fg);
                 bg = *(const f32x4*)(L1.bias + 256 * c + vb + 64 + 4 * fg);
             }
-            st.template kloop<KS, ARS, false>(u, st.bufA, 0, S1);
+            bf16x8 uv = {0, 0, 0, 0, 0, 0, 0, 0}, ug = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (L1.tf) {
+                const unsigned su = (unsigned)uniform((int)((unsigned)(256 * c + vb) * L1.ldup_b));
+                uv = buf_load16(ru1, vu1, su);
+                ug = buf_load16(ru1, vu1, su + 64u * L1.ldup_b);
+            }
+            st.template kloop<KS, ARS, false>(u, st.bufA, 0, S1, wf);
+            // FF2's first fragments of this chunk fly during the K-extension, GEGLU and the barrier
+            S2.s0 = (unsigned)uniform((int)(s2_0 + cinc * (unsigned)c));
+            S2.s1 = (unsigned)uniform((int)(s2_1 + cinc * (unsigned)c));
+            S2.s2 = (unsigned)uniform((int)(s2_2 + cinc2 * (unsigned)c));
+            st.template prefetch<4, 3>(wf2, S2);
             if (L1.tf) {
                 if (c == 0) {
                     if (duty1) {
@@ -705,9 +757,6 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
                     barrier_keep_dma();
                 }
                 // K-extension of the chunk: T (scale up)^T for its value / gate rows
-                const unsigned su = (unsigned)uniform((int)((unsigned)(256 * c + vb) * L1.ldup_b));
-                const bf16x8 uv = buf_load16(ru1, vu1, su);
-                const bf16x8 ug = buf_load16(ru1, vu1, su + 64u * L1.ldup_b);
                 const unsigned char* tp = st.bufT + fr * 64 + ((fg ^ st.t_sw) << 4);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -737,20 +786,29 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
                     *(u32x2*)(gb + (16 * i + fr) * GRS + (((2 * wave + (fg >> 1)) ^ fr) << 4) + ((fg & 1) << 3)) = w;
                 }
             }
+            // the next chunk's FF1 fragments fly during FF2
+            if (c + 1 < NCHUNK) {
+                s1_chunk(c + 1);
+                st.template prefetch<KS>(wf, S1);
+            }
             // chunk visible; every wave has finished FF2 of chunk c - 1, i.e. image (c + 1) & 1 is free again
             barrier_keep_dma();
             if (c == 0) XSTAMP(12);
             // FF2 partial sums: h += g[:, chunk] W2[:, 128 c .. + 128]^T
-            S2.s0 = (unsigned)uniform((int)(s2_0 + cinc * (unsigned)c));
-            S2.s1 = (unsigned)uniform((int)(s2_1 + cinc * (unsigned)c));
-            S2.s2 = (unsigned)uniform((int)(s2_2 + cinc2 * (unsigned)c));
-            st.template kloop<4, GRS, true>(h, st.bufG + (c & 1) * Cf::GBUF, 0, S2);
+            st.template kloop<4, GRS, true, 3>(h, st.bufG + (c & 1) * Cf::GBUF, 0, S2, wf2);
             if (c == 0) XSTAMP(13);
         }
+        // proj_out's first fragments fly during the last K-extension and the hand-over of h3
+        if (p.has_po) {
+            S = st.src_c(p.lin[5], 0, 0, true);
+            st.template prefetch<KS>(wf, S);
+        }
         if (L2.tf) {
+            bf16x8 uf[NFW];
+            st.ext_load(uf, L2, 0);
             st.write_t(h, L2.tf);
             barrier_keep_dma();
-            st.ext(h, L2, 0);
+            st.ext_apply(h, uf);
         }
     }
 
@@ -763,12 +821,13 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
         Acc y;
         St::zero(y);
         const XLin& L = p.lin[5];
-        const typename St::Src S = st.src_c(L, 0, 0, true);
-        st.template kloop<KS, ARS, false>(y, st.bufA, 0, S);
+        bf16x8 uf[NFW];
+        st.ext_load(uf, L, 0);
+        st.template kloop<KS, ARS, false>(y, st.bufA, 0, S, wf);
         if (L.tf) {
             st.write_t(y, L.tf);
             barrier_keep_dma();
-            st.ext(y, L, 0);
+            st.ext_apply(y, uf);
         }
         XSTAMP(9);
         st.store_out(y, L.bias, p.res, p.ld_res, p.out, p.ld_out, m0, M, p.col_stats, p.stats_atom, p.rows_per_sample);
@@ -792,6 +851,9 @@ __global__ __launch_bounds__(512) void xblock_head_kernel(const XHeadArgs p) {
     St st;
     const int m0 = (int)blockIdx.x * XBM, M = p.m;
     const int tid = (int)threadIdx.x;
+    typename St::WF wf;
+    typename St::Src S = st.src_c(p.lin[0], 0, 0, true);
+    st.template prefetch<KS>(wf, S);
     *(u32x2*)(st.bufT + tid * 8) = u32x2{0u, 0u};
     if (p.gn_cstats) {
         // ---- GroupNorm apply: per-channel {mean, rstd * gamma, beta} of this stripe's sample in LDS, then one pass over the
@@ -849,10 +911,14 @@ __global__ __launch_bounds__(512) void xblock_head_kernel(const XHeadArgs p) {
     // ---- p = proj_in(n) + bias -> h_out (the residual stream the tail kernel starts from)
     Acc h;
     St::zero(h);
-    st.linear(h, p.lin[0]);
+    st.linear(h, p.lin[0], S, wf);
     st.store_global(h, p.h_out, p.ld_hout, 0, m0, M);
-    // ---- l1 = LN1(p) -> activation image (n is dead behind LN's first barrier)
-    st.layernorm(h, p.ln1_g, p.ln1_b, p.ln_eps);
+    // ---- l1 = LN1(p) -> activation image (n is dead behind LN's first barrier); the q sweep's first fragments fly meanwhile
+    f32x4 lg[Cf::NFW], lb[Cf::NFW];
+    st.ln_params(lg, lb, p.ln1_g, p.ln1_b);
+    S = st.src_c(p.lin[1], 0, 0, true);
+    st.template prefetch<KS>(wf, S);
+    st.layernorm(h, lg, lb, p.ln_eps);
     barrier_keep_dma();
     // ---- q | k | v: three sweeps over 320 weight rows each; the stacked lora_down rows ride in the first one only
     {
@@ -861,16 +927,21 @@ __global__ __launch_bounds__(512) void xblock_head_kernel(const XHeadArgs p) {
         for (int c = 0; c < 3; ++c) {
             Acc y;
             St::zero(y);
-            const typename St::Src S = st.src_c(L, C * c, 0, c == 0);
             f32x4 b[Cf::NFW];
+            bf16x8 uf[Cf::NFW];
             st.load_bias(b, L.bias, C * c);
-            st.template kloop<KS, ARS, false>(y, st.bufA, 0, S);
+            st.ext_load(uf, L, C * c);
+            st.template kloop<KS, ARS, false>(y, st.bufA, 0, S, wf);
+            if (c + 1 < 3) {        // the next sweep's first fragments fly during the K-extension and the stores
+                S = st.src_c(L, C * (c + 1), 0, false);
+                st.template prefetch<KS>(wf, S);
+            }
             if (L.tf) {
                 if (c == 0) {
                     st.write_t(y, L.tf);
                     barrier_keep_dma();
                 }
-                st.ext(y, L, C * c);
+                st.ext_apply(y, uf);
             }
             st.add_bias(y, b);
             st.store_global(y, p.qkv_out, p.ld_qkv, C * c, m0, M);

@@ -1069,15 +1069,16 @@ class PlanBuilder:
         return out
 
     def basic_block(self, bname: str, hcur: TRef, ctx: TRef, heads: int, hw: int, tname: str = "", last: bool = False,
-                    x_res: Optional[TRef] = None) -> Tuple[TRef, bool]:
+                    x_res: Optional[TRef] = None, qkv: Optional[TRef] = None) -> Tuple[TRef, bool]:
         """Returns (output, done): `done` = the output already is the Transformer2DModel's (proj_out + residual applied by the
-        fused tail kernel)."""
+        fused tail kernel).  ``qkv``: already computed by the fused head kernel (`block_head_fused`)."""
         eng = self.eng
         rows, Cc = hcur.rows, hcur.cols
         S = eng.sites
         fused = bool(tname) and self.stripe_ok(bname, tname, Cc, heads, hw, ctx.rows // self.B)
-        l1 = self.layernorm(bname + ".norm1", hcur, bname + ".l1")
-        qkv = self.gemm_fwd(S[bname + ".attn1.qkv"], l1, bname + ".qkv", rows=rows)
+        if qkv is None:
+            l1 = self.layernorm(bname + ".norm1", hcur, bname + ".l1")
+            qkv = self.gemm_fwd(S[bname + ".attn1.qkv"], l1, bname + ".qkv", rows=rows)
         a1 = self.attention(qkv, qkv, heads, hw, hw, bname + ".a1")
         if fused:
             n_on, n_off = len(self.f_on), len(self.f_off)
@@ -1117,15 +1118,51 @@ class PlanBuilder:
             self.tape.append(bwd)
         return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2), False
 
+    def block_head_fused(self, tname: str, bname: str, x: TRef, hw: int) -> Tuple[TRef, TRef]:
+        """GroupNorm (from the statistics the producer of x left, else the per-op GroupNorm first) + proj_in + norm1 + q|k|v of
+        the first block as ONE launch per list: `leco_xblock_head`.  Returns (residual stream, qkv)."""
+        eng, S = self.eng, self.eng.sites
+        rows, Cc = x.rows, x.cols
+        G = self.cfg.norm_num_groups
+        use_stats = x.cstats is not None and (Cc // G) % self.stat_atom == 0
+        src = x if use_stats else self.groupnorm(tname + ".norm", x, hw, ACT_NONE, 1e-6, tname + ".n")
+        p = self.act(tname + ".pin", rows, Cc)
+        qkv = self.act(bname + ".qkv", rows, 3 * Cc)
+        gg, gb = eng.norm_p[tname + ".norm"]
+        lg, lb = eng.norm_p[bname + ".norm1"]
+        for lora_on, lst in ((True, self.f_on), (False, self.f_off)):
+            A = hip.XBlockHeadArgs()
+            keep = [x, src, p, qkv, gg, gb, lg, lb, self.stat_arena]
+            A.m, A.c, A.rows_per_sample = rows, Cc, hw
+            A.x, A.ld_x = src.ptr, src.ld
+            if use_stats:
+                A.gn_cstats, A.stats_atom, A.groups = x.cstats, self.stat_atom, G
+                A.gn_g, A.gn_b, A.gn_eps = gg.data_ptr(), gb.data_ptr(), 1e-6
+            for fld, nm in (("proj_in", tname + ".proj_in"), ("qkv", bname + ".attn1.qkv")):
+                xl, kp_ = self._xlin(S[nm], lora_on)
+                setattr(A, fld, xl)
+                keep.append(kp_)
+            A.ln1_g, A.ln1_b, A.ln_eps = lg.data_ptr(), lb.data_ptr(), 1e-5
+            A.h_out, A.ld_hout, A.qkv_out, A.ld_qkv = p.ptr, p.ld, qkv.ptr, qkv.ld
+            lst.append(ops.xblock_head(A, keep=keep))
+        return p, qkv
+
     def transformer(self, tname: str, x: TRef, ctx: TRef, level: int, hs: int, ws: int) -> TRef:
         eng, m = self.eng, self.eng.named[tname]
         hw, rows = hs * ws, self.B * hs * ws
-        n = self.groupnorm(tname + ".norm", x, hw, ACT_NONE, 1e-6, tname + ".n")
-        p = self.gemm_fwd(eng.sites[tname + ".proj_in"], n, tname + ".pin", rows=rows)
         nb = len(m.transformer_blocks)
+        b0 = f"{tname}.transformer_blocks.0"
+        qkv0 = None
+        import os
+        if self.stripe_ok(b0, tname, x.cols, self.cfg.heads(level), hw, ctx.rows // self.B) and not isinstance(x, tuple) \
+                and os.environ.get("LECO_STRIPE_HEAD", "1") != "0":
+            p, qkv0 = self.block_head_fused(tname, b0, x, hw)
+        else:
+            n = self.groupnorm(tname + ".norm", x, hw, ACT_NONE, 1e-6, tname + ".n")
+            p = self.gemm_fwd(eng.sites[tname + ".proj_in"], n, tname + ".pin", rows=rows)
         for i in range(nb):
             p, done = self.basic_block(f"{tname}.transformer_blocks.{i}", p, ctx, self.cfg.heads(level), hw, tname=tname,
-                                       last=i == nb - 1, x_res=x)
+                                       last=i == nb - 1, x_res=x, qkv=qkv0 if i == 0 else None)
             if done:
                 return p
         return self.gemm_fwd(eng.sites[tname + ".proj_out"], p, tname + ".out", rows=rows, residual=x, stats_hw=hw)

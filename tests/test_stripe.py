@@ -218,9 +218,9 @@ def test_forward_only_plans_run_the_stripe_kernels_and_match_the_per_op_plan(dev
         m.prepare((B, 4, h, w), lora_on=True)
     fused = eng.plan(B, h, w, need_bwd=False)
     names = [op.name for op in fused.lists["fwd_on"]]
-    assert names.count("leco_xblock_tail") == 3 and names.count("leco_xattn_prep") == 3
-    # norm1 of the 3 fused blocks (norm2 / norm3 live in the stripe kernel) + the mid block (16 pixels: per-op launches)
-    assert names.count("leco_layernorm_fwd") == 3 + 3
+    assert names.count("leco_xblock_tail") == 3 and names.count("leco_xattn_prep") == 3 and names.count("leco_xblock_head") == 3
+    # every LayerNorm of the 3 fused blocks lives in the stripe kernels; the mid block (16 pixels) keeps its per-op launches
+    assert names.count("leco_layernorm_fwd") == 3
     y_on = _run_plan(m, fused, "fwd_on", x, ctx)
     y_off = _run_plan(m, fused, "fwd_off", x, ctx)
     monkeypatch.setenv("LECO_STRIPE", "0")
