@@ -42,10 +42,10 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 900.0):
     DDIM, AdamW), as a port: `oracle/step_ref.leco_step` restates one iteration of train_lora.py:141-281 on the
     oracle UNet / DDIM / LoRA (the reference's own files need `diffusers` and do not exist on the GPU box), followed
     by `loss.backward()`, `optimizer.step()`, `lr_scheduler.step()` and the reference's per-step `flush()`
-    (train_lora.py:279-290).  FULL optimizer steps are timed, one per entry of `ks` (k denoising passes each) after an
-    untimed warm-up forward; the steady-state step is scaled with W_ref(k) to the k mean of the GPU run and by the
-    prompt batch (2 x the samples -> 2 x the time; a CPU has no idle lanes to fill).  The reference's OWN files driving
-    the same oracle UNet cost the same (oracle/time_reference_cpu.py, build container: 64 s / 50 s for k = 1 / 2)."""
+    (train_lora.py:279-290).  FULL optimizer steps are timed AT THE GPU RUN'S PROMPT BATCH (`bs` latents per step: nothing
+    about the batch is assumed), one per entry of `ks` (k denoising passes each) after an untimed warm-up forward; the
+    steady-state step is scaled with W_ref(k) to the k mean of the GPU run.  The reference's OWN files driving the same
+    oracle UNet cost the same (oracle/time_reference_cpu.py, build container: 64 s / 50 s for k = 1 / 2 at prompt batch 1)."""
     import gc
     from oracle import lora_ref, step_ref
     from oracle import unet_ref as R
@@ -67,16 +67,16 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 900.0):
     emb = {n: torch.randn(1, 77, 768, generator=eg) for n in ("target", "neutral")}
     emb["positive"], emb["unconditional"] = emb["target"], emb["neutral"]       # 'van gogh' erase: 2 distinct prompts
     with torch.no_grad():      # untimed warm-up pass (thread pool, allocator): the first forward of a process is ~1.6x slow
-        unet(torch.zeros(2, 4, 64, 64), torch.tensor(1), encoder_hidden_states=torch.zeros(2, 77, 768))
+        unet(torch.zeros(2 * bs, 4, 64, 64), torch.tensor(1), encoder_hidden_states=torch.zeros(2 * bs, 77, 768))
     times, losses = [], []
     t_all = time.perf_counter()
     for i, k in enumerate(ks):
         # ALWAYS at least two full steps (the first still pays allocator / autograd warm-up); further ones only inside the budget
         if len(times) >= 2 and time.perf_counter() - t_all + times[-1] * 1.3 > budget_s:
             break
-        lat = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(1000 + i))
+        lat = torch.randn(bs, 4, 64, 64, generator=torch.Generator().manual_seed(1000 + i))
         t0 = time.perf_counter()
-        out = step_ref.leco_step(unet, net, sched, emb, lat, k, 50, guidance_scale=1.0, action="erase", batch_size=1)
+        out = step_ref.leco_step(unet, net, sched, emb, lat, k, 50, guidance_scale=1.0, action="erase", batch_size=bs)
         opt.zero_grad()
         out["loss"].backward()
         opt.step()
@@ -91,14 +91,12 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 900.0):
     b = times[-1] / (ks[len(times) - 1] + 5 + ATTN_SHARE)
     a = b * (5 + ATTN_SHARE)
     how = f"W_ref(k): {b:.1f} s per forward-equivalent from the last step"
-    t_bs1 = a + b * k_mean
-    t_step = bs * t_bs1
+    t_step = a + b * k_mean
     return {"value": 1.0 / t_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(times)} full fp32 optimizer steps of the ported reference loop at prompt batch 1 with k = "
-                      f"{list(ks[:len(times)])}: {', '.join(f'{t:.1f} s' for t in times)}; the LAST one, evaluated at k = "
-                      f"{k_mean:.1f} ({how}); prompt batch {bs} is ASSUMED to cost {bs}x prompt batch 1 (not measured: the "
-                      f"CPU has no idle lanes to fill) -- value_prompt_batch_1 is the measured-batch figure",
-            "value_prompt_batch_1": 1.0 / t_bs1,
+            "sample": f"{len(times)} full fp32 optimizer steps of the ported reference loop at prompt batch {bs} (the GPU run's: "
+                      f"measured, not scaled from batch 1) with k = {list(ks[:len(times)])}: "
+                      f"{', '.join(f'{t:.1f} s' for t in times)}; the LAST one, evaluated at k = {k_mean:.1f} ({how})",
+            "prompt_batch": bs,
             "steps_timed": len(times), "k": list(ks[:len(times)]), "step_seconds": times,
             "host_cpus": os.cpu_count(), "threads": torch.get_num_threads()}
 
@@ -167,6 +165,17 @@ def _launch_identity(op):
         qf = 2 if -(-sq // 128) * H * B >= 1024 else 1
         return ([f"attn_fwd_kernel<{d}, {qf}, {'true' if skv % 64 else 'false'}>"], (op.name, B, H, sq, skv, d),
                 4.0 * B * H * sq * skv * d, 2.0 * B * H * d * (2 * sq + 2 * skv))
+    if op.name == "leco_xblock_tail":
+        A = op.keep[0]
+        po = 1 if A.proj_out.w else 0
+        lora = 1 if A.to_out1.dn else 0
+        return ([f"xblock_tail_kernel<{A.c}, {A.c // A.heads}>"], (op.name, A.m, A.c, A.heads, po, lora),
+                A.m * (2.0 * A.c * A.c * (15 + po) + 4.0 * A.skv * A.c),
+                2.0 * (A.m * A.c * (3 + po) + A.c * A.c * (15 + po)))
+    if op.name == "leco_xblock_head":
+        A = op.keep[0]
+        return ([f"xblock_head_kernel<{A.c}>"], (op.name, A.m, A.c, 1 if A.gn_cstats else 0, 1 if A.proj_in.dn else 0),
+                A.m * 2.0 * A.c * A.c * 4, 2.0 * (A.m * A.c * 5 + 4 * A.c * A.c))
     if op.name == "leco_attention_bwd":
         B, H, sq, skv, d = a[26], a[27], a[28], a[29], a[30]
         return ["attention_bwd(3 kernels)"], (op.name, B, H, sq, skv, d), 10.0 * B * H * sq * skv * d, 2.0 * B * H * d * (4 * sq + 4 * skv)
@@ -220,7 +229,7 @@ def _time_launch_us(op, reps=8):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-def dominant_kernel_roofline(st, k_mean, only_replay=False):
+def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
     """Times every distinct launch of a step in isolation (HIP events on the compute stream, L2-warm repeats), attributes
     each to its kernel instantiation, picks the instantiation with the largest share of the step and reports its
     launch-weighted average duration and algorithmic FLOPs per launch.  MFMA-busy and HBM traffic per launch come from the
@@ -264,9 +273,11 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False):
     # live ranking decides.
     name = top["name"] if (top and top["name"] in per_name and _summary_hash(PROFILE_STATS) == cur) else live_name
 
+    trace_current = bool(top and top["name"] in per_name and _summary_hash(PROFILE_STATS) == cur)
+
     def describe_kernel(nm):
         n, us, fl, shapes, by = per_name[nm]
-        achieved = fl / us / 1e6 if us else 0.0       # TFLOP/s
+        achieved = fl / us / 1e6 if us else 0.0       # TFLOP/s, from the isolated (L2-warm, back-to-back) live timing
         heavy = max(shapes.items(), key=lambda kv: kv[1][0] * kv[1][1])
         return {"name": nm, "launches_per_step": n, "us_per_launch": us / n, "flops_per_launch": fl / n,
                 "algorithmic_bytes_per_launch": by / n,
@@ -276,6 +287,25 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False):
                                    "tflops": heavy[1][2] / heavy[1][1] / 1e6 if heavy[1][1] else 0.0}}
     out = describe_kernel(name)
     out.update({"profile_top_row": top, "live_top": live_name, "agrees_with_profile": bool(top and top["name"] == name)})
+    # The headline fraction divides the algorithmic FLOPs per launch by the kernel's average duration IN THE COMMITTED KERNEL
+    # TRACE of this command (launches in step order, cold L2 between different kernels) whenever that trace was taken on the
+    # running kernel sources; the isolated live timing stays as `frac_isolated` / `achieved_isolated`.
+    out["achieved_isolated"], out["frac_isolated"] = out["achieved"], out["frac"]
+    out["timing_source"] = "live isolated launches (no kernel trace of these kernel sources in profiles/)"
+    if trace_current and top["avg_us"] > 0:
+        out["us_per_launch_trace"] = top["avg_us"]
+        out["achieved"] = out["flops_per_launch"] / top["avg_us"] / 1e6
+        out["frac"] = out["achieved"] / (PEAK_BF16 / 1e12)
+        out["timing_source"] = f"avg duration of the row in {os.path.relpath(PROFILE_STATS, ROOT)} (rocprofv3 --kernel-trace of this command)"
+    if dump_shapes:
+        # every shape the dominant kernel runs in a step: the numerator of the fraction can be recomputed from this table
+        n, us, fl, shapes, by = per_name[name]
+        with open(dump_shapes, "w") as fh:
+            fh.write(f"# dominant kernel {name} on kernel sources {cur}: launches per step (k mean {k_mean:.2f}), algorithmic GFLOP and "
+                     f"isolated us per launch, by shape key {'(op, m, n, k, a_mode, ext_k, fusedT, residual, act, batch, h_in, h_out, tile, split)' if 'gemm' in name or 'conv' in name else ''}\n")
+            for key, (w, u, f) in sorted(shapes.items(), key=lambda kv: -kv[1][0] * kv[1][2]):
+                fh.write(f"{w:9.2f} launches  {f / 1e9:10.3f} GFLOP  {u:8.1f} us  {' '.join(str(x) for x in key)}\n")
+            fh.write(f"# total: {n:.2f} launches per step, {fl / 1e9:.1f} GFLOP per step -> {fl / n / 1e9:.3f} GFLOP per launch (launch-weighted)\n")
     # the next instantiations by share of the step (live timing), each with its own fraction of the MFMA peak and -- from the
     # same counter files, which also hold the launches of the plan-building pass -- its MFMA-busy share
     out["next_kernels"] = []
@@ -327,6 +357,8 @@ def main():
     ap.add_argument("--no-dominant", action="store_true",
                     help="skip the per-launch isolation timing behind the roofline object (kernel traces of the benchmark "
                          "command are taken with it, so the trace holds the step's own launches only)")
+    ap.add_argument("--dump-shapes", default=None, metavar="FILE",
+                    help="write the per-shape (launches, GFLOP, us) table of the dominant kernel to FILE (profiles/rNN_dominant_shapes.txt)")
     ap.add_argument("--k", type=int, default=0, help="profiling only: fixed number of denoising passes per step "
                                                      "(0 = the seeded reference distribution; the headline number uses 0)")
     args = ap.parse_args()
@@ -493,7 +525,7 @@ def main():
         if args.no_dominant or emu:
             raise RuntimeError("--no-dominant")
         st = fused._state[(args.bs, args.res // 8, args.res // 8)]
-        dom = dominant_kernel_roofline(st, sum(timed_ks) / len(timed_ks))
+        dom = dominant_kernel_roofline(st, sum(timed_ks) / len(timed_ks), dump_shapes=args.dump_shapes)
         # the roofline object is the DOMINANT KERNEL's (algorithmic FLOPs per launch / its average launch duration);
         # the whole-step figure rides along
         out["roofline"] = {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",

@@ -71,12 +71,13 @@ class LoRAModule(nn.Module):
 class LoRANetwork(nn.Module):
     def __init__(self, unet, rank: int = 4, multiplier: float = 1.0, alpha: float = 1.0,
                  train_method: TRAINING_METHODS = "full", target_replace_modules: Optional[List[str]] = None,
-                 strict_reference: bool = False) -> None:
+                 strict_reference: bool = False, strict_dtype: torch.dtype = torch.bfloat16) -> None:
         super().__init__()
         self.multiplier = multiplier
         self.lora_dim = rank
         self.alpha = alpha
         self.strict_reference = strict_reference
+        self.strict_dtype = strict_dtype          # the precision `--strict_reference` rounds the parameters to (train.precision)
         targets = list(DEFAULT_TARGET_REPLACE if target_replace_modules is None else target_replace_modules)
         self.unet_loras: List[LoRAModule] = self.create_modules(LORA_PREFIX_UNET, unet, targets, rank, multiplier,
                                                                train_method)
@@ -145,8 +146,8 @@ class LoRANetwork(nn.Module):
 
     def _adopt(self, slab: torch.Tensor) -> None:
         dev = slab.device
-        if self.strict_reference:  # reference keeps bf16 parameters and bf16 AdamW state (train_lora.py:78,89)
-            slab = slab.to(torch.bfloat16).float()
+        if self.strict_reference:  # reference keeps the parameters and the AdamW state in train.precision (train_lora.py:78,89)
+            slab = slab.to(getattr(self, "strict_dtype", torch.bfloat16)).float()
         self.slab = slab.requires_grad_(True)         # autograd anchor of the engine's Function
         self.grad = torch.zeros_like(slab)
         self.shadow = slab.detach().to(torch.bfloat16)
@@ -299,6 +300,12 @@ class ForeignLoRANetwork(LoRANetwork):
         self.unet_loras = [_ForeignModuleView(n, fm) for n, fm in patched]
         self.lora_dim = self.unet_loras[0].lora_dim
         self.alpha = float(self.unet_loras[0].scale * self.lora_dim)
+        # the packed operand images carry ONE rank and ONE scale per GEMM site (fused q|k|v: three modules): modules that
+        # share a site must agree -- which the reference's own network guarantees (one rank / alpha for all, lora.py:118-127)
+        for l in self.unet_loras:
+            if l.lora_dim != self.lora_dim or abs(l.scale - self.unet_loras[0].scale) > 1e-12:
+                raise ValueError(f"adopted LoRA modules must share rank and alpha: {l.lora_name} has rank {l.lora_dim} / scale "
+                                 f"{l.scale}, the first module rank {self.lora_dim} / scale {self.unet_loras[0].scale}")
         self.version = 0
         self._packed_version = -1
         self._unet = [unet]

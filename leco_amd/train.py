@@ -189,21 +189,19 @@ class FusedStep:
                       preds={n: fplan.pred[2 * bs * i:2 * bs * (i + 1)]
                              for i, n in enumerate(("positive", "neutral", "unconditional"))},
                       half_n=bs * 4 * h * w)
-            f32ctx = ops.f32_mode(eng.f32)
-            f32ctx.__enter__()
-            if self.generic:
-                st["noise"] = (torch.zeros(st["half_n"], dtype=torch.float32, device=self.dev)
-                               if self.sched.needs_noise else None)
-                st["hist"] = (torch.zeros(self.sched.n_hist * st["half_n"], dtype=torch.float32, device=self.dev)
-                              if self.sched.n_hist else None)
-                tail = [ops.cfg_sched_step(dplan.pred, st["x"], dplan.x_in, self.coef, dplan.t_idx, DENOISE_GUIDANCE,
-                                           st["half_n"], st["noise"], st["hist"], self.sched.n_hist),
-                        ops.advance(dplan.t_idx)]
-            else:
-                tail = [ops.cfg_ddim_step(dplan.pred, st["x"], dplan.x_in, self.coef, dplan.t_idx, DENOISE_GUIDANCE,
-                                          st["half_n"]),
-                        ops.advance(dplan.t_idx)]
-            f32ctx.__exit__()
+            with ops.f32_mode(eng.f32):       # (context manager: an exception in here must not leave the module flag set)
+                if self.generic:
+                    st["noise"] = (torch.zeros(st["half_n"], dtype=torch.float32, device=self.dev)
+                                   if self.sched.needs_noise else None)
+                    st["hist"] = (torch.zeros(self.sched.n_hist * st["half_n"], dtype=torch.float32, device=self.dev)
+                                  if self.sched.n_hist else None)
+                    tail = [ops.cfg_sched_step(dplan.pred, st["x"], dplan.x_in, self.coef, dplan.t_idx, DENOISE_GUIDANCE,
+                                               st["half_n"], st["noise"], st["hist"], self.sched.n_hist),
+                            ops.advance(dplan.t_idx)]
+                else:
+                    tail = [ops.cfg_ddim_step(dplan.pred, st["x"], dplan.x_in, self.coef, dplan.t_idx, DENOISE_GUIDANCE,
+                                              st["half_n"]),
+                            ops.advance(dplan.t_idx)]
             # cross-attention K/V (+ their LoRA down projections) depend only on the prompt embeddings: the k
             # denoising passes of a step share one evaluation ("ctx_on"), the per-pass list skips those ops
             dplan.lists["ctx_on"] = [op for op in dplan.lists["fwd_on"] if op.tag == "ctx"]
@@ -411,11 +409,29 @@ def load_training_state(path, fused: "FusedStep", lr_scheduler=None) -> int:
     """Restores `save_training_state`; returns the next iteration index."""
     blob = torch.load(path, map_location="cpu", weights_only=True)
     net = fused.net
+    # ---- validate everything BEFORE touching the live network / optimizer (a refused resume must leave them as they were)
+    rngs = blob["rng"]
+    if isinstance(rngs, torch.Tensor):          # format 1 (single process): the CPU generator state alone
+        rngs = [{"cpu": rngs}]
+    saved_world = int(blob.get("world_size", len(rngs)))
+    if saved_world != fused.world or len(rngs) != fused.world:
+        # a different rank count means a different global batch and a different replay of the shared k stream: the
+        # continuation would silently be another run
+        raise ValueError(f"{path}: training state was saved by {saved_world} rank(s) ({len(rngs)} RNG streams); this run "
+                         f"has {fused.world}.  Resume with the same number of ranks.")
+    for k in STATE_KEYS:
+        if tuple(blob[k].shape) != tuple(getattr(net, k).shape):
+            raise ValueError(f"{path}: {k} has shape {tuple(blob[k].shape)}, the network's is {tuple(getattr(net, k).shape)} "
+                             "(different rank / network type / model)")
+    has_obj_state = blob.get("optimizer") is not None
+    if has_obj_state == isinstance(fused.optimizer, str):
+        raise ValueError(f"{path}: saved with {'an optimizer object' if has_obj_state else 'the fused optimizer kernel'}, this "
+                         f"run uses {'the fused optimizer kernel' if has_obj_state else 'an optimizer object'}: same config needed")
     with torch.no_grad():
         for k in STATE_KEYS:
             getattr(net, k).detach().copy_(blob[k].to(getattr(net, k).device))
     fused.opt_step = int(blob["opt_step"])
-    if blob.get("optimizer") is not None and not isinstance(fused.optimizer, str):
+    if has_obj_state:
         fused.optimizer.load_state_dict(blob["optimizer"])
     if lr_scheduler is not None and blob.get("lr_scheduler") is not None:
         lr_scheduler.load_state_dict(blob["lr_scheduler"])
@@ -426,15 +442,6 @@ def load_training_state(path, fused: "FusedStep", lr_scheduler=None) -> int:
     if fused.world > 1:
         import torch.distributed as dist
         rank = dist.get_rank(fused.pg)
-    rngs = blob["rng"]
-    if isinstance(rngs, torch.Tensor):          # format 1 (single process): the CPU generator state alone
-        rngs = [{"cpu": rngs}]
-    saved_world = int(blob.get("world_size", len(rngs)))
-    if saved_world != fused.world or len(rngs) != fused.world:
-        # a different rank count means a different global batch and a different replay of the shared k stream: the
-        # continuation would silently be another run
-        raise ValueError(f"{path}: training state was saved by {saved_world} rank(s) ({len(rngs)} RNG streams); this run "
-                         f"has {fused.world}.  Resume with the same number of ranks.")
     torch.set_rng_state(rngs[rank]["cpu"])
     if fused.dev.type == "cuda" and "cuda" in rngs[rank]:
         torch.cuda.set_rng_state(rngs[rank]["cuda"], fused.dev)
@@ -488,11 +495,13 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
     save_weight_dtype = config_util.parse_precision(config.train.precision)  # sic, train_lora.py:55
     # train.precision (config_util.py:75-83, train_lora.py:54-67): float32 runs the fp32 compute mode (fp32 activations,
     # weights and LoRA operands, exact fp32 MFMA contractions: csrc/f32.hip -- the reference's arithmetic for such
-    # configs, several times slower than the bf16 MFMA path); bfloat16 is the MFMA path; float16 has no kernels here
-    # and is computed in bf16 (same 16-bit storage cost, wider exponent), the saved LoRA is fp16 as requested.
-    compute_dtype = torch.float32 if weight_dtype == torch.float32 else torch.bfloat16
+    # configs, several times slower than the bf16 MFMA path); bfloat16 is the MFMA path; float16 (11 significand bits) has
+    # no MFMA instantiation here and must not silently run on the narrower bf16 (8 bits): it is computed in the fp32 mode
+    # (>= the requested precision everywhere), the saved LoRA is fp16 as requested.
+    compute_dtype = torch.bfloat16 if weight_dtype == torch.bfloat16 else torch.float32
     if weight_dtype == torch.float16:
-        print("note: train.precision=float16 is computed on the bf16 MFMA path; only the saved LoRA is fp16.")
+        print("note: train.precision=float16 is computed in the fp32 mode (there are no fp16 kernels; bf16 would be narrower "
+              "than requested); only the saved LoRA is fp16.  Use bfloat16 for the fast MFMA path.")
 
     if xl:
         tokenizers, text_encoders, unet, noise_scheduler = model_util.load_models_xl(
@@ -517,7 +526,8 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
         torch.manual_seed(DP_BASE_SEED)
     network = LoRANetwork(unet, rank=config.network.rank, multiplier=1.0, alpha=config.network.alpha,
                           train_method=config.network.training_method, target_replace_modules=modules,
-                          strict_reference=strict_reference).to(device, dtype=weight_dtype)
+                          strict_reference=strict_reference,
+                          strict_dtype=weight_dtype if weight_dtype != torch.float32 else torch.bfloat16).to(device, dtype=weight_dtype)
 
     if world > 1:
         # ... and from here on every rank draws its OWN prompt pair / resolution / crops / latents (the reference's
@@ -582,21 +592,46 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
     # DP: every rank draws its own prompt pair / noise, but the SAME k (shared-seed generator) so that
     # all ranks run the same number of denoising passes.
     k_gen = torch.Generator().manual_seed(20230701) if world > 1 else None
+    # ... and the SAME shape class: a step's (batch_size, height, width) decides which launch plans run, so ranks in
+    # different classes would wait for the slowest at the all-reduce ("prefer same-shape prompts per
+    # step").  The shared generator draws a pair index (uniform over the pairs, like train_lora.py:148-150) and -- for
+    # dynamic_resolution prompts -- the bucket; every rank then draws ITS pair among the pairs of that index's class
+    # (batch_size, resolution, dynamic_resolution) from its own stream.  The marginal distribution over pairs stays uniform.
+    shape_gen = torch.Generator().manual_seed(20230702) if world > 1 else None
+    shape_class = lambda p: (p.batch_size, p.resolution, bool(p.dynamic_resolution))
+    class_members = {}
+    for idx, p in enumerate(prompt_pairs):
+        class_members.setdefault(shape_class(p), []).append(idx)
+
+    def draw_shared(step_k_only: bool = False):
+        """One step's shared draws, in a fixed order (the resume path replays them)."""
+        k = torch.randint(1, config.train.max_denoising_steps, (1,), generator=k_gen).item()
+        if shape_gen is None:
+            return k, None, None
+        lead = prompt_pairs[torch.randint(0, len(prompt_pairs), (1,), generator=shape_gen).item()]
+        hw = None
+        if lead.dynamic_resolution:
+            hw = train_util.get_random_resolution_in_bucket(lead.resolution, generator=shape_gen)
+        return k, shape_class(lead), hw
     loss = None
     start = 0
     if resume_from is not None:
         start = load_training_state(resume_from, fused, lr_scheduler)
-        if k_gen is not None:   # replay the shared k stream up to the resume point
+        if k_gen is not None:   # replay the shared streams up to the resume point
             for _ in range(start):
-                torch.randint(1, config.train.max_denoising_steps, (1,), generator=k_gen)
+                draw_shared()
     for i in it:
         if i < start:
             continue
-        pair = prompt_pairs[torch.randint(0, len(prompt_pairs), (1,)).item()]
-        timesteps_to = torch.randint(1, config.train.max_denoising_steps, (1,), generator=k_gen).item()
+        timesteps_to, cls, shared_hw = draw_shared()
+        if cls is None:
+            pair = prompt_pairs[torch.randint(0, len(prompt_pairs), (1,)).item()]
+        else:
+            members = class_members[cls]
+            pair = prompt_pairs[members[torch.randint(0, len(members), (1,)).item()]]
         height, width = pair.resolution, pair.resolution
         if pair.dynamic_resolution:
-            height, width = train_util.get_random_resolution_in_bucket(pair.resolution)
+            height, width = shared_hw if shared_hw is not None else train_util.get_random_resolution_in_bucket(pair.resolution)
         if config.logging.verbose:
             print("gudance_scale:", pair.guidance_scale, "resolution:", pair.resolution, "dynamic_resolution:",
                   pair.dynamic_resolution, (height, width), "batch_size:", pair.batch_size)

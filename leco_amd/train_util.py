@@ -169,9 +169,11 @@ def get_lr_scheduler(name: Optional[str], optimizer, max_iterations: Optional[in
     return table[name]()
 
 
-def get_random_resolution_in_bucket(bucket_resolution: int = 512):
+def get_random_resolution_in_bucket(bucket_resolution: int = 512, generator=None):
+    """train_util.py:404-416.  ``generator`` (extension): the data-parallel loop draws the bucket from a generator shared by
+    all ranks, so that a step has the same shape everywhere."""
     max_resolution, min_resolution, step = bucket_resolution, bucket_resolution // 2, 64
     min_step, max_step = min_resolution // step, max_resolution // step
-    height = torch.randint(min_step, max_step, (1,)).item() * step
-    width = torch.randint(min_step, max_step, (1,)).item() * step
+    height = torch.randint(min_step, max_step, (1,), generator=generator).item() * step
+    width = torch.randint(min_step, max_step, (1,), generator=generator).item() * step
     return height, width

@@ -52,6 +52,7 @@ def shape_key(g: GemmArgs, has_ws: bool = True) -> str:
     return (f"m{g.m}n{g.n}k{g.k}a{g.a_mode}{conv}"
             f"{'s' if g.a1 else ''}e{ext}{'T%d' % g.t_rows if g.t_w else ''}{'o' if g.t_out else ''}"
             f"{'r' if g.residual else ''}{'b' if g.bias else ''}{'B' if g.rowbias else ''}A{g.act}{'f' if g.c_f32 else ''}"
+            f"{'S' if g.col_stats else ''}"      # producer-side GroupNorm statistics: extra epilogue work, tiled split-K finish
             f"{'' if has_ws else 'W0'}")
 
 

@@ -1402,12 +1402,26 @@ class UNet2DConditionModel(nn.Module):
     def _adopt_foreign_patches(self) -> None:
         """The reference's LoRAModule (lora.py:97-100) works by re-assigning ``org_module.forward``.  The leaves here only
         HOLD weights -- the launch plans never call ``leaf.forward`` -- so such a network is ADOPTED instead
-        (`lora.adopt_forward_patches`: its parameters become slab views, its products run fused in the GEMMs).  Checked
-        only while no LoRA network is attached: one walk over the leaves per forward until then, nothing afterwards."""
-        if self.engine().network is not None:
+        (`lora.adopt_forward_patches`: its parameters become slab views, its products run fused in the GEMMs).  The leaf list
+        is cached; every forward checks the leaves' instance dicts (cheap) -- also AFTER a network has been attached: a patch
+        that is not part of the attached network would be silently ignored by the launch plans, so it raises."""
+        leaves = self.__dict__.get("_leaf_cache")
+        if leaves is None:
+            leaves = self.__dict__["_leaf_cache"] = [(n, m) for n, m in self.named_modules() if isinstance(m, (nn.Linear, nn.Conv2d))]
+        patched = [(n, m) for n, m in leaves if "forward" in m.__dict__]
+        net = self.engine().network
+        if net is None:
+            if patched:
+                from .lora import adopt_forward_patches
+                adopt_forward_patches(self)
             return
-        from .lora import adopt_forward_patches
-        adopt_forward_patches(self)
+        if patched:
+            owned = {id(getattr(l, "fm", None)) for l in net.unet_loras}
+            for n, m in patched:
+                fm = getattr(m.__dict__["forward"], "__self__", None)
+                if id(fm) not in owned:
+                    raise RuntimeError(f"{n}.forward was re-assigned after a LoRA network had been attached, by something that is "
+                                       "not part of that network: the launch plans would silently ignore it.")
 
     def forward(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None):
         self._adopt_foreign_patches()
