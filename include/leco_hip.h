@@ -304,6 +304,10 @@ int leco_lion(float* p, const float* g, float* m, void* shadow, const float* hyp
               float wd, int64_t n, leco_stream_t stream);
 int leco_cast_f32_bf16(const float* x, void* y, int64_t n, leco_stream_t stream);
 int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream);
+/* dst = `reps` copies of the `bytes` (multiple of 16) at src, back to back: batch broadcast of a tensor that is identical for
+ * several samples (the two halves of predict_noise's cat([latents] * 2), train_util.py:151, before the first use of the
+ * prompt embeddings) */
+int leco_repeat(const void* src, void* dst, int64_t bytes, int32_t reps, leco_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Row-stripe fused transformer-block kernels (csrc/stripe.hip): forward-only, bf16, C = 320 (the 64^2 level of SD1.x /
@@ -349,6 +353,9 @@ int leco_xattn_prep(const void* kv, int64_t ld_kv, void* kp, void* vt, int32_t b
  * like leco_gemm_args.col_stats. */
 typedef struct leco_xblock_tail_args {
     int32_t m, c, heads, skv, rows_per_sample;
+    int32_t src_rows;                    /* 0: attn / h_in / res have m rows.  Else (a multiple of 64 dividing m): they have
+                                            src_rows rows and row r reads row r % src_rows -- samples that are identical up to
+                                            the first use of the prompt (classifier-free-guidance duplicates) are computed once */
     const void* attn; int64_t ld_attn;   /* self-attention output, bf16 [m][c] */
     const void* h_in; int64_t ld_h;      /* residual stream entering the block, bf16 [m][c] */
     leco_xlin to_out1, to_q2, to_out2, ff1, ff2, proj_out;

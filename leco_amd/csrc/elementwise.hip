@@ -698,6 +698,18 @@ extern "C" int leco_cast_f32_bf16(const float* x, void* y, int64_t n, leco_strea
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n)), dim3(256), 0, LECO_STREAM, x, (bf16_t*)y, n);
     return check_launch("leco_cast_f32_bf16");
 }
+// dst[r * bytes + i] = src[i], r < reps (16-byte granules)
+__global__ __launch_bounds__(256) void repeat_kernel(const u32x4* src, u32x4* dst, int64_t n16, int reps) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n16; e += (int64_t)gridDim.x * 256) {
+        const u32x4 v = src[e];
+        for (int r = 0; r < reps; ++r) dst[(int64_t)r * n16 + e] = v;
+    }
+}
+extern "C" int leco_repeat(const void* src, void* dst, int64_t bytes, int32_t reps, leco_stream_t stream) {
+    if (!src || !dst || bytes <= 0 || bytes % 16 || reps <= 0) return fail(-EINVAL, "leco_repeat: bytes=%lld (multiple of 16), reps=%d", (long long)bytes, reps);
+    hipLaunchKernelGGL(repeat_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, LECO_STREAM, (const u32x4*)src, (u32x4*)dst, bytes / 16, reps);
+    return check_launch("leco_repeat");
+}
 extern "C" int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream) {
     hipError_t e = hipMemsetAsync(p, value, (size_t)bytes, LECO_STREAM);
     if (e != hipSuccess) return fail(-EIO, "leco_memset: %s", hipGetErrorString(e));

@@ -98,6 +98,7 @@ struct XCfg {
 
 struct XTailArgs {
     int m, heads, skv, rows_per_sample;
+    int src_rows;     // attn / h_in / res: row r reads row r % src_rows (src_rows % 64 == 0; == m: no wrap)
     const bf16_t* attn; int64_t ld_attn;
     const bf16_t* h_in; int64_t ld_h;
     const float *ln2_g, *ln2_b, *ln3_g, *ln3_b; float ln_eps;
@@ -545,13 +546,14 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
     St st;
     const int wave = st.wave, fr = st.fr, fg = st.fg, f0 = st.f0, nf = st.nf;
     const int m0 = (int)blockIdx.x * XBM, M = p.m;
+    const int ms = m0 % p.src_rows;             // first row of the stripe in the (possibly batch-shared) input tensors
 
     // ---- prologue: the first weight fragments of sweep 1; the self-attention output stripe -> activation image; the T image
     // zeroed (its columns 16 .. 31 are only written by rank-stacks > 16); the residual stream h0 -> registers
     typename St::WF wf;
     typename St::Src S = st.src_c(p.lin[0], 0, 0, true);
     st.template prefetch<KS>(wf, S);
-    st.load_stripe(p.attn, p.ld_attn, m0, M);
+    st.load_stripe(p.attn, p.ld_attn, ms, ms + (M - m0));
     *(u32x2*)(st.bufT + (int)threadIdx.x * 8) = u32x2{0u, 0u};
     Acc h;
     St::zero(h);
@@ -561,7 +563,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
 #pragma unroll
         for (int j = 0; j < NFW; ++j)
             if (j < nf && row < M) {
-                const u32x2 raw = *(const u32x2*)(p.h_in + (int64_t)row * p.ld_h + 16 * (f0 + j) + 4 * fg);
+                const u32x2 raw = *(const u32x2*)(p.h_in + (int64_t)(ms + 16 * i + fr) * p.ld_h + 16 * (f0 + j) + 4 * fg);
                 h[i][j] = f32x4{bf2f((bf16_t)(raw[0] & 0xffffu)), bf2f((bf16_t)(raw[0] >> 16)), bf2f((bf16_t)(raw[1] & 0xffffu)),
                                 bf2f((bf16_t)(raw[1] >> 16))};
             }
@@ -830,7 +832,8 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
             st.ext_apply(y, uf);
         }
         XSTAMP(9);
-        st.store_out(y, L.bias, p.res, p.ld_res, p.out, p.ld_out, m0, M, p.col_stats, p.stats_atom, p.rows_per_sample);
+        st.store_out(y, L.bias, p.res ? p.res + (int64_t)(ms - m0) * p.ld_res : nullptr, p.ld_res, p.out, p.ld_out, m0, M, p.col_stats,
+                     p.stats_atom, p.rows_per_sample);
         XSTAMP(10);
     } else {
         st.store_out(h, nullptr, nullptr, 0, p.out, p.ld_out, m0, M, p.col_stats, p.stats_atom, p.rows_per_sample);
@@ -1062,6 +1065,8 @@ extern "C" int leco_xblock_tail(const leco_xblock_tail_args* a, leco_stream_t st
     const bool has_po = a->proj_out.w != nullptr;
     if (has_po && (rc = fill_lin(p.lin[5], a->proj_out, C, C, "leco_xblock_tail.proj_out"))) return rc;
     p.m = a->m; p.heads = a->heads; p.skv = a->skv; p.rows_per_sample = a->rows_per_sample;
+    if (a->src_rows && (a->src_rows % XBM || a->m % a->src_rows)) return fail(-EINVAL, "leco_xblock_tail: src_rows=%d must be a multiple of 64 dividing m=%d", a->src_rows, a->m);
+    p.src_rows = a->src_rows ? a->src_rows : (a->m + XBM - 1) / XBM * XBM;
     p.attn = (const bf16_t*)a->attn; p.ld_attn = a->ld_attn;
     p.h_in = (const bf16_t*)a->h_in; p.ld_h = a->ld_h;
     p.ln2_g = a->ln2_g; p.ln2_b = a->ln2_b; p.ln3_g = a->ln3_g; p.ln3_b = a->ln3_b; p.ln_eps = a->ln_eps;

@@ -67,6 +67,7 @@ class XLin(C.Structure):          # mirrors `leco_xlin`
 class XBlockTailArgs(C.Structure):     # mirrors `leco_xblock_tail_args`
     _fields_ = [
         ("m", C.c_int32), ("c", C.c_int32), ("heads", C.c_int32), ("skv", C.c_int32), ("rows_per_sample", C.c_int32),
+        ("src_rows", C.c_int32),
         ("attn", C.c_void_p), ("ld_attn", C.c_int64), ("h_in", C.c_void_p), ("ld_h", C.c_int64),
         ("to_out1", XLin), ("to_q2", XLin), ("to_out2", XLin), ("ff1", XLin), ("ff2", XLin), ("proj_out", XLin),
         ("ln2_g", C.c_void_p), ("ln2_b", C.c_void_p), ("ln3_g", C.c_void_p), ("ln3_b", C.c_void_p), ("ln_eps", C.c_float),

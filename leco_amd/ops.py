@@ -45,6 +45,7 @@ _SIGS = {
     "leco_lion": [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp],
     "leco_cast_f32_bf16": [_vp, _vp, _i64, _vp],
     "leco_memset": [_vp, _i32, _i64, _vp],
+    "leco_repeat": [_vp, _vp, _i64, _i32, _vp],
     "leco_lora_pack": [_vp, _i32, _vp],
     "leco_lora_wgrad_conv": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32,
                              _i32, _i32, _vp, _i64, _vp],
@@ -259,6 +260,11 @@ def cast_f32_bf16(x, y, n) -> Op:
 
 def memset(t: torch.Tensor, value: int = 0) -> Op:
     return Op("leco_memset", (ptr(t), value, t.numel() * t.element_size()))
+
+
+def repeat(src: int, dst: int, nbytes: int, reps: int, keep=None) -> Op:
+    """dst = `reps` back-to-back copies of the `nbytes` at src (raw device addresses)."""
+    return Op("leco_repeat", (src, dst, nbytes, reps), keep=keep)
 
 
 def lora_pack(sites_dev: torch.Tensor, nsites: int) -> Op:

@@ -173,17 +173,18 @@ class FusedStep:
                 self._state.pop(old)
                 eng = self.unet.engine()
                 ob, oh, ow = old
-                for pk in ((2 * ob, oh, ow, True), (2 * ob, oh, ow, False), (6 * ob, oh, ow, False), (6 * ob, oh, ow, False, 1)):
+                for pk in [k_ for k_ in eng.plans if k_[0] in (2 * ob, 6 * ob) and k_[1:3] == (oh, ow)]:
                     eng.drop_plan(pk)
             plan = self.unet.prepare((2 * bs, 4, h, w), lora_on=True)
             eng = self.unet.engine()
             # the k partial-denoising passes never see a backward: they run on their own forward-only plan
             # (GEGLU fused into the ff projection's epilogue, no gradient buffers)
-            dplan = eng.plan(2 * bs, h, w, need_bwd=False)
+            # (share: predict_noise's cat([latents] * 2) -- both halves are the same sample until the prompt is used)
+            dplan = eng.plan(2 * bs, h, w, need_bwd=False, share=2)
             # the three LoRA-off predictions (positive / neutral / unconditional) run as ONE forward-only pass of
             # batch 3 x 2bs: same arithmetic per sample (GroupNorm / attention are per sample), three times
             # the rows per GEMM, a third of the launches
-            fplan = eng.plan(6 * bs, h, w, need_bwd=False, ws_slot=1 if self.overlap else 0)
+            fplan = eng.plan(6 * bs, h, w, need_bwd=False, ws_slot=1 if self.overlap else 0, share=6)
             st = dict(plan=plan, dplan=dplan, fplan=fplan,
                       x=torch.zeros(bs, 4, h, w, dtype=torch.float32, device=self.dev),
                       preds={n: fplan.pred[2 * bs * i:2 * bs * (i + 1)]

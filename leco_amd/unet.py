@@ -518,15 +518,21 @@ class Engine:
         net._packed_version = net.version
 
     # ---- plan construction ---------------------------------------------------------------------
-    def plan(self, B: int, h: int, w: int, need_bwd: bool = True, ws_slot: int = 0) -> Plan:
+    def plan(self, B: int, h: int, w: int, need_bwd: bool = True, ws_slot: int = 0, share: int = 1) -> Plan:
         """``need_bwd=False`` builds a forward-only plan (no gradient buffers): used for the batched
         LoRA-off passes, which never run a backward.  ``ws_slot`` > 0 gives the plan's split-K launches a workspace of
         their own (the only mutable buffer plans share), so that its lists may run CONCURRENTLY with another plan's on a
-        second stream (`FusedStep`: the batched frozen pass beside the LoRA-on target pass)."""
+        second stream (`FusedStep`: the batched frozen pass beside the LoRA-on target pass).  ``share`` > 1 (forward-only
+        plans): the caller guarantees that the B input latents are ``share`` back-to-back copies of B / share samples at one
+        timestep (``predict_noise``'s ``cat([latents] * 2)``, train_util.py:151) -- everything in front of the first use of
+        the prompt embeddings is then computed once per distinct sample (`PlanBuilder.shared_prefix`)."""
         key = (B, h, w, need_bwd) if ws_slot == 0 else (B, h, w, need_bwd, ws_slot)
+        if share > 1:
+            assert not need_bwd and B % share == 0
+            key = key + ("share", share)
         if key not in self.plans:
             with ops.f32_mode(self.f32):
-                self.plans[key] = PlanBuilder(self, B, h, w, need_bwd, ws=self.workspace_slot(ws_slot)).build()
+                self.plans[key] = PlanBuilder(self, B, h, w, need_bwd, ws=self.workspace_slot(ws_slot), share=share).build()
         return self.plans[key]
 
     def workspace_slot(self, slot: int) -> torch.Tensor:
@@ -561,8 +567,11 @@ class Engine:
 
 
 class PlanBuilder:
-    def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True, ws: Optional[torch.Tensor] = None):
+    def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True, ws: Optional[torch.Tensor] = None,
+                 share: int = 1):
         self.eng, self.cfg, self.dev = eng, eng.cfg, eng.device
+        self.share = share
+        self.Bfull = B          # (self.B is lowered to B / share while the batch-shared prefix is built)
         self.ws = eng.workspace if ws is None else ws      # split-K slabs of this plan's launches
         self.B, self.h, self.w = B, h, w
         self.need_bwd = need_bwd
@@ -610,14 +619,15 @@ class PlanBuilder:
         self.f_on.append(op)
         self.f_off.append(op)
 
-    def stat_slice(self, cols: int, hw: int) -> Optional[int]:
+    def stat_slice(self, cols: int, hw: int, batch: Optional[int] = None) -> Optional[int]:
         """Device address of a fresh [B][cols / atom][2] slice of the statistics arena (None when the fusion is off or does
         not pay for a tensor of this shape)."""
+        B = self.B if batch is None else batch
         if not self.gn_fused or cols % self.stat_atom:
             return None
-        if self.gn_mode == "auto" and hip.lib().leco_groupnorm_single_launch(self.B, hw, cols, self.cfg.norm_num_groups):
+        if self.gn_mode == "auto" and hip.lib().leco_groupnorm_single_launch(B, hw, cols, self.cfg.norm_num_groups):
             return None
-        n = 2 * self.B * (cols // self.stat_atom)
+        n = 2 * B * (cols // self.stat_atom)
         assert self.stat_used + n <= self.stat_arena.numel(), "GroupNorm statistics arena too small"
         p = self.stat_arena.data_ptr() + 4 * self.stat_used
         self.stat_used += n
@@ -998,6 +1008,24 @@ class PlanBuilder:
         return self.gemm_fwd(eng.sites[rname + ".conv2"], n2, rname + ".out", conv=conv, amode=A_CONV3_S1, rows=rows,
                              residual=sc, stats_hw=hw)
 
+    def shared_prefix_ok(self, ctx: TRef) -> bool:
+        """`share` copies of each sample: can the prompt-independent prefix run once per distinct sample?  Needs the stripe tail
+        kernel on the first transformer (it re-expands the batch) and a time embedding that does not depend on the sample
+        (not SDXL's text_time add-embedding).  LECO_SHARE_PREFIX=0 switches it off (A/B measurements)."""
+        import os
+        if self.share <= 1 or self.need_bwd or self.eng.f32 or os.environ.get("LECO_SHARE_PREFIX", "1") == "0":
+            return False
+        if self.cfg.addition_embed_type is not None:
+            return False
+        blk = self.eng.unet.down_blocks[0]
+        if not blk.has_attn or len(self.eng.named["down_blocks.0.attentions.0"].transformer_blocks) != 1:
+            return False
+        hw = self.h * self.w
+        if (self.Bfull // self.share) * hw % 64:
+            return False
+        return self.stripe_ok("down_blocks.0.attentions.0.transformer_blocks.0", "down_blocks.0.attentions.0",
+                              self.cfg.block_out_channels[0], self.cfg.heads(0), hw, ctx.rows // self.Bfull)
+
     def stripe_ok(self, bname: str, tname: str, Cc: int, heads: int, hw: int, skv: int) -> bool:
         """The row-stripe fused kernels (csrc/stripe.hip) cover this block: forward-only bf16 plan, a supported shape, and
         LoRA operands (if any) in the 32-column packed form.  LECO_STRIPE=0 keeps the per-op launches (A/B measurements)."""
@@ -1034,23 +1062,27 @@ class PlanBuilder:
         """Everything of the block after its self-attention core (+ proj_out and the Transformer2DModel residual when the
         block is the last one) as ONE launch per list (LoRA on / off): `leco_xblock_tail`."""
         eng, S = self.eng, self.eng.sites
-        rows, Cc = hcur.rows, hcur.cols
-        skv = kv.rows // self.B
+        Bt = self.Bfull            # (the block's inputs may exist once per distinct sample: `shared_prefix`)
+        rows, Cc = Bt * hw, hcur.cols
+        skv = kv.rows // Bt
         d = Cc // heads
-        kp, vt = ops.xattn_buffers(self.B, heads, d, self.dev)
+        kp, vt = ops.xattn_buffers(Bt, heads, d, self.dev)
         self.plan.bufs[bname + ".xattn_kp"], self.plan.bufs[bname + ".xattn_vt"] = kp, vt
-        prep = ops.xattn_prep(kv.ptr, kv.ld, kp, vt, self.B, heads, skv, d)
+        prep = ops.xattn_prep(kv.ptr, kv.ld, kp, vt, Bt, heads, skv, d)
         prep.tag = "ctx"
         self.both(prep)
         out = self.act((tname + ".out") if last else (bname + ".h3"), rows, Cc)
         if last:
-            out.cstats = self.stat_slice(Cc, hw) if self.stat_atom % 2 == 0 else None
+            out.cstats = self.stat_slice(Cc, hw, batch=Bt) if self.stat_atom % 2 == 0 else None
         g2, b2 = eng.norm_p[bname + ".norm2"]
         g3, b3 = eng.norm_p[bname + ".norm3"]
         for lora_on, lst in ((True, self.f_on), (False, self.f_off)):
             A = hip.XBlockTailArgs()
             keep = [a1, hcur, kv, out, kp, vt, g2, b2, g3, b3, x_res, self.stat_arena]
             A.m, A.c, A.heads, A.skv, A.rows_per_sample = rows, Cc, heads, skv, hw
+            if a1.rows != rows:        # batch-shared prefix: the block's inputs exist once per distinct sample
+                assert hcur.rows == a1.rows and (x_res is None or x_res.rows == a1.rows) and rows % a1.rows == 0
+                A.src_rows = a1.rows
             A.attn, A.ld_attn, A.h_in, A.ld_h = a1.ptr, a1.ld, hcur.ptr, hcur.ld
             for fld, nm, gg in (("to_out1", bname + ".attn1.to_out.0", False), ("to_q2", bname + ".attn2.to_q", False),
                                 ("to_out2", bname + ".attn2.to_out.0", False), ("ff1", bname + ".ff.net.0.proj", True),
@@ -1075,7 +1107,7 @@ class PlanBuilder:
         eng = self.eng
         rows, Cc = hcur.rows, hcur.cols
         S = eng.sites
-        fused = bool(tname) and self.stripe_ok(bname, tname, Cc, heads, hw, ctx.rows // self.B)
+        fused = bool(tname) and self.stripe_ok(bname, tname, Cc, heads, hw, ctx.rows // self.Bfull)
         if qkv is None:
             l1 = self.layernorm(bname + ".norm1", hcur, bname + ".l1")
             qkv = self.gemm_fwd(S[bname + ".attn1.qkv"], l1, bname + ".qkv", rows=rows)
@@ -1154,7 +1186,7 @@ class PlanBuilder:
         b0 = f"{tname}.transformer_blocks.0"
         qkv0 = None
         import os
-        if self.stripe_ok(b0, tname, x.cols, self.cfg.heads(level), hw, ctx.rows // self.B) and not isinstance(x, tuple) \
+        if self.stripe_ok(b0, tname, x.cols, self.cfg.heads(level), hw, ctx.rows // self.Bfull) and not isinstance(x, tuple) \
                 and os.environ.get("LECO_STRIPE_HEAD", "1") != "0":
             p, qkv0 = self.block_head_fused(tname, b0, x, hw)
         else:
@@ -1200,20 +1232,38 @@ class PlanBuilder:
         self.emb_silu = emb_silu
         self.temb_all = self.buf("temb_all", (B, eng.temb_total), torch.float32)
         self.gemm_fwd(S["time_emb_proj_all"], emb_silu, "temb_all_g", rows=B, out_f32=self.temb_all)
-        # -- conv_in
-        h0 = self.act("conv_in", B * h * w, ch[0])
-        self.both(ops.conv_in(P.x_in, eng.conv_in_w, eng.conv_in_b, h0.t, B, h, w, cfg.in_channels, ch[0]))
+        # -- conv_in.  BATCH-SHARED PREFIX (share > 1: the B latents are `share` copies of B / share samples at one timestep):
+        # conv_in, the first ResnetBlock2D and the first Transformer2DModel up to and including its self-attention do not see
+        # the prompt, so they run ONCE per distinct sample (batch Bp); the stripe tail kernel of that transformer reads them
+        # with a row wrap (leco_xblock_tail_args.src_rows) and produces the full batch, conv_in's output -- a skip connection
+        # of the last up block -- is replicated by one copy.  Same arithmetic per sample: the result does not change.
+        Bp = B // self.share if self.shared_prefix_ok(ctx) else B
+        self.B = Bp
+        h0 = self.act("conv_in", Bp * h * w, ch[0])
+        self.both(ops.conv_in(P.x_in, eng.conv_in_w, eng.conv_in_b, h0.t, Bp, h, w, cfg.in_channels, ch[0]))
         h0.cstats = self.stat_slice(ch[0], h * w)
         if h0.cstats is not None:   # conv_in has no statistics epilogue: one light pass over its output
-            self.both(ops.Op("leco_colstats", (h0.ptr, h0.ld, h0.cstats, self.stat_atom, B, h * w, ch[0]), keep=(h0, self.stat_arena)))
+            self.both(ops.Op("leco_colstats", (h0.ptr, h0.ld, h0.cstats, self.stat_atom, Bp, h * w, ch[0]), keep=(h0, self.stat_arena)))
         cur, hs, ws = h0, h, w
-        skips = [h0]
+        if Bp != B:
+            full = self.act("conv_in.rep", B * h * w, ch[0])
+            self.both(ops.repeat(h0.ptr, full.ptr, Bp * h * w * ch[0] * eng.esz, self.share, keep=(h0, full)))
+            if h0.cstats is not None:
+                nst = 2 * Bp * (ch[0] // self.stat_atom) * 4
+                full.cstats = self.stat_slice(ch[0], h * w, batch=B) if nst % 16 == 0 else None
+                if full.cstats is not None:
+                    self.both(ops.repeat(h0.cstats, full.cstats, nst, self.share, keep=(self.stat_arena,)))
+            skips = [full]
+        else:
+            skips = [h0]
         for i, blk in enumerate(eng.unet.down_blocks):
             bn = f"down_blocks.{i}"
             for j in range(len(blk.resnets)):
                 cur = self.resnet(f"{bn}.resnets.{j}", cur, hs, ws)
                 if blk.has_attn:
                     cur = self.transformer(f"{bn}.attentions.{j}", cur, ctx, i, hs, ws)
+                self.B = B          # (the first transformer's tail has produced the full batch)
+                assert cur.rows == B * hs * ws
                 skips.append(cur)
             if blk.downsamplers is not None:
                 ho, wo = (hs + 1) // 2, (ws + 1) // 2

@@ -274,3 +274,31 @@ def test_xblock_head_matches_the_per_op_chain(dev, rank, gn, B, hw):
     _sync(dev)
     e_h, e_q = rel_err(h_out.cpu(), p), rel_err(qkv_out.cpu(), q)
     assert e_h < 3e-3 and e_q < 3e-3, (e_h, e_q)
+
+
+@pytest.mark.parametrize("share", [2, 6])
+def test_batch_shared_prefix_gives_the_same_prediction(dev, share):
+    """`Engine.plan(..., share=n)`: the latents are n copies of B / n samples (predict_noise's cat([latents] * 2),
+    train_util.py:151; the batched frozen pass: 6 copies), so conv_in, the first ResnetBlock2D and the first transformer up to
+    its self-attention run once per distinct sample and the stripe tail kernel re-expands the batch.  Same arithmetic per
+    sample: the prediction equals the unshared plan's (up to the run-to-run noise of atomically accumulated GroupNorm
+    statistics, absent at this size)."""
+    torch.manual_seed(9)
+    m = _stripe_unet(dev, 8)
+    bs, h, w = 1, 8, 8
+    B = share * bs
+    x1 = torch.randn(bs, 4, h, w).to(bf)
+    x = x1.repeat(share, 1, 1, 1).to(dev)
+    ctx = torch.randn(B, 77, 64).to(dev, bf)          # a different prompt per copy: the tail must use the right one
+    eng = m.engine()
+    shared = eng.plan(B, h, w, need_bwd=False, share=share)
+    plain = eng.plan(B, h, w, need_bwd=False)
+    n_s, n_p = [op.name for op in shared.lists["fwd_off"]], [op.name for op in plain.lists["fwd_off"]]
+    assert n_s.count("leco_repeat") >= 1 and "leco_repeat" not in n_p and len(n_s) <= len(n_p) + 2
+    # the shared plan's prefix tensors hold B / share samples
+    assert shared.bufs["conv_in"].shape[0] == bs * h * w and plain.bufs["conv_in"].shape[0] == B * h * w
+    y_s = _run_plan(m, shared, "fwd_off", x, ctx)
+    y_p = _run_plan(m, plain, "fwd_off", x, ctx)
+    _sync(dev)
+    assert rel_err(y_s, y_p) < 1e-6, rel_err(y_s, y_p)
+    assert rel_err(y_s[0], y_s[1]) > 1e-3          # (the copies really differ through their prompts)

@@ -29,8 +29,13 @@ def build_variant(v):
         define = f"-DLECO_ATTN_OCC40={str(v)[3:]}"
     else:
         define = f"-DLECO_ATTN_ABLATE={v}"
-    srcs = [os.path.join(B.CSRC, f) for f in sorted(os.listdir(B.CSRC)) if f.endswith((".hip", ".cpp"))]
-    subprocess.run([B.HIPCC, *B.FLAGS, define, "-shared", "-x", "hip", *srcs, "-o", out], check=True)
+    # only attention.hip is rebuilt with the switch; the other objects are the product build's
+    B.build()
+    src = os.path.join(B.CSRC, "attention.hip")
+    objs = [o for o in open(os.path.join(B.OBJ, "link.stamp")).read().split() if "/attention.hip." not in o]
+    obj = os.path.join(d, f"attention_{v}.o")
+    subprocess.run([B.HIPCC, *B.FLAGS, define, "-x", "hip", "-c", src, "-o", obj], check=True)
+    subprocess.run([B.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out, *objs, obj], check=True)
     return out
 
 
