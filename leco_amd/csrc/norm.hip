@@ -418,24 +418,47 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
         }
     }
     __syncthreads();
+    // Thread = (row lane, 16-byte channel vector): the per-channel scale / shift a = rstd gamma, b = beta - mean a of its 8
+    // channels live in registers, so the pixel loop is load -> 8 fma (+ SiLU) -> store with no index arithmetic.
     const int nvec = C / 8;
     const int p0 = (int)blockIdx.x * rows_per_block;
     const int p1 = min(hw, p0 + rows_per_block);
-    const int total = (p1 - p0) * nvec;
-    for (int e = tid; e < total; e += 256) {
-        const int pr = e / nvec, c = (e - pr * nvec) * 8;
-        const int64_t row = (int64_t)b * hw + p0 + pr;
-        float x[8], o[8];
-        unpack8(gn_load(src, row, c), x);
-        const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
-        const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+    for (int v0 = 0; v0 < nvec; v0 += 256) {
+        const int nvc = min(256, nvec - v0), rows_par = 256 / nvc;
+        const int rl = tid / nvc, c = (v0 + tid - rl * nvc) * 8;
+        if (rl >= rows_par) continue;
+        float sa[8], sb[8];
+        {
+            const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int g = (c + i) / cg;
-            const float z = (x[i] - gmr[2 * g]) * gmr[2 * g + 1] * (i < 4 ? g0[i] : g1[i - 4]) + (i < 4 ? b0[i] : b1[i - 4]);
-            o[i] = act ? silu(z) : z;
+            for (int i = 0; i < 8; ++i) {
+                const int g = (c + i) / cg;
+                sa[i] = gmr[2 * g + 1] * (i < 4 ? g0[i] : g1[i - 4]);
+                sb[i] = (i < 4 ? b0[i] : b1[i - 4]) - gmr[2 * g] * sa[i];
+            }
         }
-        *(u32x4*)(out + row * ldo + c) = pack8(o);
+        for (int pr = p0 + rl; pr < p1; pr += 4 * rows_par) {
+            u32x4 xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = pr + u * rows_par;
+                xv[u] = gn_load(src, (int64_t)b * hw + (p < p1 ? p : pr), c);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = pr + u * rows_par;
+                if (p >= p1) break;
+                float x[8], o[8];
+                unpack8(xv[u], x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float z = fmaf(x[i], sa[i], sb[i]);
+                    o[i] = act ? silu(z) : z;
+                }
+                *(u32x4*)(out + ((int64_t)b * hw + p) * ldo + c) = pack8(o);
+            }
+        }
     }
 }
 // col_stats[b][c / A] += {sum, sumsq} over a chunk of sample b's rows (tensors whose producer has no statistics
@@ -667,9 +690,9 @@ extern "C" int leco_groupnorm_apply_stats(const void* x0, int64_t ld0, const voi
     if (atom <= 0 || (c / groups) % atom || (x1 && c0 % atom))
         return fail(-EINVAL, "leco_groupnorm_apply_stats: atom %d must divide the group size %d and the concat split", atom, c / groups);
     GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
-    // pixels per block: ~2 blocks per CU (every block first folds its sample's atom sums into group statistics), at least
+    // pixels per block: ~4 blocks per CU (every block first folds its sample's atom sums into group statistics), at least
     // 16 KB of the tensor each
-    int rpb = cdiv((int64_t)batch * hw, 512);
+    int rpb = cdiv((int64_t)batch * hw, 1024);
     const int min_rows = cdiv(16384, (int64_t)c * 2);
     if (rpb < min_rows) rpb = min_rows;
     if (rpb > hw) rpb = hw;

@@ -360,7 +360,8 @@ def test_producer_side_groupnorm_statistics(dev, kind, atom):
 
 
 @pytest.mark.parametrize("act,B,HW,C0,C1,G,atom", [(1, 2, 70, 64, 0, 32, 2), (0, 3, 33, 64, 128, 32, 2), (1, 1, 300, 320, 0, 32, 10),
-                                                   (1, 2, 16, 1280, 640, 32, 10), (0, 2, 20, 64, 0, 16, 1)])
+                                                   (1, 2, 16, 1280, 640, 32, 10), (0, 2, 20, 64, 0, 16, 1),
+                                                   (1, 1, 11, 1280, 1280, 32, 10)])      # 320 channel vectors: two column sweeps
 def test_groupnorm_from_channel_statistics(dev, act, B, HW, C0, C1, G, atom):
     """leco_colstats + leco_groupnorm_apply_stats == F.group_norm(+SiLU) on the (optionally two-source) input; the group
     sums it leaves in `stats` are what the backward kernel expects (same dx as with leco_groupnorm_fwd's statistics)."""

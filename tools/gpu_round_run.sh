@@ -10,14 +10,14 @@
 #          4. every launch of the denoising pass in isolation   -> rNN_plan_denoise.txt;  smoke()
 # tests:   the GPU test tier                                    -> rNN_gpu_tests.log
 # configs: BASELINE configs 3-5: launch-shape tuning + bench    -> rNN_bench_*.json, rNN_tune_*.txt
-RN=${ROUND:-r03}
+RN=${ROUND:-r04}
 R=$PWD; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 what=${1:-measure}
 if [ "$what" = "measure" ]; then
 cd /tmp
-timeout 150 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dominant > /tmp/prof.log 2>&1
+timeout 420 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dominant > /tmp/prof.log 2>&1
 DB=$(find /tmp/prof -name "*.db" | head -1)
-{ echo "# cd /tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-dominant   (tools/gpu_round_run.sh)"
+{ echo "# cd /tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dominant   (tools/gpu_round_run.sh; the driver's own --steps/--warmup, so the k sequence and launch mix are the benchmark's)"
   echo "# SD1.5 bs=2 512^2 rank-4 LECO step; summarised from the rocpd database with tools/rocpd_stats.py"
   echo "# csrc_sha1=$(cd $R && python -c 'import bench; print(bench.kernel_sources_hash())')"
   python $R/tools/rocpd_stats.py $DB 60; } > $O/${RN}_step_kernel_stats.txt 2>&1
@@ -32,8 +32,9 @@ python $R/tools/pmc_summary.py /tmp/pmc_mfma > $O/${RN}_pmc_mfma_step.csv 2>&1
 timeout 110 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d /tmp/pmc_fetch -o bench -- python $R/bench.py --steps 1 --warmup 0 --k 4 --no-cpu-baseline --no-graphs --no-dominant > /tmp/pmc2.log 2>&1
 python $R/tools/pmc_summary.py /tmp/pmc_fetch > $O/${RN}_pmc_fetch_step.csv 2>&1
 cd $R
-( timeout 900 python bench.py 2>/dev/null | tail -1 ) > $O/${RN}_bench.json
+( timeout 900 python bench.py --steps 20 --warmup 5 --dump-shapes $O/${RN}_dominant_shapes.txt 2>/dev/null | tail -1 ) > $O/${RN}_bench.json
 ( timeout 150 python tools/plan_profile.py --list denoise --top 45 2>/dev/null ) > $O/${RN}_plan_denoise.txt
+( timeout 150 python tools/plan_profile.py --list frozen --top 30 2>/dev/null ) > $O/${RN}_plan_frozen.txt
 ( timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ) > $O/${RN}_smoke.log 2>&1
 cut -c1-1800 $O/${RN}_bench.json; head -14 $O/${RN}_step_kernel_stats.txt; head -4 $O/${RN}_pmc_dominant_mfma.csv; head -4 $O/${RN}_pmc_dominant_fetch.csv; tail -3 /tmp/pmc_dm.log; cat $O/${RN}_smoke.log
 fi
