@@ -280,6 +280,268 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
 
 
 // ------------------------------------------------------------------------------------------
+// Self-attention forward with the K / V tiles brought in by LDS-DMA (round 4).  Same mapping and arithmetic as
+// attn_fwd_kernel<D, QF, false> (swapped products, one query row per lane, P in registers); what changes is the staging:
+// tools/ablate_attn.py measured the register-staged path (4 global loads + 4 ds_write_b128 per thread and tile, written
+// in the shadow of the PV MFMAs, one tile ahead) at 40 of 174 us on the level-0 problem.  Here
+//   * a tile is KS + VS wave-wide `buffer_load ... lds` pieces (KS / VS = 16-byte slots per K / V row), three per wave, into
+//     a 3-deep ring: the DMA of tile t + 2 is issued right behind the barrier that opens tile t, so a landing has two
+//     tiles of compute to hide under and the barrier never waits for memory;
+//   * the LDS image of a DMA is lane-linear, so the rows are DENSE: K row = KS slots (KS odd: the 16 rows of a fragment
+//     read start in 16 different bank groups), V row = VS slots (VS / 2 odd: the transpose reads of a half wave cover the
+//     64 banks once); slots past the head dim are out-of-range lanes of the descriptor (zeros, no traffic; the ring is
+//     also zeroed once);
+//   * K fragment reads beyond the head dim (d = 40: k-step 1, lane groups 1..3) re-read the row's last slot: Q is zero
+//     there, the product does not depend on it;
+//   * the softmax row sum comes from one extra MFMA per P operand against an all-ones fragment (the ones COLUMN of the
+//     register-staged kernel cannot be DMA'd);
+//   * every LDS read is inline asm (ds_read_b128 / ds_read_b64_tr_b16 with immediate offsets): with LDS-DMA in flight the
+//     compiler would otherwise drain vmcnt in front of each of them.
+// Requirements (else the register-staged kernel runs): skv % 64 == 0, sq % (64 QF) == 0.
+template <int D>
+struct AttnDmaCfg {
+    static constexpr int NDC = D / 8, KS = NDC | 1;
+    static constexpr int DV = (D + 15) / 16 * 16, VS0 = DV / 8, VS = ((VS0 / 2) % 2) ? VS0 : VS0 + 2;
+    static constexpr int KB = KT * KS * 16, VB = KT * VS * 16, TILE = KB + VB;
+    static constexpr int NP = KS + VS, PPW = (NP + 3) / 4;
+    static constexpr int NBUF = 3, OFF_DUMP = NBUF * TILE, LDS_BYTES = OFF_DUMP + 1024;
+};
+template <int D, int QF>
+__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OCC40 : 2) void attn_fwd_dma_kernel(AttnArgs p) {
+    using Cf = AttnDmaCfg<D>;
+    constexpr int DK = (D + 31) / 32 * 32, DV = Cf::DV;
+    constexpr int NKS = DK / 32, NFD = DV / 16, NDC = Cf::NDC, KS = Cf::KS, VS = Cf::VS, PPW = Cf::PPW;
+    constexpr int KB = Cf::KB, TILE = Cf::TILE;
+    unsigned char* lds = dyn_lds();
+
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int h = (int)blockIdx.y, b = (int)blockIdx.z;
+    const int q0 = (int)blockIdx.x * (64 * QF) + wave * (16 * QF);
+    const bf16_t* qb = p.q + (int64_t)b * p.bsq + (int64_t)h * D;
+    const bf16_t* kb = p.k + (int64_t)b * p.bsk + (int64_t)h * D;
+    const bf16_t* vb = p.v + (int64_t)b * p.bsv + (int64_t)h * D;
+
+    // zero the ring once (slots no DMA lane ever fills must not hold NaN patterns), then the Q fragments
+    for (int e = tid; e < Cf::LDS_BYTES / 16; e += 256) *(u32x4*)(lds + e * 16) = u32x4{0u, 0u, 0u, 0u};
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    bf16x8 qf[QF][NKS];
+#pragma unroll
+    for (int u = 0; u < QF; ++u) {
+        const int qrow = q0 + u * 16 + fr;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int ch = ks * 4 + fg;
+            u32x4 t = ch < NDC ? *(const u32x4*)(qb + (int64_t)qrow * p.ldq + ch * 8) : zero4;
+            qf[u][ks] = __builtin_bit_cast(bf16x8, t);
+        }
+    }
+    __syncthreads();
+
+    // ---- DMA pieces of this wave: piece j = wave * PPW + i; j < KS: K slots 64 j .. 64 j + 63, then the V pieces, then
+    // (to keep the per-wave count uniform) dummies that read nothing and land in a dump area
+    const buf_rsrc rk = make_rsrc(kb, (unsigned)((((int64_t)p.skv - 1) * p.ldk + D) * 2));
+    const buf_rsrc rv = make_rsrc(vb, (unsigned)((((int64_t)p.skv - 1) * p.ldv + D) * 2));
+    unsigned voff[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int j = wave * PPW + i;
+        if (j < KS) {
+            const int sl = j * 64 + lane, key = sl / KS, c = sl - key * KS;
+            voff[i] = c < NDC ? (unsigned)key * (unsigned)p.ldk * 2u + (unsigned)c * 16u : DMA_OOB;
+        } else if (j < KS + VS) {
+            const int sl = (j - KS) * 64 + lane, key = sl / VS, c = sl - key * VS;
+            voff[i] = c < NDC ? (unsigned)key * (unsigned)p.ldv * 2u + (unsigned)c * 16u : DMA_OOB;
+        } else {
+            voff[i] = DMA_OOB;
+        }
+    }
+    const int ntiles = p.skv / KT;
+    auto issue = [&](int tile, int buf) {
+        const unsigned dead = tile < ntiles ? 0u : DMA_OOB;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int j = wave * PPW + i;
+            const bool isk = j < KS, isv = !isk && j < KS + VS;
+            const unsigned soff = (unsigned)tile * (unsigned)KT * (unsigned)(isk ? p.ldk : p.ldv) * 2u;
+            unsigned char* dst = isk ? lds + buf * TILE + j * 1024 : (isv ? lds + buf * TILE + KB + (j - KS) * 1024 : lds + Cf::OFF_DUMP);
+            glds16_buf(isk ? rk : rv, voff[i] | dead, tile < ntiles ? soff : 0u, dst);
+        }
+    };
+
+    f32x4 acc_o[QF][NFD], acc_l[QF];
+    float m_run[QF];
+#pragma unroll
+    for (int u = 0; u < QF; ++u) {
+        m_run[u] = -INFINITY;
+        acc_l[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd) acc_o[u][fd] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const u32x4 ones4 = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, ones4);
+
+    // lane parts of the fragment addresses (bytes inside a tile buffer)
+    const unsigned ka[NKS == 1 ? 1 : 2] = {(unsigned)(fr * KS * 16 + (fg < NDC ? fg : NDC - 1) * 16),
+                                           (unsigned)(fr * KS * 16 + (4 + fg < NDC ? 4 + fg : NDC - 1) * 16)};
+    const unsigned va = (unsigned)(KB + ((4 * fg + (fr >> 2)) * VS * 16) + 8 * (fr & 3));
+    static_assert(NKS <= 2 || D > 64, "ka[] covers two k-steps; larger head dims compute the slot per k-step");
+
+    issue(0, 0);
+    issue(1, 1);
+    int cur = 0;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        wait_vmcnt<PPW>();            // this wave's pieces of `tile` have landed (the PPW of tile + 1 may be in flight)
+        barrier_keep_dma();           // ... every wave's; and every wave is done with tile - 1, whose buffer is refilled now
+        issue(tile + 2, cur == 0 ? 2 : cur - 1);
+        const unsigned base = lds_addr(lds) + (unsigned)(cur * TILE);
+
+        // S^T = K Q^T : lane holds S[q = fr][key = 16 f + 4 fg + r]
+        f32x4 acc_s[QF][4];
+        bf16x8 kf[4][NKS];
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                const unsigned a = base + (ks == 0 ? ka[0] : (NKS <= 2 ? ka[NKS == 1 ? 0 : 1]
+                                                                       : (unsigned)(fr * KS * 16 + (ks * 4 + fg < NDC ? ks * 4 + fg : NDC - 1) * 16)));
+                switch (f) {
+                    case 0: kf[f][ks] = lds_read16_at<0 * 16 * KS * 16>(a); break;
+                    case 1: kf[f][ks] = lds_read16_at<1 * 16 * KS * 16>(a); break;
+                    case 2: kf[f][ks] = lds_read16_at<2 * 16 * KS * 16>(a); break;
+                    default: kf[f][ks] = lds_read16_at<3 * 16 * KS * 16>(a); break;
+                }
+            }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            if (f == 0) lds_wait<3 * NKS>();
+            else if (f == 1) lds_wait<2 * NKS>();
+            else if (f == 2) lds_wait<1 * NKS>();
+            else lds_wait<0>();
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) lds_tie(kf[f][ks]);
+#pragma unroll
+            for (int u = 0; u < QF; ++u) {
+                f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) a = mfma16(kf[f][ks], qf[u][ks], a);
+                acc_s[u][f] = a;
+            }
+        }
+
+        // online softmax per owned query row on the RAW scores; P^T operand built in registers.  DEFERRED maximum: the
+        // reference point m of a row only has to keep exp2(s - m) in range, it need not be the maximum -- while no row of
+        // the wave outgrew its m by more than 2^8 the old m stays (P <= 256: exact in the fp32 / bf16 exponent range, the
+        // softmax is invariant to m), and the alpha exponentials and the rescale of O and l are skipped.  On the first
+        // tile m = -inf forces the update.
+        u32x4 pw[QF][2];
+        float m_new[QF];
+        bool grow = false;
+#pragma unroll
+        for (int u = 0; u < QF; ++u) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc_s[u][f][r]);
+            mx = fmaxf(mx, shfl_xor(mx, 16));
+            mx = fmaxf(mx, shfl_xor(mx, 32));
+            m_new[u] = fmaxf(m_run[u], mx * p.scale_log2);
+            grow |= !(m_new[u] - m_run[u] <= 8.f);
+        }
+        if (wave_any(grow)) {
+#pragma unroll
+            for (int u = 0; u < QF; ++u) {
+                const float alpha = fast_exp2(m_run[u] - m_new[u]);
+                m_run[u] = m_new[u];
+                acc_l[u][0] *= alpha;
+#pragma unroll
+                for (int fd = 0; fd < NFD; ++fd) {
+                    acc_o[u][fd][0] *= alpha; acc_o[u][fd][1] *= alpha;
+                    acc_o[u][fd][2] *= alpha; acc_o[u][fd][3] *= alpha;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < QF; ++u) {
+            const f32x2 sc2 = {p.scale_log2, p.scale_log2}, nm2 = {-m_run[u], -m_run[u]};
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const f32x2 t01 = pk_fma(f32x2{acc_s[u][f][0], acc_s[u][f][1]}, sc2, nm2);
+                const f32x2 t23 = pk_fma(f32x2{acc_s[u][f][2], acc_s[u][f][3]}, sc2, nm2);
+                pw[u][f >> 1][(f & 1) * 2] = pack_bf2(fast_exp2(t01[0]), fast_exp2(t01[1]));
+                pw[u][f >> 1][(f & 1) * 2 + 1] = pack_bf2(fast_exp2(t23[0]), fast_exp2(t23[1]));
+            }
+        }
+
+        // O^T += V^T P^T (transpose reads: 16-lane group fg gathers keys 16 (2 s + hh) + 4 fg .. + 3 of columns 16 fd ..),
+        // l += 1^T P^T
+        const unsigned vbase = base + va;
+        u32x2 vt[NFD][4];
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd) {
+            auto rd = [&](auto fd_c) {
+                constexpr int F = decltype(fd_c)::value;
+                vt[F][0] = lds_read_tr16_at<(0 * 16) * VS * 16 + 32 * F>(vbase);
+                vt[F][1] = lds_read_tr16_at<(1 * 16) * VS * 16 + 32 * F>(vbase);
+                vt[F][2] = lds_read_tr16_at<(2 * 16) * VS * 16 + 32 * F>(vbase);
+                vt[F][3] = lds_read_tr16_at<(3 * 16) * VS * 16 + 32 * F>(vbase);
+            };
+            if (fd == 0) rd(std::integral_constant<int, 0>{});
+            if (fd == 1) rd(std::integral_constant<int, 1 < NFD ? 1 : 0>{});
+            if (fd == 2) rd(std::integral_constant<int, 2 < NFD ? 2 : 0>{});
+            if (fd == 3) rd(std::integral_constant<int, 3 < NFD ? 3 : 0>{});
+            if (fd == 4) rd(std::integral_constant<int, 4 < NFD ? 4 : 0>{});
+            if (fd >= 5) rd(std::integral_constant<int, (5 < NFD ? 5 : 0)>{});
+        }
+        static_assert(NFD <= 6, "transpose-read dispatch covers 6 column fragments");
+#pragma unroll
+        for (int u = 0; u < QF; ++u) {
+            acc_l[u] = mfma16(ones, __builtin_bit_cast(bf16x8, pw[u][0]), acc_l[u]);
+            acc_l[u] = mfma16(ones, __builtin_bit_cast(bf16x8, pw[u][1]), acc_l[u]);
+        }
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd) {
+            if (fd == 0) lds_wait<4 * (NFD - 1) < 16 ? 4 * (NFD - 1) : 15>();
+            else if (fd == NFD - 1) lds_wait<0>();
+            else if (fd == 1) lds_wait<4 * (NFD - 2) < 16 ? 4 * (NFD - 2) : 15>();
+            else lds_wait<0>();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) lds_tie2(vt[fd][q]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const u32x4 t = {vt[fd][2 * s2][0], vt[fd][2 * s2][1], vt[fd][2 * s2 + 1][0], vt[fd][2 * s2 + 1][1]};
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, t);
+#pragma unroll
+                for (int u = 0; u < QF; ++u) acc_o[u][fd] = mfma16(vf, __builtin_bit_cast(bf16x8, pw[u][s2]), acc_o[u][fd]);
+            }
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+    wait_vmcnt<0>();                  // the out-of-range pieces issued past the last tile
+
+    bf16_t* ob = p.o + (int64_t)b * p.bso + (int64_t)h * D;
+#pragma unroll
+    for (int u = 0; u < QF; ++u) {
+        const float l = acc_l[u][0];
+        const float inv = 1.f / l;
+        const int qrow = q0 + u * 16 + fr;
+#pragma unroll
+        for (int fd = 0; fd < NFD; ++fd) {
+            const int d = 16 * fd + 4 * fg;
+            if (d < D) {
+                f32x4 o = acc_o[u][fd];
+                u32x2 w = {pack_bf2(o[0] * inv, o[1] * inv), pack_bf2(o[2] * inv, o[3] * inv)};
+                *(u32x2*)(ob + (int64_t)qrow * p.ldo + d) = w;
+            }
+        }
+        if (fg == 0 && p.lse)
+            p.lse[((int64_t)b * p.heads + h) * p.sq + qrow] = (m_run[u] + log2f(l)) * 0.6931471805599453f;
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
 // Backward (once per optimizer step, for the LoRA-on "target" pass only).  P is recomputed
 // from the saved LSE; no atomics, deterministic:
 //   attn_delta : delta[q] = sum_d dO[q][d] O[q][d]
@@ -573,6 +835,17 @@ int launch_fwd(const AttnArgs& a, int batch, hipStream_t s) {
     // there are still >= 4 workgroups per CU (measured: 4x8x4096^2x40 218 vs 238 us, 4x8x1024^2x80 35.8 vs 31.8 us)
     const long wgs2 = (long)cdiv(a.sq, 128) * a.heads * batch;
     const bool masked = a.skv % KT != 0;
+    // large self-attention problems at d = 40 (SD1.x level 0): the LDS-DMA staged kernel (LECO_ATTN_DMA=0: off)
+    // (=2: also for small grids -- the kernel tests)
+    const char* dma_env = getenv("LECO_ATTN_DMA");             // (read per launch: launches are recorded into graphs once)
+    const int use_dma = dma_env ? atoi(dma_env) : 1;
+    if constexpr (D == 40) {
+        if (use_dma && !masked && a.sq % 128 == 0 && (wgs2 >= 512 || use_dma == 2) && (force_qf == 0 || force_qf == 2) &&
+            ((int64_t)a.skv * a.ldk * 2 < (1ll << 31)) && ((int64_t)a.skv * a.ldv * 2 < (1ll << 31))) {
+            hipLaunchKernelGGL((attn_fwd_dma_kernel<D, 2>), dim3(a.sq / 128, a.heads, batch), dim3(256), AttnDmaCfg<D>::LDS_BYTES, s, a);
+            return check_launch("leco_attention_fwd");
+        }
+    }
     if (force_qf ? force_qf == 2 : wgs2 >= 1024) {
         const dim3 grid(cdiv(a.sq, 128), a.heads, batch);
         if (masked) hipLaunchKernelGGL((attn_fwd_kernel<D, 2, true>), grid, dim3(256), 0, s, a);

@@ -191,6 +191,139 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const bf16_t* x, const bf
     }
 }
 
+// ---- conv_in / conv_out on the matrix cores (round 4) ---------------------------------------------------------------
+// The two kernels above re-read their weights once per output element (conv_in: 72 16-byte loads per 8 outputs; conv_out:
+// the whole 23 KB weight set per pixel) and cost 28 us each per UNet pass -- as much as a level-0 3x3 convolution with 80x
+// the work.  Both are tiny GEMMs:
+//   conv_in : [pixels][Cin * 9 (<= 64)] x [Cin * 9][Cout]   -- weights stationary in REGISTERS (fp32 split into bf16 hi + lo:
+//             the result keeps the fp32-weight accuracy of the scalar kernel), a wave owns up to 5 fragments of 16 output
+//             channels, the activation fragment is gathered from the NCHW input;
+//   conv_out: [pixels][9 C] x [9 C][4 (one 16-row fragment, rows >= 4 zero)] -- K split over the 4 waves of a workgroup,
+//             activation and weight fragments straight from global / L2, partial sums meet in LDS.
+// mfma16(W, X, acc): lane (fr, fg) receives rows n = 4 fg + r of column (pixel) fr.
+constexpr int CIN_FPW = 5;     // output fragments per wave (Cout <= 4 * 5 * 16)
+__global__ __launch_bounds__(256) void conv_in_mfma_kernel(const bf16_t* x, const float* w, const float* bias, bf16_t* y, int B,
+                                                            int H, int W, int Cin, int Cout, int groups_per_block) {
+    const int lane = lane_id(), wave = (int)(threadIdx.x >> 6), fr = lane & 15, fg = lane >> 4;
+    const int nf = Cout / 16, fpw = (nf + 3) / 4, f0 = wave * fpw, f1 = min(nf, f0 + fpw);
+    const int K = Cin * 9;
+    if (f0 >= f1) return;
+    // weight fragments: k = 32 ks + 8 fg + i, row n = 16 f + fr
+    bf16x8 whi[CIN_FPW][2], wlo[CIN_FPW][2];
+    f32x4 bia[CIN_FPW];
+#pragma unroll
+    for (int q = 0; q < CIN_FPW; ++q) {
+        const int f = f0 + q;
+        const bool live = f < f1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                const int k = 32 * ks + 8 * fg + i;
+                const float a = (live && k < K) ? w[(int64_t)k * Cout + 16 * f + fr] : 0.f;
+                const float b = (live && k + 1 < K) ? w[(int64_t)(k + 1) * Cout + 16 * f + fr] : 0.f;
+                const unsigned h2 = pack_bf2(a, b);
+                hi[i >> 1] = h2;
+                lo[i >> 1] = pack_bf2(a - bf2f((bf16_t)(h2 & 0xffffu)), b - bf2f((bf16_t)(h2 >> 16)));
+            }
+            whi[q][ks] = __builtin_bit_cast(bf16x8, hi);
+            wlo[q][ks] = __builtin_bit_cast(bf16x8, lo);
+        }
+        bia[q] = live ? *(const f32x4*)(bias + 16 * f + 4 * fg) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int npix = B * H * W;                  // (host: < 2^31; 32-bit divisions only -- a 64-bit one is ~200 instructions)
+    for (int g = 0; g < groups_per_block; ++g) {
+        const int pix = ((int)blockIdx.x * groups_per_block + g) * 16 + fr;
+        if (((int)blockIdx.x * groups_per_block + g) * 16 >= npix) break;
+        const bool pv = pix < npix;
+        const unsigned pp = pv ? (unsigned)pix : 0u;
+        const unsigned row = pp / (unsigned)W;
+        const int px = (int)(pp - row * (unsigned)W), b = (int)(row / (unsigned)H), py = (int)(row - (unsigned)b * (unsigned)H);
+        bf16x8 xf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 t = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = 32 * ks + 8 * fg + i;
+                const int c = k / 9, tap = k - 9 * c;
+                const int iy = py + tap / 3 - 1, ix = px + tap % 3 - 1;
+                unsigned v = 0u;
+                if (pv && k < K && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((int64_t)(b * Cin + c) * H + iy) * W + ix];
+                t[i >> 1] |= v << ((i & 1) * 16);
+            }
+            xf[ks] = __builtin_bit_cast(bf16x8, t);
+        }
+#pragma unroll
+        for (int q = 0; q < CIN_FPW; ++q) {
+            const int f = f0 + q;
+            if (f >= f1) break;
+            f32x4 acc = bia[q];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                acc = mfma16(whi[q][ks], xf[ks], acc);
+                acc = mfma16(wlo[q][ks], xf[ks], acc);
+            }
+            if (pv) {
+                const u32x2 o = {pack_bf2(acc[0], acc[1]), pack_bf2(acc[2], acc[3])};
+                *(u32x2*)(y + (int64_t)pix * Cout + 16 * f + 4 * fg) = o;
+            }
+        }
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_out_mfma_kernel(const bf16_t* x, const bf16_t* w, const float* bias, float* y, int B,
+                                                             int H, int W, int C) {
+    __shared__ f32x4 red[4][64];
+    const int lane = lane_id(), wave = uniform((int)(threadIdx.x >> 6)), fr = lane & 15, fg = lane >> 4;
+    const int npix = B * H * W, pix = (int)blockIdx.x * 16 + fr;       // (host: < 2^31; 32-bit divisions only)
+    const bool pv = pix < npix;
+    const unsigned pp = pv ? (unsigned)pix : 0u;
+    const unsigned row = pp / (unsigned)W;
+    const int px = (int)(pp - row * (unsigned)W), b = (int)(row / (unsigned)H), py = (int)(row - (unsigned)b * (unsigned)H);
+    const int nkc = C / 32;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    // k-steps are handed out in UNITS of (channel block, kernel row): the three horizontal taps of a unit read the same
+    // cache lines, and the three kernel rows of a channel block are in flight on the workgroup's waves together -- the input
+    // is fetched from L2 ~once instead of once per tap (9x: 94 MB per launch at level 0, the bound of the first version)
+    constexpr int UU = 4;                                  // units (x 3 taps) in flight per wave
+    const int nunits = 3 * nkc;
+    for (int u0 = wave; u0 < nunits; u0 += 4 * UU) {
+        u32x4 xv[UU][3], wv[UU][3];
+#pragma unroll
+        for (int uu = 0; uu < UU; ++uu) {
+            const int unit = u0 + 4 * uu;
+            const int cb = unit / 3, ky = unit - 3 * cb;
+            const int iy = py + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = px + kx - 1;
+                const bool ok = unit < nunits && pv && iy >= 0 && iy < H && ix >= 0 && ix < W;
+                xv[uu][kx] = ok ? *(const u32x4*)(x + ((int64_t)(b * H + iy) * W + ix) * C + cb * 32 + fg * 8) : z;
+                wv[uu][kx] = (unit < nunits && fr < COUT) ? *(const u32x4*)(w + (int64_t)(fr * 9 + ky * 3 + kx) * C + cb * 32 + fg * 8) : z;
+            }
+        }
+#pragma unroll
+        for (int uu = 0; uu < UU; ++uu)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                acc = mfma16(__builtin_bit_cast(bf16x8, wv[uu][kx]), __builtin_bit_cast(bf16x8, xv[uu][kx]), acc);
+    }
+    red[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && 4 * fg < COUT && pv) {
+        const f32x4 a0 = red[0][lane], a1 = red[1][lane], a2 = red[2][lane], a3 = red[3][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 4 * fg + r;
+            if (n < COUT) y[((int64_t)(b * COUT + n) * H + py) * W + px] = (a0[r] + a1[r]) + (a2[r] + a3[r]) + bias[n];
+        }
+    }
+}
+
 // dgrad of conv_out: dx[pix][c] = sum_{tap,o} dy[b][o][pix - off(tap)] * w[o][tap][c]
 template <int COUT>
 __global__ __launch_bounds__(256) void conv_out_bwd_kernel(const float* dy, const bf16_t* w, bf16_t* dx, int B,
@@ -628,6 +761,13 @@ extern "C" int leco_upsample2x_bwd(const void* dy, void* dx, int32_t batch, int3
 extern "C" int leco_conv_in(const void* x, const float* w, const float* bias, void* y, int32_t batch, int32_t h,
                             int32_t wd, int32_t cin, int32_t cout, leco_stream_t stream) {
     if (cout % 8) return fail(-EINVAL, "conv_in: Cout=%d %% 8 != 0", cout);
+    if (cout % 16 == 0 && cout <= 64 * CIN_FPW && cin * 9 <= 64 && (int64_t)batch * h * wd < (1ll << 30)) {
+        const int64_t groups = ((int64_t)batch * h * wd + 15) / 16;
+        const int gpb = groups >= 2048 ? 4 : (groups >= 512 ? 2 : 1);       // >= 256 workgroups where the problem has them
+        hipLaunchKernelGGL(conv_in_mfma_kernel, dim3((unsigned)((groups + gpb - 1) / gpb)), dim3(256), 0, LECO_STREAM,
+                           (const bf16_t*)x, w, bias, (bf16_t*)y, batch, h, wd, cin, cout, gpb);
+        return check_launch("leco_conv_in");
+    }
     hipLaunchKernelGGL(conv_in_kernel, dim3(grid_for((int64_t)batch * h * wd * cout / 8)), dim3(256), 0, LECO_STREAM,
                        (const bf16_t*)x, w, bias, (bf16_t*)y, batch, h, wd, cin, cout);
     return check_launch("leco_conv_in");
@@ -636,6 +776,11 @@ extern "C" int leco_conv_out(const void* x, const void* w, const float* bias, fl
                              int32_t wd, int32_t c, int32_t cout, leco_stream_t stream) {
     if (cout != 4 || c % 8) return fail(-EINVAL, "conv_out: needs Cout=4 (got %d), C %% 8 == 0", cout);
     const int64_t npix = (int64_t)batch * h * wd;
+    if (c % 32 == 0 && npix < (1ll << 30)) {
+        hipLaunchKernelGGL((conv_out_mfma_kernel<4>), dim3((unsigned)((npix + 15) / 16)), dim3(256), 0, LECO_STREAM,
+                           (const bf16_t*)x, (const bf16_t*)w, bias, y, batch, h, wd, c);
+        return check_launch("leco_conv_out");
+    }
     hipLaunchKernelGGL((conv_out_kernel<4>), dim3((unsigned)((npix + 3) / 4)), dim3(256), 0, LECO_STREAM,
                        (const bf16_t*)x, (const bf16_t*)w, bias, y, batch, h, wd, c);
     return check_launch("leco_conv_out");

@@ -13,6 +13,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 hw_bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
@@ -124,6 +125,16 @@ __device__ __forceinline__ u32x2 lds_read_tr16(const void* lds_ptr) {
     const s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s4*)lds_ptr);
     return __builtin_bit_cast(u32x2, v);
 }
+// The transpose read through inline asm, by LDS byte address + compile-time displacement: not tracked by the compiler's
+// s_waitcnt insertion (see lds_read16_async) -- complete with lds_wait<N>() + lds_tie2().
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr16_at(unsigned addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds offset field is 16 bits");
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_tie2(u32x2& v) { asm volatile("" : "+v"(v)); }
 // wait until at most N LDS (lgkm) operations of this wave are outstanding
 template <int N>
 __device__ __forceinline__ void lds_wait() {
@@ -156,6 +167,9 @@ __device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) { return __umu
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+// two fp32 fused multiply-adds in one instruction (v_pk_fma_f32); true when the predicate holds in any lane of the wave
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 }  // namespace leco

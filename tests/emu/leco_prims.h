@@ -11,6 +11,7 @@ typedef short bf16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 static inline float __uint_as_float_emu(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
 static inline unsigned __float_as_uint_emu(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
@@ -146,6 +147,9 @@ static inline u32x2 lds_read_tr16(const void* lds_ptr) {
     r[1] = (unsigned)out[2] | ((unsigned)out[3] << 16);
     return r;
 }
+template <int OFF>
+static inline u32x2 lds_read_tr16_at(unsigned addr) { return lds_read_tr16(dyn_lds() + addr + OFF); }
+static inline void lds_tie2(u32x2&) {}
 template <int N>
 static inline void lds_wait() {}
 static inline void lds_tie(bf16x8&) {}
@@ -161,6 +165,14 @@ static inline unsigned char* dyn_lds() {
 static inline int uniform(int v) { return v; }
 static inline unsigned mul24(unsigned a, unsigned b) { return (a & 0xffffffu) * (b & 0xffffffu); }
 static inline int lane_id() { return emu::lane(); }
+static inline f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a[0], b[0], c[0]), fmaf(a[1], b[1], c[1])}; }
+static inline bool wave_any(bool pred) {
+    const int v = pred ? 1 : 0;
+    const unsigned char* all = emu::wave_gather(&v, 4);
+    int any = 0;
+    for (int l = 0; l < 64; ++l) { int t; memcpy(&t, all + (size_t)l * emu::kSlot, 4); any |= t; }
+    return any != 0;
+}
 static inline float shfl_xor(float v, int mask) {
     const unsigned char* all = emu::wave_gather(&v, 4);
     float r;

@@ -478,6 +478,40 @@ def test_attention_fwd_bwd(dev, B, H, Sq, Skv, D):
     assert rel_err(dv.cpu(), vv.grad) < 4e-3
 
 
+@pytest.mark.parametrize("B,H,S,fused,gain", [(1, 2, 256, False, 1.0), (2, 1, 384, True, 1.0), (1, 1, 128, True, 1.0),
+                                              (1, 1, 512, False, 3.0)])     # scores x 9: the deferred maximum has to move mid-way
+def test_attention_dma_staged_forward(dev, monkeypatch, B, H, S, fused, gain):
+    """attn_fwd_dma_kernel (d = 40 self-attention with the K / V tiles brought in by LDS-DMA into a 3-deep ring; the
+    planner's level-0 shapes take it by default, LECO_ATTN_DMA=2 forces it for small grids) against fp32 torch and against
+    the register-staged kernel (LECO_ATTN_DMA=0); 2 / 4 / 6 key tiles: prologue only, one ring wrap, two ring wraps; separate
+    and q|k|v-fused layouts.  tests/test_host.py re-runs this under the emulator's late-DMA model."""
+    torch.manual_seed(S + H)
+    D = 40
+    C = H * D
+    if fused:
+        qkv = (torch.randn(B, S, 3 * C) * gain).to(bf).to(dev)
+        ptrs = (qkv.data_ptr(), qkv.data_ptr() + 2 * C, qkv.data_ptr() + 4 * C)
+        ld, bs = 3 * C, S * 3 * C
+        q, k, v = [t.float().cpu() for t in qkv.chunk(3, -1)]
+    else:
+        qs = [(torch.randn(B, S, C) * gain).to(bf).to(dev) for _ in range(3)]
+        ptrs, ld, bs = tuple(t.data_ptr() for t in qs), C, S * C
+        q, k, v = [t.float().cpu() for t in qs]
+    outs = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("LECO_ATTN_DMA", mode)
+        o = torch.zeros(B, S, C, dtype=bf, device=dev); lse = torch.zeros(B, H, S, device=dev)
+        ops.attention_fwd(ptrs[0], ld, bs, ptrs[1], ld, bs, ptrs[2], ld, bs, o.data_ptr(), C, S * C, lse, B, H, S, S, D, D ** -0.5).run()
+        _sync(dev)
+        outs[mode] = (o.cpu(), lse.cpu())
+    qh, kh, vh = [t.reshape(B, S, H, D).transpose(1, 2) for t in (q, k, v)]
+    sc = qh @ kh.transpose(-1, -2) * D ** -0.5
+    ref = (torch.softmax(sc, -1) @ vh).transpose(1, 2).reshape(B, S, C)
+    assert rel_err(outs["2"][0], ref) < TOLBF and rel_err(outs["2"][1], torch.logsumexp(sc, -1)) < 2e-4
+    # (different reference maxima -> different bf16 roundings of P: the two kernels agree to the rounding, not bit for bit)
+    assert rel_err(outs["2"][0], outs["0"][0]) < 4e-3 and rel_err(outs["2"][1], outs["0"][1]) < 1e-4
+
+
 def test_attention_strided_fused_qkv(dev):
     """q|k|v packed in one [B][S][3C] buffer (how the UNet engine lays them out)."""
     torch.manual_seed(6)
@@ -523,16 +557,21 @@ def test_elementwise_family(dev):
     assert rel_err(dx.cpu().permute(0, 3, 1, 2), xx.grad) < TOLBF
 
 
-def test_conv_in_out(dev):
+@pytest.mark.parametrize("B,H,W,Co,C", [(2, 6, 7, 64, 128),     # one output fragment per wave; ragged last pixel group
+                                        (1, 16, 20, 320, 320),   # SD level-0 widths: 5 fragments per wave, 90 k-steps over 4 waves
+                                        (3, 5, 5, 48, 96),       # 3 fragments: an idle wave; 27 k-steps
+                                        (2, 4, 4, 24, 72)])      # widths the MFMA forms do not take: the scalar kernels
+def test_conv_in_out(dev, B, H, W, Co, C):
+    """leco_conv_in (NCHW bf16 -> channels-last, fp32 weights) and leco_conv_out (channels-last -> NCHW fp32) against
+    F.conv2d; both run on the matrix cores where the widths allow (hi + lo split of the fp32 conv_in weights)."""
     torch.manual_seed(8)
-    B, H, W, Ci, Co = 2, 6, 7, 4, 64
+    Ci = 4
     x = torch.randn(B, Ci, H, W).to(bf).to(dev); w = (torch.randn(Co, Ci, 3, 3) * 0.2).to(dev); bias = torch.randn(Co).to(dev)
     y = torch.zeros(B, H, W, Co, dtype=bf, device=dev)
     wt_in = w.permute(1, 2, 3, 0).contiguous()
     ops.conv_in(x, wt_in, bias, y, B, H, W, Ci, Co).run()
     _sync(dev)
     assert rel_err(y.cpu().permute(0, 3, 1, 2), F.conv2d(x.float().cpu(), w.cpu(), bias.cpu(), padding=1)) < TOLBF
-    C = 128
     xh = torch.randn(B, H, W, C).to(bf).to(dev); w4 = (torch.randn(4, C, 3, 3) * 0.05).to(bf); b4 = torch.randn(4).to(dev)
     wl = w4.permute(0, 2, 3, 1).contiguous().to(dev); yo = torch.zeros(B, 4, H, W, device=dev)
     ops.conv_out(xh, wl, b4, yo, B, H, W, C, 4).run()

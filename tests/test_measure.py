@@ -63,7 +63,7 @@ def test_tuner_keys_candidates_and_table():
 def test_bench_attributes_launches_to_kernel_trace_rows(tmp_path, monkeypatch):
     import bench
     top = bench._profile_top_row()
-    assert top and top["name"].startswith("gemm_kernel<") and top["share_pct"] > 5
+    assert top and top["name"].startswith(("gemm_kernel<", "conv_patch_kernel<")) and top["share_pct"] > 5
     # counter summaries: kernel names contain commas; the row is found by its full name
     row = bench._pmc_row(bench.PMC_MFMA, top["name"])
     assert row and row["calls"] > 0 and 0.05 < row["SQ_VALU_MFMA_BUSY_CYCLES"] / (row["GRBM_GUI_ACTIVE"] / 8 * 1024) < 1

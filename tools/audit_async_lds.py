@@ -123,7 +123,7 @@ def audit_function(name, body):
         st = list(state_in[i])
         for kind, s in blocks[i][1]:
             op = s.split()[0]
-            if kind == "asm" and op == "ds_read_b128":
+            if kind == "asm" and op in ("ds_read_b128", "ds_read_b64_tr_b16"):
                 dst = s.split(None, 1)[1].split(",")[0]
                 st.append(frozenset(vregs(dst)))
                 continue
@@ -149,7 +149,7 @@ def audit_function(name, body):
             if new != state_in[j]:
                 state_in[j] = new
                 work.append(j)
-    n_reads = sum(1 for _, ins in blocks for k, s in ins if k == "asm" and s.startswith("ds_read_b128"))
+    n_reads = sum(1 for _, ins in blocks for k, s in ins if k == "asm" and s.startswith(("ds_read_b128", "ds_read_b64_tr_b16")))
     return n_reads, violations
 
 
@@ -174,7 +174,7 @@ def pretty(mangled):
 
 def main(argv):
     srcs = argv or [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))
-                    if f.endswith(".hip") and "lds_read16_async" in open(os.path.join(CSRC, f)).read()]
+                    if f.endswith(".hip") and re.search(r"lds_read16_async|lds_read16_at|lds_read_tr16_at", open(os.path.join(CSRC, f)).read())]
     bad = 0
     for src in srcs:
         for name, n_reads, viol in audit_source(src):
