@@ -185,7 +185,7 @@ def _launch_identity(op):
 def step_launches(st, k_mean):
     """[(op, launches per step)] of one reference-faithful step with k_mean denoising passes."""
     out = []
-    skip = ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step")      # mutate the step state; negligible time
+    skip = ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step", "leco_fork", "leco_join")      # step state / stream edges; negligible time
     for plan, which, w in ((st["dplan"], "ctx_on", 1.0), (st["dplan"], "denoise", float(k_mean)), (st["fplan"], "fwd_off", 1.0),
                            (st["plan"], "fwd_on", 1.0), (st["plan"], "bwd", 1.0)):
         out += [(op, w) for op in plan.lists[which] if op.name not in skip]

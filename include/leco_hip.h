@@ -395,6 +395,19 @@ int leco_graph_end_capture(leco_stream_t stream, leco_graph_t* out);
 int leco_graph_launch(leco_graph_t graph, leco_stream_t stream);
 int leco_graph_destroy(leco_graph_t graph);
 
+/* ------------------------------------------------------------------------
+ * Two-stream sections of a launch list (round 4).  The reference runs every op of a UNet pass serially on one stream
+ * (train_util.py:156-160); a few of them are independent of their neighbours -- ResnetBlock2D.conv_shortcut reads the
+ * block's INPUT and is only needed by conv2's residual add, so it can run beside norm1 -> conv1 -> norm2, whose
+ * GroupNorm launches leave most of the chip idle.  leco_fork makes the library's side stream (one per device, created on
+ * first use) wait for everything enqueued on `stream` so far; launches handed leco_side_stream() then run concurrently
+ * with `stream`; leco_join makes `stream` wait for them.  Inside a stream capture the fork / join become graph edges.
+ * A forked launch must not share mutable scratch (split-K workspace) with the launches it runs beside.
+ * ---------------------------------------------------------------------- */
+int leco_fork(leco_stream_t stream);
+int leco_join(leco_stream_t stream);
+leco_stream_t leco_side_stream(void);
+
 /* ---- fp32 compute mode (`train.precision: float32`, config_util.py:75-83; csrc/f32.hip) --------------------------------
  * One twin per entry point above that touches activations: SAME argument list and meaning, but every tensor the bf16
  * entry point takes as bf16 (activations, packed weights, LoRA operand images) is fp32 here, strides still in elements.

@@ -46,6 +46,7 @@ _SIGS = {
     "leco_cast_f32_bf16": [_vp, _vp, _i64, _vp],
     "leco_memset": [_vp, _i32, _i64, _vp],
     "leco_repeat": [_vp, _vp, _i64, _i32, _vp],
+    "leco_fork": [_vp], "leco_join": [_vp],
     "leco_lora_pack": [_vp, _i32, _vp],
     "leco_lora_wgrad_conv": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32,
                              _i32, _i32, _vp, _i64, _vp],
@@ -105,12 +106,25 @@ def _fn(name: str):
     return f
 
 
+_STREAM_OPS = ("leco_fork", "leco_join")     # two-stream sections of a launch list (leco_hip.h); no-ops on the host emulator
+
+
+def _noop(*_a):
+    return 0
+
+
 class Op:
-    """One enqueue-only C-ABI call: ``fn(*args, stream)``."""
-    __slots__ = ("name", "fn", "args", "keep", "tag")
+    """One enqueue-only C-ABI call: ``fn(*args, stream)``.  ``side``: the launch belongs to a forked section (between a
+    ``leco_fork`` and a ``leco_join`` op of the list) and is handed the library's side stream instead of ``stream``."""
+    __slots__ = ("name", "fn", "args", "keep", "tag", "side")
 
     def __init__(self, name: str, args: tuple, keep=None):
         self.tag = None   # plan builders label ops (e.g. "ctx": depends only on the prompt embeddings)
+        self.side = False
+        if name in _STREAM_OPS:
+            self.name, self.args, self.keep = name, args, keep
+            self.fn = _noop if hip.is_emulated() else _fn(name)
+            return
         if _f32_active:
             if name in _F32_TWINS:
                 name = "leco_f32_" + name[len("leco_"):]
@@ -136,11 +150,29 @@ def default_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def side_stream():
+    """Handle of the library's side stream (None on the host emulator: forked launches then run in list order)."""
+    if hip.is_emulated() or not torch.cuda.is_available():
+        return None
+    f = hip.lib().leco_side_stream
+    f.restype = C.c_void_p
+    f.argtypes = []
+    return f()
+
+
 def run_plan(plan: Sequence[Op], stream=None) -> None:
     if stream is None:
         stream = default_stream()
+    side = None
     for op in plan:
-        rc = op.fn(*op.args, stream)
+        s = stream
+        if op.side and stream is not None:
+            if side is None:
+                side = side_stream()
+            s = side
+        elif stream is None and op.name in _STREAM_OPS:
+            continue
+        rc = op.fn(*op.args, s)
         if rc != 0:
             hip.check(rc, op.name)
 

@@ -23,6 +23,7 @@ HIP kernels in ``libleco_hip.so``:
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import math
 from dataclasses import dataclass
@@ -532,7 +533,8 @@ class Engine:
             key = key + ("share", share)
         if key not in self.plans:
             with ops.f32_mode(self.f32):
-                self.plans[key] = PlanBuilder(self, B, h, w, need_bwd, ws=self.workspace_slot(ws_slot), share=share).build()
+                self.plans[key] = PlanBuilder(self, B, h, w, need_bwd, ws=self.workspace_slot(ws_slot), share=share,
+                                              ws_side=self.workspace_slot(ws_slot + 2)).build()
         return self.plans[key]
 
     def workspace_slot(self, slot: int) -> torch.Tensor:
@@ -568,9 +570,10 @@ class Engine:
 
 class PlanBuilder:
     def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True, ws: Optional[torch.Tensor] = None,
-                 share: int = 1):
+                 share: int = 1, ws_side: Optional[torch.Tensor] = None):
         self.eng, self.cfg, self.dev = eng, eng.cfg, eng.device
         self.share = share
+        self._ws_side = ws_side                                # split-K slabs of the launches of forked sections
         self.Bfull = B          # (self.B is lowered to B / share while the batch-shared prefix is built)
         self.ws = eng.workspace if ws is None else ws      # split-K slabs of this plan's launches
         self.B, self.h, self.w = B, h, w
@@ -618,6 +621,30 @@ class PlanBuilder:
     def both(self, op: ops.Op):
         self.f_on.append(op)
         self.f_off.append(op)
+
+    # ---- two-stream sections (leco_hip.h: leco_fork / leco_join): launches built inside `with self.forked():` go to the
+    # library's side stream and use their own split-K workspace; the caller emits the join before the first consumer
+    def fork_ok(self) -> bool:
+        import os
+        # default OFF: measured step-neutral on MI355X / ROCm 7.2 (227.8 vs 228.2 ms per step, profiles/r04_fork_join.txt) --
+        # a replayed hipGraph does not overlap the two branches enough to pay for the extra edges
+        return not self.need_bwd and not self.eng.f32 and os.environ.get("LECO_FORK", "0") not in ("", "0")
+
+    @contextlib.contextmanager
+    def forked(self):
+        n_on, n_off = len(self.f_on), len(self.f_off)
+        self.both(ops.Op("leco_fork", ()))
+        ws_main, self.ws = self.ws, (self._ws_side if self._ws_side is not None else self.eng.workspace_slot(2))
+        try:
+            yield
+        finally:
+            self.ws = ws_main
+            for lst, n0 in ((self.f_on, n_on + 1), (self.f_off, n_off + 1)):
+                for op in lst[n0:]:
+                    op.side = True
+
+    def join(self):
+        self.both(ops.Op("leco_join", ()))
 
     def stat_slice(self, cols: int, hw: int, batch: Optional[int] = None) -> Optional[int]:
         """Device address of a fresh [B][cols / atom][2] slice of the statistics arena (None when the fusion is off or does
@@ -970,9 +997,18 @@ class PlanBuilder:
         eng, m = self.eng, self.eng.named[rname]
         hw, rows = hs * ws, self.B * hs * ws
         conv = (self.B, hs, ws, hs, ws)
+        # conv_shortcut reads the block's input and is only needed by conv2's residual: it runs on the side stream beside
+        # norm1 -> conv1 -> norm2 (whose GroupNorm launches leave most of the chip idle)
+        sc_early = None
+        if m.conv_shortcut is not None and self.fork_ok():
+            with self.forked():
+                sc_early = self.gemm_fwd(eng.sites[rname + ".conv_shortcut"], x, rname + ".sc", rows=rows)
         n1 = self.groupnorm(rname + ".norm1", x, hw, ACT_SILU, self.cfg.norm_eps, rname + ".n1")
         off = eng.temb_off[rname]
         temb = self.temb_all  # fp32 [B][temb_total]
+        if getattr(self, "_pending_join", False):     # the time-embedding chain of build() ran on the side stream
+            self.join()
+            self._pending_join = False
         tsite = eng.temb_lora_sites.get(rname)
         temb_T = None
         if tsite is not None:
@@ -1000,7 +1036,10 @@ class PlanBuilder:
                 self.lora_bwd(tsite, (self.emb_silu,), dtb, temb_T, None, A_PLAIN, self.B, rname + ".temb")
             self.tape.append(temb_bwd)
         n2 = self.groupnorm(rname + ".norm2", h1, hw, ACT_SILU, self.cfg.norm_eps, rname + ".n2")
-        if m.conv_shortcut is not None:
+        if sc_early is not None:
+            sc = sc_early
+            self.join()
+        elif m.conv_shortcut is not None:
             sc = self.gemm_fwd(eng.sites[rname + ".conv_shortcut"], x, rname + ".sc", rows=rows)
         else:
             assert not isinstance(x, tuple)
@@ -1214,7 +1253,13 @@ class PlanBuilder:
         P.pred = self.buf("pred", (B, cfg.out_channels, h, w), torch.float32)
         P.dpred = self.buf("dpred", (B, cfg.out_channels, h, w), torch.float32, zero=True)
         ctx = TRef(P.ctx, B * 77, cfg.cross_attention_dim, name="ctx")
-        # -- time embedding
+        # -- time embedding.  Forward-only plans: the whole chain (sinusoid, the two Linears, SDXL's add-embedding, the fused
+        # time_emb_proj GEMM) runs on the side stream beside conv_in and the first GroupNorm; the first consumer -- conv1 of
+        # the first ResnetBlock2D -- joins (resnet())
+        temb_fork = contextlib.ExitStack()
+        if self.fork_ok():
+            temb_fork.enter_context(self.forked())
+            self._pending_join = True
         tsin = self.act("t_sin", B, ch[0])
         self.both(ops.timestep_embedding(P.t_table, P.t_idx, 0, B, ch[0], tsin.t))
         e1 = self.gemm_fwd(S["time_embedding.linear_1"], tsin, "t_e1", rows=B, act=ACT_SILU)
@@ -1232,6 +1277,7 @@ class PlanBuilder:
         self.emb_silu = emb_silu
         self.temb_all = self.buf("temb_all", (B, eng.temb_total), torch.float32)
         self.gemm_fwd(S["time_emb_proj_all"], emb_silu, "temb_all_g", rows=B, out_f32=self.temb_all)
+        temb_fork.close()
         # -- conv_in.  BATCH-SHARED PREFIX (share > 1: the B latents are `share` copies of B / share samples at one timestep):
         # conv_in, the first ResnetBlock2D and the first Transformer2DModel up to and including its self-attention do not see
         # the prompt, so they run ONCE per distinct sample (batch Bp); the stripe tail kernel of that transformer reads them
@@ -1427,6 +1473,8 @@ class UNet2DConditionModel(nn.Module):
                 side = self._capture_stream = torch.cuda.Stream()
             side.wait_stream(cur)
             sp = side.cuda_stream
+            if any(op.side for op in oplist):
+                ops.side_stream()       # forked sections: the library's side stream exists before the capture begins
             hip.check(lib.leco_graph_begin_capture(sp), "graph begin")
             try:
                 ops.run_plan(oplist, sp)

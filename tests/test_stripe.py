@@ -237,6 +237,51 @@ def test_forward_only_plans_run_the_stripe_kernels_and_match_the_per_op_plan(dev
         assert rel_err(p_on, p_off) > 1e-3 and rel_err(y_on, y_off) > 1e-3     # the LoRA term is really there
 
 
+def test_forked_shortcut_convolutions_give_the_same_prediction(dev, monkeypatch):
+    """Forward-only plans run ResnetBlock2D.conv_shortcut on the library's side stream beside norm1 -> conv1 -> norm2
+    (leco_fork / leco_join, include/leco_hip.h) and the time-embedding chain beside conv_in: every fork is closed by a join before the consumer, forked GEMMs own a
+    split-K workspace, and the prediction -- graph replay and eager, twice each -- equals the single-stream plan's."""
+    torch.manual_seed(11)
+    monkeypatch.setenv("LECO_FORK", "1")         # (off by default: measured step-neutral under graph replay)
+    m = _stripe_unet(dev)
+    B, h, w = 2, 8, 8
+    x = torch.randn(B, 4, h, w).to(dev, bf); ctx = torch.randn(B, 77, 64).to(dev, bf)
+    eng = m.engine()
+    plan = eng.plan(B, h, w, need_bwd=False)
+    lst = plan.lists["fwd_off"]
+    names = [op.name for op in lst]
+    n_sc = sum(1 for nm, mod in m.named_modules() if nm.endswith("conv_shortcut"))
+    # one section per conv_shortcut + the time-embedding chain beside conv_in
+    assert n_sc >= 2 and names.count("leco_fork") == n_sc + 1 == names.count("leco_join")
+    depth = 0
+    for op in lst:                                # sections do not nest, side launches only inside one, all closed at the end
+        if op.name == "leco_fork":
+            assert depth == 0
+            depth = 1
+        elif op.name == "leco_join":
+            assert depth == 1
+            depth = 0
+        elif op.side:
+            assert depth == 1 and op.name.startswith(("leco_gemm", "leco_timestep_embedding"))
+            if op.name.startswith("leco_gemm") and op.args[3]:
+                assert op.args[3] == eng.workspace_slot(2).data_ptr() != eng.workspace.data_ptr()
+    assert depth == 0 and any(op.side for op in lst)
+    assert not any(op.side for op in eng.plan(B, h, w, need_bwd=True).lists["fwd_off"])      # training plans stay single-stream
+    outs = []
+    for graphs in (True, False):
+        m.use_graphs = graphs
+        for _ in range(2):
+            outs.append(_run_plan(m, plan, "fwd_off", x, ctx))
+    monkeypatch.setenv("LECO_FORK", "0")
+    eng.plans.clear()
+    plain = eng.plan(B, h, w, need_bwd=False)
+    assert "leco_fork" not in [op.name for op in plain.lists["fwd_off"]]
+    ref = _run_plan(m, plain, "fwd_off", x, ctx)
+    _sync(dev)
+    for o in outs:
+        assert rel_err(o, ref) < 2e-3 and torch.isfinite(o).all()
+
+
 @pytest.mark.parametrize("rank,gn,B,hw", [(4, True, 2, 64), (0, False, 1, 128), (8, True, 1, 64)])
 def test_xblock_head_matches_the_per_op_chain(dev, rank, gn, B, hw):
     """GroupNorm (from producer statistics) -> proj_in -> LayerNorm -> q|k|v: h_out and qkv_out vs the fp32 chain."""

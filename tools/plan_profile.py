@@ -102,7 +102,7 @@ def main():
     plan, which = {"denoise": (st["dplan"], "denoise"), "frozen": (st["fplan"], "fwd_off"), "fwd_on": (st["plan"], "fwd_on"),
                    "fwd_off": (st["plan"], "fwd_off"), "bwd": (st["plan"], "bwd")}[args.list]
     # the CFG / DDIM update and the timestep advance mutate the step state: leave them out of the repeats
-    ops_ = [op for op in plan.lists[which] if op.name not in ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step")]
+    ops_ = [op for op in plan.lists[which] if op.name not in ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step", "leco_fork", "leco_join")]
     x = torch.randn(4096, 4096, device=dev)
     for _ in range(20):
         (x @ x).sum().item()      # clock ramp
