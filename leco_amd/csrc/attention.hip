@@ -297,21 +297,45 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
 //     register-staged kernel cannot be DMA'd);
 //   * every LDS read is inline asm (ds_read_b128 / ds_read_b64_tr_b16 with immediate offsets): with LDS-DMA in flight the
 //     compiler would otherwise drain vmcnt in front of each of them.
-// Requirements (else the register-staged kernel runs): skv % 64 == 0, sq % (64 QF) == 0.
-template <int D>
+// Requirements (else the register-staged kernel runs): skv % 64 == 0, sq % (64 QF) == 0; built for d = 40 / 64 / 80.
+template <int D, int NBUF>
 struct AttnDmaCfg {
     static constexpr int NDC = D / 8, KS = NDC | 1;
     static constexpr int DV = (D + 15) / 16 * 16, VS0 = DV / 8, VS = ((VS0 / 2) % 2) ? VS0 : VS0 + 2;
     static constexpr int KB = KT * KS * 16, VB = KT * VS * 16, TILE = KB + VB;
     static constexpr int NP = KS + VS, PPW = (NP + 3) / 4;
-    static constexpr int NBUF = 3, OFF_DUMP = NBUF * TILE, LDS_BYTES = OFF_DUMP + 1024;
+    static constexpr int OFF_DUMP = NBUF * TILE, LDS_BYTES = OFF_DUMP + 1024;
 };
-template <int D, int QF>
-__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OCC40 : 2) void attn_fwd_dma_kernel(AttnArgs p) {
-    using Cf = AttnDmaCfg<D>;
+// completes all but the n youngest LDS operations; n is a compile-time constant after unrolling (lgkmcnt holds 0..15)
+__device__ __forceinline__ void lds_wait_n(int n) {
+    switch (n < 15 ? n : 15) {
+        case 0: lds_wait<0>(); break;
+        case 1: lds_wait<1>(); break;
+        case 2: lds_wait<2>(); break;
+        case 3: lds_wait<3>(); break;
+        case 4: lds_wait<4>(); break;
+        case 5: lds_wait<5>(); break;
+        case 6: lds_wait<6>(); break;
+        case 7: lds_wait<7>(); break;
+        case 8: lds_wait<8>(); break;
+        case 9: lds_wait<9>(); break;
+        case 10: lds_wait<10>(); break;
+        case 11: lds_wait<11>(); break;
+        case 12: lds_wait<12>(); break;
+        case 13: lds_wait<13>(); break;
+        case 14: lds_wait<14>(); break;
+        default: lds_wait<15>(); break;
+    }
+}
+// NBUF: depth of the K / V ring (3 where the LDS budget of the occupancy target allows: d = 40 at 4 workgroups per CU, d = 80
+// at 2; d = 64 runs 3 workgroups per CU on a 2-deep ring)
+template <int D, int QF, int NBUF>
+__global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OCC40 : (D == 64 ? LECO_ATTN_OCC64 : 2)) void attn_fwd_dma_kernel(AttnArgs p) {
+    using Cf = AttnDmaCfg<D, NBUF>;
     constexpr int DK = (D + 31) / 32 * 32, DV = Cf::DV;
     constexpr int NKS = DK / 32, NFD = DV / 16, NDC = Cf::NDC, KS = Cf::KS, VS = Cf::VS, PPW = Cf::PPW;
     constexpr int KB = Cf::KB, TILE = Cf::TILE;
+    static_assert(NFD <= 10 && NKS <= 5, "fragment dispatch tables");
     unsigned char* lds = dyn_lds();
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
@@ -382,42 +406,63 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
     const bf16x8 ones = __builtin_bit_cast(bf16x8, ones4);
 
     // lane parts of the fragment addresses (bytes inside a tile buffer)
-    const unsigned ka[NKS == 1 ? 1 : 2] = {(unsigned)(fr * KS * 16 + (fg < NDC ? fg : NDC - 1) * 16),
-                                           (unsigned)(fr * KS * 16 + (4 + fg < NDC ? 4 + fg : NDC - 1) * 16)};
+    unsigned ka[NKS];
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) ka[ks] = (unsigned)(fr * KS * 16 + (ks * 4 + fg < NDC ? ks * 4 + fg : NDC - 1) * 16);
     const unsigned va = (unsigned)(KB + ((4 * fg + (fr >> 2)) * VS * 16) + 8 * (fr & 3));
-    static_assert(NKS <= 2 || D > 64, "ka[] covers two k-steps; larger head dims compute the slot per k-step");
 
-    issue(0, 0);
-    issue(1, 1);
+    // fragment reads with compile-time displacements (f / fd are constants after unrolling; the switch folds)
+    auto read_k = [&](unsigned base, int f, bf16x8 (&dst)[NKS]) {
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const unsigned a = base + ka[ks];
+            switch (f) {
+                case 0: dst[ks] = lds_read16_at<0 * 16 * KS * 16>(a); break;
+                case 1: dst[ks] = lds_read16_at<1 * 16 * KS * 16>(a); break;
+                case 2: dst[ks] = lds_read16_at<2 * 16 * KS * 16>(a); break;
+                default: dst[ks] = lds_read16_at<3 * 16 * KS * 16>(a); break;
+            }
+        }
+    };
+    auto read_v4 = [&](unsigned vbase, auto fd_c, u32x2 (&dst)[4]) {
+        constexpr int F = decltype(fd_c)::value;
+        dst[0] = lds_read_tr16_at<(0 * 16) * VS * 16 + 32 * F>(vbase);
+        dst[1] = lds_read_tr16_at<(1 * 16) * VS * 16 + 32 * F>(vbase);
+        dst[2] = lds_read_tr16_at<(2 * 16) * VS * 16 + 32 * F>(vbase);
+        dst[3] = lds_read_tr16_at<(3 * 16) * VS * 16 + 32 * F>(vbase);
+    };
+    auto read_v = [&](unsigned vbase, int fd, u32x2 (&dst)[4]) {
+        switch (fd) {
+            case 0: read_v4(vbase, std::integral_constant<int, 0>{}, dst); break;
+            case 1: read_v4(vbase, std::integral_constant<int, (1 < NFD ? 1 : 0)>{}, dst); break;
+            case 2: read_v4(vbase, std::integral_constant<int, (2 < NFD ? 2 : 0)>{}, dst); break;
+            case 3: read_v4(vbase, std::integral_constant<int, (3 < NFD ? 3 : 0)>{}, dst); break;
+            case 4: read_v4(vbase, std::integral_constant<int, (4 < NFD ? 4 : 0)>{}, dst); break;
+            case 5: read_v4(vbase, std::integral_constant<int, (5 < NFD ? 5 : 0)>{}, dst); break;
+            case 6: read_v4(vbase, std::integral_constant<int, (6 < NFD ? 6 : 0)>{}, dst); break;
+            case 7: read_v4(vbase, std::integral_constant<int, (7 < NFD ? 7 : 0)>{}, dst); break;
+            case 8: read_v4(vbase, std::integral_constant<int, (8 < NFD ? 8 : 0)>{}, dst); break;
+            default: read_v4(vbase, std::integral_constant<int, (9 < NFD ? 9 : 0)>{}, dst); break;
+        }
+    };
+
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t) issue(t, t);
     int cur = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
-        wait_vmcnt<PPW>();            // this wave's pieces of `tile` have landed (the PPW of tile + 1 may be in flight)
-        barrier_keep_dma();           // ... every wave's; and every wave is done with tile - 1, whose buffer is refilled now
-        issue(tile + 2, cur == 0 ? 2 : cur - 1);
+        wait_vmcnt<(NBUF - 2) * PPW>();   // this wave's pieces of `tile` have landed (those of the next NBUF - 2 tiles may be in flight)
+        barrier_keep_dma();               // ... every wave's; and every wave is done with tile - 1, whose buffer is refilled now
+        issue(tile + NBUF - 1, cur == 0 ? NBUF - 1 : cur - 1);
         const unsigned base = lds_addr(lds) + (unsigned)(cur * TILE);
 
-        // S^T = K Q^T : lane holds S[q = fr][key = 16 f + 4 fg + r]
+        // S^T = K Q^T : lane holds S[q = fr][key = 16 f + 4 fg + r].  Fragment reads run two key fragments ahead.
         f32x4 acc_s[QF][4];
         bf16x8 kf[4][NKS];
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int ks = 0; ks < NKS; ++ks) {
-                const unsigned a = base + (ks == 0 ? ka[0] : (NKS <= 2 ? ka[NKS == 1 ? 0 : 1]
-                                                                       : (unsigned)(fr * KS * 16 + (ks * 4 + fg < NDC ? ks * 4 + fg : NDC - 1) * 16)));
-                switch (f) {
-                    case 0: kf[f][ks] = lds_read16_at<0 * 16 * KS * 16>(a); break;
-                    case 1: kf[f][ks] = lds_read16_at<1 * 16 * KS * 16>(a); break;
-                    case 2: kf[f][ks] = lds_read16_at<2 * 16 * KS * 16>(a); break;
-                    default: kf[f][ks] = lds_read16_at<3 * 16 * KS * 16>(a); break;
-                }
-            }
+        read_k(base, 0, kf[0]);
+        read_k(base, 1, kf[1]);
 #pragma unroll
         for (int f = 0; f < 4; ++f) {
-            if (f == 0) lds_wait<3 * NKS>();
-            else if (f == 1) lds_wait<2 * NKS>();
-            else if (f == 2) lds_wait<1 * NKS>();
-            else lds_wait<0>();
+            lds_wait_n(f < 3 ? NKS : 0);
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) lds_tie(kf[f][ks]);
 #pragma unroll
@@ -427,7 +472,13 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
                 for (int ks = 0; ks < NKS; ++ks) a = mfma16(kf[f][ks], qf[u][ks], a);
                 acc_s[u][f] = a;
             }
+            if (f + 2 < 4) read_k(base, f + 2, kf[f + 2]);
         }
+        // the first two V^T fragments travel while the softmax runs
+        const unsigned vbase = base + va;
+        u32x2 vt[NFD][4];
+        read_v(vbase, 0, vt[0]);
+        if (NFD > 1) read_v(vbase, 1, vt[NFD > 1 ? 1 : 0]);
 
         // online softmax per owned query row on the RAW scores; P^T operand built in registers.  DEFERRED maximum: the
         // reference point m of a row only has to keep exp2(s - m) in range, it need not be the maximum -- while no row of
@@ -476,25 +527,6 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
 
         // O^T += V^T P^T (transpose reads: 16-lane group fg gathers keys 16 (2 s + hh) + 4 fg .. + 3 of columns 16 fd ..),
         // l += 1^T P^T
-        const unsigned vbase = base + va;
-        u32x2 vt[NFD][4];
-#pragma unroll
-        for (int fd = 0; fd < NFD; ++fd) {
-            auto rd = [&](auto fd_c) {
-                constexpr int F = decltype(fd_c)::value;
-                vt[F][0] = lds_read_tr16_at<(0 * 16) * VS * 16 + 32 * F>(vbase);
-                vt[F][1] = lds_read_tr16_at<(1 * 16) * VS * 16 + 32 * F>(vbase);
-                vt[F][2] = lds_read_tr16_at<(2 * 16) * VS * 16 + 32 * F>(vbase);
-                vt[F][3] = lds_read_tr16_at<(3 * 16) * VS * 16 + 32 * F>(vbase);
-            };
-            if (fd == 0) rd(std::integral_constant<int, 0>{});
-            if (fd == 1) rd(std::integral_constant<int, 1 < NFD ? 1 : 0>{});
-            if (fd == 2) rd(std::integral_constant<int, 2 < NFD ? 2 : 0>{});
-            if (fd == 3) rd(std::integral_constant<int, 3 < NFD ? 3 : 0>{});
-            if (fd == 4) rd(std::integral_constant<int, 4 < NFD ? 4 : 0>{});
-            if (fd >= 5) rd(std::integral_constant<int, (5 < NFD ? 5 : 0)>{});
-        }
-        static_assert(NFD <= 6, "transpose-read dispatch covers 6 column fragments");
 #pragma unroll
         for (int u = 0; u < QF; ++u) {
             acc_l[u] = mfma16(ones, __builtin_bit_cast(bf16x8, pw[u][0]), acc_l[u]);
@@ -502,10 +534,7 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
         }
 #pragma unroll
         for (int fd = 0; fd < NFD; ++fd) {
-            if (fd == 0) lds_wait<4 * (NFD - 1) < 16 ? 4 * (NFD - 1) : 15>();
-            else if (fd == NFD - 1) lds_wait<0>();
-            else if (fd == 1) lds_wait<4 * (NFD - 2) < 16 ? 4 * (NFD - 2) : 15>();
-            else lds_wait<0>();
+            lds_wait_n(fd + 1 < NFD ? 4 : 0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) lds_tie2(vt[fd][q]);
 #pragma unroll
@@ -515,8 +544,9 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
 #pragma unroll
                 for (int u = 0; u < QF; ++u) acc_o[u][fd] = mfma16(vf, __builtin_bit_cast(bf16x8, pw[u][s2]), acc_o[u][fd]);
             }
+            if (fd + 2 < NFD) read_v(vbase, fd + 2, vt[fd + 2 < NFD ? fd + 2 : 0]);
         }
-        cur = cur == 2 ? 0 : cur + 1;
+        cur = cur == NBUF - 1 ? 0 : cur + 1;
     }
     wait_vmcnt<0>();                  // the out-of-range pieces issued past the last tile
 
@@ -539,7 +569,19 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
             p.lse[((int64_t)b * p.heads + h) * p.sq + qrow] = (m_run[u] + log2f(l)) * 0.6931471805599453f;
     }
 }
-
+template <int D, int QF, int NBUF>
+void launch_fwd_dma(const AttnArgs& a, int batch, hipStream_t s) {
+    using Cf = AttnDmaCfg<D, NBUF>;
+    static bool attr_set[64] = {};
+    int dev_id = 0;
+    (void)hipGetDevice(&dev_id);
+    if (Cf::LDS_BYTES > 64 * 1024 && (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id])) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_dma_kernel<D, QF, NBUF>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
+        if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
+    }
+    hipLaunchKernelGGL((attn_fwd_dma_kernel<D, QF, NBUF>), dim3(a.sq / (64 * QF), a.heads, batch), dim3(256), Cf::LDS_BYTES, s, a);
+}
 
 // ------------------------------------------------------------------------------------------
 // Backward (once per optimizer step, for the LoRA-on "target" pass only).  P is recomputed
@@ -835,15 +877,23 @@ int launch_fwd(const AttnArgs& a, int batch, hipStream_t s) {
     // there are still >= 4 workgroups per CU (measured: 4x8x4096^2x40 218 vs 238 us, 4x8x1024^2x80 35.8 vs 31.8 us)
     const long wgs2 = (long)cdiv(a.sq, 128) * a.heads * batch;
     const bool masked = a.skv % KT != 0;
-    // large self-attention problems at d = 40 (SD1.x level 0): the LDS-DMA staged kernel (LECO_ATTN_DMA=0: off)
-    // (=2: also for small grids -- the kernel tests)
+    // self-attention at d = 40 / 64 / 80 with enough workgroups to fill the chip: the LDS-DMA staged kernel (LECO_ATTN_DMA=0:
+    // off; =2: also for small grids -- the kernel tests)
     const char* dma_env = getenv("LECO_ATTN_DMA");             // (read per launch: launches are recorded into graphs once)
     const int use_dma = dma_env ? atoi(dma_env) : 1;
-    if constexpr (D == 40) {
-        if (use_dma && !masked && a.sq % 128 == 0 && (wgs2 >= 512 || use_dma == 2) && (force_qf == 0 || force_qf == 2) &&
-            ((int64_t)a.skv * a.ldk * 2 < (1ll << 31)) && ((int64_t)a.skv * a.ldv * 2 < (1ll << 31))) {
-            hipLaunchKernelGGL((attn_fwd_dma_kernel<D, 2>), dim3(a.sq / 128, a.heads, batch), dim3(256), AttnDmaCfg<D>::LDS_BYTES, s, a);
-            return check_launch("leco_attention_fwd");
+    if constexpr (D == 40 || D == 64 || D == 80) {
+        constexpr int NBUF = D == 64 ? 2 : 3;
+        const long wgs1 = (long)cdiv(a.sq, 64) * a.heads * batch;
+        const bool fits = ((int64_t)a.skv * a.ldk * 2 < (1ll << 31)) && ((int64_t)a.skv * a.ldv * 2 < (1ll << 31));
+        if (use_dma && !masked && fits) {
+            if (a.sq % 128 == 0 && (wgs2 >= 512 || (use_dma == 2 && force_qf != 1)) && force_qf != 1) {
+                launch_fwd_dma<D, 2, NBUF>(a, batch, s);
+                return check_launch("leco_attention_fwd");
+            }
+            if (a.sq % 64 == 0 && (wgs1 >= 512 || use_dma == 2) && force_qf != 2) {
+                launch_fwd_dma<D, 1, NBUF>(a, batch, s);
+                return check_launch("leco_attention_fwd");
+            }
         }
     }
     if (force_qf ? force_qf == 2 : wgs2 >= 1024) {

@@ -507,12 +507,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, int64_t ld
     const bool live = row < M;
     const int64_t r = live ? row : 0;
     float v[LN_MAXV][8];
+    f32x4 ga[LN_MAXV][2], be[LN_MAXV][2];      // gamma / beta travel with the row: no third memory round trip behind the statistics
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXV; ++j) {
         const int vv = lane + 64 * j;
         if (vv < nvec) {
-            unpack8(*(const u32x4*)(x + r * ldx + vv * 8), v[j]);
+            const u32x4 xv = *(const u32x4*)(x + r * ldx + vv * 8);
+            ga[j][0] = *(const f32x4*)(gamma + vv * 8); ga[j][1] = *(const f32x4*)(gamma + vv * 8 + 4);
+            be[j][0] = *(const f32x4*)(beta + vv * 8); be[j][1] = *(const f32x4*)(beta + vv * 8 + 4);
+            unpack8(xv, v[j]);
 #pragma unroll
             for (int i = 0; i < 8; ++i) s += v[j][i];
         }
@@ -534,7 +538,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, int64_t ld
         if (vv < nvec) {
             float o[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = (v[j][i] - mu) * rs * gamma[vv * 8 + i] + beta[vv * 8 + i];
+            for (int i = 0; i < 8; ++i) o[i] = (v[j][i] - mu) * rs * ga[j][i >> 2][i & 3] + be[j][i >> 2][i & 3];
             *(u32x4*)(y + r * ldy + vv * 8) = pack8(o);
         }
     }

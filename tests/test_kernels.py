@@ -478,15 +478,17 @@ def test_attention_fwd_bwd(dev, B, H, Sq, Skv, D):
     assert rel_err(dv.cpu(), vv.grad) < 4e-3
 
 
-@pytest.mark.parametrize("B,H,S,fused,gain", [(1, 2, 256, False, 1.0), (2, 1, 384, True, 1.0), (1, 1, 128, True, 1.0),
-                                              (1, 1, 512, False, 3.0)])     # scores x 9: the deferred maximum has to move mid-way
-def test_attention_dma_staged_forward(dev, monkeypatch, B, H, S, fused, gain):
-    """attn_fwd_dma_kernel (d = 40 self-attention with the K / V tiles brought in by LDS-DMA into a 3-deep ring; the
-    planner's level-0 shapes take it by default, LECO_ATTN_DMA=2 forces it for small grids) against fp32 torch and against
+@pytest.mark.parametrize("B,H,S,fused,gain,D", [(1, 2, 256, False, 1.0, 40), (2, 1, 384, True, 1.0, 40), (1, 1, 128, True, 1.0, 40),
+                                                (1, 1, 512, False, 3.0, 40),     # scores x 9: the deferred maximum has to move mid-way
+                                                (1, 1, 192, True, 1.0, 40),      # 64-query workgroups (one query fragment per wave)
+                                                (1, 2, 256, True, 1.0, 64), (1, 1, 192, False, 2.0, 64),     # 2-deep ring
+                                                (1, 1, 256, False, 1.0, 80), (2, 1, 192, True, 1.0, 80)])    # three k-steps, 5 column fragments
+def test_attention_dma_staged_forward(dev, monkeypatch, B, H, S, fused, gain, D):
+    """attn_fwd_dma_kernel (d = 40 / 64 / 80 self-attention with the K / V tiles brought in by LDS-DMA into a 2- or 3-deep ring;
+    the planner's large self-attention shapes take it by default, LECO_ATTN_DMA=2 forces it for small grids) against fp32 torch and against
     the register-staged kernel (LECO_ATTN_DMA=0); 2 / 4 / 6 key tiles: prologue only, one ring wrap, two ring wraps; separate
     and q|k|v-fused layouts.  tests/test_host.py re-runs this under the emulator's late-DMA model."""
     torch.manual_seed(S + H)
-    D = 40
     C = H * D
     if fused:
         qkv = (torch.randn(B, S, 3 * C) * gain).to(bf).to(dev)
