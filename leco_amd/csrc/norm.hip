@@ -13,6 +13,7 @@
 // LayerNorm over the last dim (C <= 2048): one wave64 per row, two-pass statistics held in
 // registers, wave-shuffle reductions.
 #include <errno.h>
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <leco_prims.h>
 
@@ -62,7 +63,10 @@ constexpr int GN_SEG = 16;           // row segments of the in-block reduction t
 //   pass 2: the same pixels again (L2-resident by now) -> normalise (+SiLU) / dgrad -> store.
 // MODE 0: forward, statistics {sum x, sum x^2} (also written to stats[b][g][2] for the backward).
 // MODE 1: backward, statistics {sum dxhat, sum dxhat*xhat}, dx = rstd*(dxhat - s1/n - xhat*s2/n).
-template <int MODE>
+// NVR > 0 (forward only): every thread owns at most NVR pixels of its channel vector and KEEPS them in registers between
+// the two passes -- one trip to memory instead of two (the launches are latency-, not bandwidth-bound: 8 - 16 us each, 45
+// of them per UNet pass).
+template <int MODE, int NVR = 0>
 __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t* dy, int64_t lddy,
                                                          const float* fstats, float* stats_out,
                                                          const float* gamma, const float* beta, int act,
@@ -105,7 +109,28 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    if (active) {
+    u32x4 keep[NVR > 0 ? NVR : 1];
+    if (active && NVR > 0) {
+#pragma unroll
+        for (int j = 0; j < NVR; ++j) {
+            const int p = pl + j * PL;
+            keep[j] = gn_load(src, (int64_t)b * hw + (p < hw ? p : pl), c);
+        }
+#pragma unroll
+        for (int j = 0; j < NVR; ++j) {
+            if (pl + j * PL < hw) {
+                float x[8];
+                unpack8(keep[j], x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s1[i] += x[i]; s2[i] += x[i] * x[i]; }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            stage[(pl * chunkC + v * 8 + i) * 2] = s1[i];
+            stage[(pl * chunkC + v * 8 + i) * 2 + 1] = s2[i];
+        }
+    } else if (active) {
         for (int p0 = pl; p0 < hw; p0 += 4 * PL) {
             u32x4 xv[4], dv[4];
 #pragma unroll
@@ -182,6 +207,23 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
             t1[i] = q1;
             t2[i] = q2;
         }
+    }
+    if (NVR > 0) {
+#pragma unroll
+        for (int j = 0; j < NVR; ++j) {
+            const int p = pl + j * PL;
+            if (p < hw) {
+                float x[8], o[8];
+                unpack8(keep[j], x);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float z = (x[i] - t1[i]) * t2[i] * ga[i] + be[i];
+                    o[i] = act ? silu(z) : z;
+                }
+                *(u32x4*)(out + ((int64_t)b * hw + p) * ldo + c) = pack8(o);
+            }
+        }
+        return;
     }
     for (int p0 = pl; p0 < hw; p0 += 4 * PL) {
         u32x4 xv[4], dv[4];
@@ -630,18 +672,31 @@ bool gn_use_block_kernel(const GnGeom& ge, int batch, int hw, int C, int G) {
     const int blocks = batch * (G / ge.gpb);
     return !(slice_bytes > 200 * 1024 && blocks < 96);
 }
+template <int MODE, int NVR>
+void gn_launch_v(const GnGeom& ge, dim3 grid, hipStream_t s, GnSrc src, const bf16_t* dy, int64_t lddy,
+                 const float* fstats, float* stats_out, const float* gamma, const float* beta, int act, float eps,
+                 int hw, int C, int G, bf16_t* out, int64_t ldo) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_block_kernel<MODE, NVR>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gn_block_kernel<MODE, NVR>), grid, dim3(ge.threads), ge.lds, s, src, dy, lddy, fstats, stats_out,
+                       gamma, beta, act, eps, hw, C, G, ge.gpb, out, ldo);
+}
 template <int MODE>
 void gn_launch(const GnGeom& ge, dim3 grid, hipStream_t s, GnSrc src, const bf16_t* dy, int64_t lddy,
                const float* fstats, float* stats_out, const float* gamma, const float* beta, int act, float eps,
                int hw, int C, int G, bf16_t* out, int64_t ldo) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_block_kernel<MODE>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_set = true;
+    if (MODE == 0) {      // forward: pixels per thread -> the register-resident instantiation that holds them (else two passes)
+        const int nv = ge.gpb * (C / G) / 8, PL = ge.threads / nv, per = (hw + PL - 1) / PL;
+        static const bool off = [] { const char* e = getenv("LECO_GN_REGS"); return e && atoi(e) == 0; }();
+        if (!off && per <= 2) return gn_launch_v<0, 2>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+        if (!off && per <= 6) return gn_launch_v<0, 6>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+        if (!off && per <= 16) return gn_launch_v<0, 16>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
     }
-    hipLaunchKernelGGL((gn_block_kernel<MODE>), grid, dim3(ge.threads), ge.lds, s, src, dy, lddy, fstats, stats_out,
-                       gamma, beta, act, eps, hw, C, G, ge.gpb, out, ldo);
+    return gn_launch_v<MODE, 0>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
 }
 }  // namespace
 }  // namespace leco

@@ -399,6 +399,9 @@ def test_groupnorm_from_channel_statistics(dev, act, B, HW, C0, C1, G, atom):
     (1, 1, 70, 640, 320, 32),     # cg = 30, concat split inside a block's channel run
     (0, 2, 16, 64, 0, 32),        # cg = 2 (tiny config): 4 groups inside one 8-channel vector
     (1, 2, 9, 1280, 1280, 32),    # cg = 80: one group per block
+    (1, 2, 1100, 320, 0, 32),     # 6 pixels per thread: the register-resident forward (one read of the tensor), NVR = 6
+    (0, 1, 1024, 640, 320, 32),   # 16 pixels per thread (cg = 30: 68 pixel lanes), NVR = 16, two-source
+    (1, 1, 1150, 480, 480, 32),   # 17 pixels per thread: back to two passes
     (1, 1, 2600, 320, 0, 32)])    # > 200 KB per (sample, group run) on few blocks: pixel-parallel three-launch path
 def test_groupnorm_fwd_bwd(dev, act, B, HW, C0, C1, G):
     torch.manual_seed(3)
