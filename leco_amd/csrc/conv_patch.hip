@@ -49,6 +49,7 @@ struct PatchRt {
     int split_k;                     // > 1: raw fp32 partials to ws[split][M][N], epilogue by splitk_finish
     int tw_log2;                     // TW = 8 or 16
     unsigned a0_bytes, a1_bytes, w_bytes;   // operand extents (buffer descriptors; < 2^31)
+    unsigned ax_bytes, wx_bytes;            // ... of the K-extension operands a_ext / w_ext (0: none)
     float* ws;
 };
 
@@ -364,6 +365,50 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     }
     wait_vmcnt<0>();                          // the out-of-range DMAs issued past the end of the K range
 
+    // ---- K-extension (leco_gemm_args.a_ext / w_ext: the LoRA up-projection of a c3lier convolution, lora.py:102-106; its
+    // 3x3 down-projection T = conv(x, down) is a skinny launch of its own): one more step whose activation rows are the
+    // tile's OUTPUT pixels of a_ext [M][ext_k] and whose weight rows are w_ext [N][ext_k] (ext_k = 32 or 64: one or two
+    // 32-wide MFMA k-steps).  Both land in the layouts of the main loop -- A as patch entries (entry = tile row, 128-byte
+    // rows, slot ^= entry & 7) in patch buffer 0, W in ring slot 0 -- so the fragment reads are the main loop's.  Split-K:
+    // the first split carries it.
+    if (p.a_ext && split == 0) {
+        const buf_rsrc rax = make_rsrc(p.a_ext, rt.ax_bytes), rwx = make_rsrc(p.w_ext, rt.wx_bytes);
+        const unsigned xk_bytes = (unsigned)p.ext_k * 2u;
+        barrier_keep_dma();                   // every wave has issued (and completed) its last fragment reads of the main loop
+#pragma unroll
+        for (int j = 0; j < BM / 64; ++j) {
+            const int r = (wave + NW * j) * 8 + st_row;                       // tile row = patch entry
+            const int g = g0 + (r >> TWl), xx = x0 + (r & (TW - 1));
+            const bool ok = g < GROWS && xx < W && cpos < xk_bytes;
+            const unsigned voff = ok ? (unsigned)(g * W + xx) * (unsigned)p.ld_aext * 2u + cpos : DMA_OOB;
+            glds16_buf(rax, voff, 0u, lds + OFF_A + (wave + NW * j) * (8 * BK * 2));
+        }
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            const int rl = (wave + NW * i) * 8 + st_row, n = n0 + rl;
+            const bool real = !RAGW || i < GW - 1 || (wave + NW * i) < GWT;   // wave-uniform
+            const bool ok = real && rl < BN && n < N && cpos < xk_bytes;
+            unsigned char* dst = real ? lds + (wave + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
+            glds16_buf(rwx, ok ? (unsigned)n * (unsigned)p.ld_wext * 2u + cpos : DMA_OOB, 0u, dst);
+        }
+        wait_vmcnt<0>();
+        barrier_keep_dma();
+        const unsigned char* abase0 = lds + OFF_A;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks * 32 >= p.ext_k) break;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = wave_m * WM + i * 16 + fr;
+                afA[i] = lds_read16_async(abase0 + (((r << 7) + ((fg ^ (r & 7)) << 4)) ^ (ks << 6)));
+            }
+            read_w(0, ks, wfA);
+            lds_wait<0>();
+            landed(afA, wfA);
+            mma(afA, wfA);
+        }
+    }
+
     // ---- epilogue through LDS: accumulators (lane = one pixel x 4 consecutive n) staged as fp32 -- the whole tile at
     // once where it fits (RR rows per round) -- so bias / residual reads and the bf16 (or fp32 partial) stores move whole
     // 16-byte row segments.  Every thread owns ITEMS (row, 8-column) items of a round; their residual loads are all
@@ -557,9 +602,11 @@ int launch_patch_m(const leco_gemm_args& a, int split_k, float* ws, hipStream_t 
     const int c0 = a.a1 ? a.k_split : cin, c1 = cin - c0;
     const int64_t e0 = ((pixels - 1) * a.lda0 + c0) * 2, e1 = a.a1 ? ((pixels - 1) * a.lda1 + c1) * 2 : 0;
     const int64_t ew = ((int64_t)(a.n - 1) * a.ldw + a.k) * 2;
-    if (e0 >= (1ll << 31) || e1 >= (1ll << 31) || ew >= (1ll << 31)) return 1;
+    const int64_t eax = a.a_ext ? ((int64_t)(a.m - 1) * a.ld_aext + a.ext_k) * 2 : 0;
+    const int64_t ewx = a.a_ext ? ((int64_t)(a.n - 1) * a.ld_wext + a.ext_k) * 2 : 0;
+    if (e0 >= (1ll << 31) || e1 >= (1ll << 31) || ew >= (1ll << 31) || eax >= (1ll << 31) || ewx >= (1ll << 31)) return 1;
     if ((int64_t)a.batch * (a.h_out + 1) >= (1 << 18)) return 1;      // exact float-reciprocal divisions in the kernel
-    PatchRt rt{tn, g.tiles_x, g.tiles_g, split_k, g.tw_log2, (unsigned)e0, (unsigned)e1, (unsigned)ew, ws};
+    PatchRt rt{tn, g.tiles_x, g.tiles_g, split_k, g.tw_log2, (unsigned)e0, (unsigned)e1, (unsigned)ew, (unsigned)eax, (unsigned)ewx, ws};
     dim3 grid((unsigned)(g.tiles_g * g.tiles_x * tn), (unsigned)split_k);
     if (describe) {
         const int used = (int)strlen(describe);
@@ -585,7 +632,8 @@ int launch_patch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s,
 }
 
 bool patch_applicable(const leco_gemm_args& a) {
-    if (a.a_ext || a.t_w || a.act == LECO_ACT_GEGLU) return false;
+    if (a.t_w || a.act == LECO_ACT_GEGLU) return false;
+    if (a.a_ext && (!a.w_ext || (a.ext_k != 32 && a.ext_k != 64))) return false;
     if (a.a_mode == LECO_A_CONV3_S1) return a.h_in == a.h_out && a.w_in == a.w_out;
     if (a.a_mode == LECO_A_CONV3_UP2) return a.h_out == 2 * a.h_in && a.w_out == 2 * a.w_in;
     return false;

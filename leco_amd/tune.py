@@ -62,7 +62,7 @@ def candidates(g: GemmArgs, has_ws: bool):
     geglu = g.act == hip.ACT_GEGLU
     tiles = [1, 4, 5, 6] if geglu else [1, 2, 3, 4] + ([5, 6] if plain else [])
     out = [(0, 0)]                                   # the C heuristic itself
-    if g.a_mode in (hip.A_CONV3_S1, hip.A_CONV3_UP2) and not (g.a_ext or g.t_w):
+    if g.a_mode in (hip.A_CONV3_S1, hip.A_CONV3_UP2) and not g.t_w:      # (K-extension launches included: conv_patch.hip carries a_ext)
         # patch-staged kernel (conv_patch.hip): tile ids 7..10; K splits are whole 64-channel chunks
         chunks = g.k // 9 // 64
         for t, (bm, bn) in {7: (256, 128), 8: (128, 160), 9: (128, 128), 10: (256, 160)}.items():

@@ -288,6 +288,35 @@ def test_conv3x3_patch_staged(dev, tile, B, H, W_, Ci, Co, ks, split):
     assert rel_err(out.cpu(), ref) < TOLBF
 
 
+@pytest.mark.parametrize("tile,B,H,W_,Ci,Co,split,ext_k,up2", [
+    (7, 1, 16, 16, 64, 128, 1, 32, False), (8, 2, 6, 10, 64, 320, 1, 64, False), (9, 2, 12, 20, 128, 64, 2, 32, False),
+    (10, 1, 20, 16, 256, 200, 2, 64, False), (7, 4, 5, 7, 64, 64, 1, 32, False), (8, 2, 10, 24, 128, 160, 1, 32, True)])
+def test_conv3x3_patch_staged_with_k_extension(dev, tile, B, H, W_, Ci, Co, split, ext_k, up2):
+    """The c3lier LoRA branch on the patch-staged convolution: C = conv3x3(x, W) + a_ext w_ext^T (a_ext = the low-rank image T
+    per OUTPUT pixel, w_ext = scale * up; lora.py:102-106) -- one extra step behind the tap loop, carried by the first K
+    split; stride 1 and the upsampler form; 32 and 64 low-rank columns; ragged tiles."""
+    torch.manual_seed(tile + ext_k)
+    Hi, Wi = (H // 2, W_ // 2) if up2 else (H, W_)
+    x = torch.randn(B, Ci, Hi, Wi).to(bf)
+    wt = (torch.randn(Co, Ci, 3, 3) / (9 * Ci) ** 0.5).to(bf)
+    M = B * H * W_
+    T = torch.randn(M, ext_k).to(bf); up = (torch.randn(Co, ext_k) * 0.2).to(bf)
+    res = torch.randn(M, Co).to(bf)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    wh = wt.permute(0, 2, 3, 1).contiguous().reshape(Co, 9 * Ci).to(dev)
+    o32 = torch.zeros(M, Co, device=dev)
+    Td, upd, resd = T.to(dev), up.to(dev), res.to(dev)
+    g = hip.gemm_args(xh, wh, None, m=M, n=Co, k=9 * Ci, lda=Ci, a_mode=hip.A_CONV3_UP2 if up2 else hip.A_CONV3_S1,
+                      conv=(B, H, W_, Hi, Wi), out_f32=o32, residual=resd, a_ext=Td, w_ext=upd, ext_k=ext_k)
+    assert "conv_patch_kernel" in hip.gemm_describe(g, tile, split, None, 0)
+    ws = torch.zeros(split * M * Co, device=dev) if split > 1 else None
+    hip.gemm(g, ops.default_stream(), tile=tile, split_k=split, ws=ws)
+    _sync(dev)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if up2 else x.float()
+    ref = F.conv2d(xin, wt.float(), padding=1).permute(0, 2, 3, 1).reshape(M, Co) + T.float() @ up.float().t() + res.float()
+    assert rel_err(o32.cpu(), ref) < TOL32
+
+
 @pytest.mark.parametrize("tile,B,Hi,Wi,Ci,Co,split", [(7, 1, 8, 8, 64, 128, 1), (8, 2, 5, 12, 128, 160, 1), (9, 3, 4, 4, 192, 72, 3),
                                                       (10, 2, 12, 8, 64, 200, 1), (7, 2, 16, 16, 64, 64, 1)])
 def test_conv3x3_patch_staged_on_upsampled_input(dev, tile, B, Hi, Wi, Ci, Co, split):
