@@ -162,9 +162,18 @@ def _launch_identity(op):
         return names, key, 2.0 * g.m * g.n * (g.k + ext), by
     if op.name == "leco_attention_fwd":
         B, H, sq, skv, d = a[13], a[14], a[15], a[16], a[17]
-        qf = 2 if -(-sq // 128) * H * B >= 1024 else 1
-        return ([f"attn_fwd_kernel<{d}, {qf}, {'true' if skv % 64 else 'false'}>"], (op.name, B, H, sq, skv, d),
-                4.0 * B * H * sq * skv * d, 2.0 * B * H * d * (2 * sq + 2 * skv))
+        # the dispatcher of csrc/attention.hip::launch_fwd, restated: LDS-DMA staged kernel for unmasked d = 40 / 64 / 80
+        # problems with >= 512 workgroups, else the register-staged one
+        wgs2, wgs1 = -(-sq // 128) * H * B, -(-sq // 64) * H * B
+        dma = int(os.environ.get("LECO_ATTN_DMA", "1") or 1)
+        name = f"attn_fwd_kernel<{d}, {2 if wgs2 >= 1024 else 1}, {'true' if skv % 64 else 'false'}>"
+        if d in (40, 64, 80) and dma and skv % 64 == 0:
+            nbuf = 2 if d == 64 else 3
+            if sq % 128 == 0 and (wgs2 >= 512 or dma == 2):
+                name = f"attn_fwd_dma_kernel<{d}, 2, {nbuf}>"
+            elif sq % 64 == 0 and (wgs1 >= 512 or dma == 2):
+                name = f"attn_fwd_dma_kernel<{d}, 1, {nbuf}>"
+        return ([name], (op.name, B, H, sq, skv, d), 4.0 * B * H * sq * skv * d, 2.0 * B * H * d * (2 * sq + 2 * skv))
     if op.name == "leco_xblock_tail":
         A = op.keep[0]
         po = 1 if A.proj_out.w else 0

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
 #pragma unroll
         for (int j = 0; j < NVR; ++j) {
             const int p = pl + j * PL;
-            keep[j] = gn_load(src, (int64_t)b * hw + (p < hw ? p : pl), c);
+            keep[j] = gn_load(src, (int64_t)b * hw + (p < hw ? p : 0), c);      // (pl itself may lie beyond a small sample)
         }
 #pragma unroll
         for (int j = 0; j < NVR; ++j) {

@@ -8,6 +8,7 @@ are only used for their device pointers; nothing here computes in PyTorch.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -150,6 +151,19 @@ def default_stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+_TRACE_OPS = os.environ.get("LECO_TRACE_OPS", "0") not in ("", "0")
+
+
+def _describe_op(op) -> str:
+    try:
+        if op.name.endswith("gemm_ex"):
+            g = op.keep[0]
+            return f"m={g.m} n={g.n} k={g.k} a_mode={g.a_mode} ext={g.ext_k} tile={op.args[1]} split={op.args[2]} stats={bool(g.col_stats)}"
+        return " ".join(str(a) for a in op.args if isinstance(a, int) and 0 <= a < (1 << 24))
+    except Exception:
+        return ""
+
+
 def side_stream():
     """Handle of the library's side stream (None on the host emulator: forked launches then run in list order)."""
     if hip.is_emulated() or not torch.cuda.is_available():
@@ -163,6 +177,18 @@ def side_stream():
 def run_plan(plan: Sequence[Op], stream=None) -> None:
     if stream is None:
         stream = default_stream()
+    if _TRACE_OPS:       # LECO_TRACE_OPS=1: name every launch on stderr before it goes out and wait for it (a GPU memory
+        import sys        # fault kills the process without a Python error: the last name printed is the faulting launch)
+        for op in plan:
+            if op.name in _STREAM_OPS:
+                continue
+            print(f"[leco op] {op.name} {_describe_op(op)}", file=sys.stderr, flush=True)
+            rc = op.fn(*op.args, stream)
+            if rc != 0:
+                hip.check(rc, op.name)
+            if torch.cuda.is_available() and not hip.is_emulated():
+                torch.cuda.synchronize()
+        return
     side = None
     for op in plan:
         s = stream

@@ -1461,7 +1461,7 @@ class UNet2DConditionModel(nn.Module):
     # ---- execution ----------------------------------------------------------------------------------
     def _run(self, plan: Plan, which: str) -> None:
         oplist = plan.lists[which]
-        if not (self.use_graphs and self.device.type == "cuda" and not hip.is_emulated()):
+        if not (self.use_graphs and self.device.type == "cuda" and not hip.is_emulated()) or ops._TRACE_OPS:
             ops.run_plan(oplist)
             return
         lib = _graph_api()

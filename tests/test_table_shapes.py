@@ -23,21 +23,21 @@ from leco_amd import hip, ops
 bf = torch.bfloat16
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TABLE = json.load(open(os.path.join(ROOT, "leco_amd", "gemm_tune_gfx950.json")))
-KEY = re.compile(r"m(\d+)n(\d+)k(\d+)a(\d)(?:c(\d+)x(\d+)x(\d+)<(\d+)x(\d+))?(s?)e(\d+)(?:T(\d+))?(o?)(r?)(b?)(B?)A(\d)(f?)(W0)?$")
+KEY = re.compile(r"m(\d+)n(\d+)k(\d+)a(\d)(?:c(\d+)x(\d+)x(\d+)<(\d+)x(\d+))?(s?)e(\d+)(?:T(\d+))?(o?)(r?)(b?)(B?)A(\d)(f?)(S?)(W0)?$")
 
 
 def parse(key):
     g = KEY.match(key).groups()
     d = dict(m=int(g[0]), n=int(g[1]), k=int(g[2]), a_mode=int(g[3]), two=bool(g[9]), ext=int(g[10]),
              t_rows=int(g[11]) if g[11] else 0, t_out=bool(g[12]), res=bool(g[13]), bias=bool(g[14]), rowbias=bool(g[15]),
-             act=int(g[16]), f32=bool(g[17]), no_ws=bool(g[18]))
+             act=int(g[16]), f32=bool(g[17]), stats=bool(g[18]), no_ws=bool(g[19]))
     if d["a_mode"]:
         d["conv"] = tuple(int(x) for x in g[4:9])        # batch, h_out, w_out, h_in, w_in
     return d
 
 
 def family(d):
-    return (d["a_mode"], d["two"], d["ext"] > 0, d["t_rows"], d["res"], d["bias"], d["rowbias"], d["act"], d["f32"])
+    return (d["a_mode"], d["two"], d["ext"] > 0, d["t_rows"], d["res"], d["bias"], d["rowbias"], d["act"], d["f32"], d["stats"])
 
 
 def run_entry(key, tile, split, dev, seed=0):
@@ -126,6 +126,12 @@ def run_entry(key, tile, split, dev, seed=0):
         ref = (u[:, :, 0] * F.gelu(u[:, :, 1])).reshape(M, N // 2)
         n_out = N // 2
         kw.update(ldc=n_out)
+    cs = None
+    if d["stats"]:            # producer-side GroupNorm statistics: {sum, sumsq} per sample and atom of columns (leco_hip.h)
+        srows = d["conv"][1] * d["conv"][2] if d["a_mode"] else M
+        atom = 10 if N % 10 == 0 else 2
+        cs = torch.zeros(M // srows, N // atom, 2, device=dev)
+        kw.update(col_stats=cs, stats_rows=srows, stats_atom=atom)
     out = None if d["f32"] else torch.zeros(M, n_out, dtype=bf, device=dev)
     o32 = torch.zeros(M, n_out, device=dev) if d["f32"] else None
     ws = None if d["no_ws"] else torch.empty(max(1, split) * M * N + 1024, device=dev)
@@ -144,6 +150,10 @@ def run_entry(key, tile, split, dev, seed=0):
     if d["t_out"]:
         R = 12 if d["t_rows"] == 16 else 24
         assert rel_err(tout[:, :R], T[:, :R]) < 1e-2 and float(tout[:, R:].float().abs().max()) == 0.0, key
+    if cs is not None and out is not None:      # the statistics are those of the STORED bf16 values
+        y = out.float().view(cs.shape[0], -1, cs.shape[1], N // cs.shape[1])
+        want = torch.stack([y.sum((1, 3)), (y * y).sum((1, 3))], dim=-1)
+        assert rel_err(cs, want) < 1e-4, f"{key}: column statistics"
     return worst
 
 
@@ -163,7 +173,7 @@ def test_table_keys_are_what_the_tuner_derives(dev):
             kw.update(t_out=x)
         g = hip.gemm_args(x, x, None if d["f32"] else x, m=d["m"], n=d["n"], k=d["k"], bias=x if d["bias"] else None,
                           rowbias=x if d["rowbias"] else None, residual=x if d["res"] else None, act=d["act"],
-                          out_f32=x if d["f32"] else None, **kw)
+                          out_f32=x if d["f32"] else None, col_stats=x if d["stats"] else None, **kw)
         assert tune.shape_key(g, not d["no_ws"]) == key
 
 
@@ -233,7 +243,9 @@ def test_attention_full_size_fwd_bwd_on_gpu(B, H, Sq, Skv, D):
             worst[name] = max(worst.get(name, 0.0), rel_err(got, want))
         del s, ref, qq, kk, vv
     print(f"attention B={B} H={H} Sq={Sq} Skv={Skv} d={D}: " + " ".join(f"{n} {e:.2e}" for n, e in worst.items()))
-    assert worst["o"] < 1e-2 and worst["lse"] < (2e-4 if D == 40 else 1e-5)
+    # d = 40 / 64 / 80 self-attention: the row sum is accumulated by an MFMA from the bf16-ROUNDED probabilities (the values the
+    # output is accumulated from), the other kernels sum the fp32 ones
+    assert worst["o"] < 1e-2 and worst["lse"] < (2e-4 if D in (40, 64, 80) else 1e-5)
     assert max(worst["dq"], worst["dk"], worst["dv"]) < 6e-3
 
 
