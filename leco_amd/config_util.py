@@ -24,7 +24,7 @@ class PretrainedModelConfig(BaseModel):
 
 
 MAX_LORA_RANK = None       # lierla: any rank, like the reference (lora.py:49-95): stacked q|k|v columns above 64 run as chained 64-wide K-extension steps
-MAX_LORA_RANK_C3LIER = 64  # conv LoRA: the low-rank image is one 64-channel tensor
+MAX_LORA_RANK_C3LIER = None  # conv LoRA: the low-rank image is a whole number of 64-channel chunks; ranks above 64 chain further 64-column slices (round 4)
 
 
 class NetworkConfig(BaseModel):
@@ -35,8 +35,7 @@ class NetworkConfig(BaseModel):
 
     @model_validator(mode="after")
     def _rank_fits_the_lora_kernels(self):
-        # the reference accepts any rank; the conv LoRA path has a cap: fail at config time, not after the model has
-        # loaded (README "Limits")
+        # the reference accepts any rank (lora.py clamps a conv module's rank to min(rank, in, out)); so do both paths here
         cap = MAX_LORA_RANK_C3LIER if self.type == "c3lier" else MAX_LORA_RANK
         if self.rank < 1 or (cap is not None and self.rank > cap):
             raise ValueError(f"network.rank={self.rank}: network.type {self.type} supports ranks 1..{cap or 'any'}")

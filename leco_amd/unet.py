@@ -272,9 +272,9 @@ class LoraSiteState:
         # columns of the packed up / down images: one 32- or 64-wide K-extension step, or (ranks whose stacked
         # columns exceed 64) several 64-wide steps, the first riding in the main GEMM, the rest chained behind it
         if site.conv3:
-            self.Rp = 64
-            if self.R > 64:
-                raise ValueError(f"conv LoRA rank {r} exceeds the 64-channel low-rank image of the c3lier path")
+            # the low-rank image T = conv3x3(x, down) is a whole number of 64-channel chunks (the conv gathers walk 64-channel
+            # chunks); ranks above 64 chain further 64-column slices of T . (scale up)^T behind the main convolution
+            self.Rp = (self.R + 63) // 64 * 64
         else:
             self.Rp = (self.R + 31) // 32 * 32 if self.R <= 64 else (self.R + 63) // 64 * 64
         K, N = site.lora_k, site.n
@@ -724,11 +724,22 @@ class PlanBuilder:
                 g_t = gemm_args(a0, lora.dn_s, T.ptr, lda=lda0, ldc=T.ld, **kw)
                 self.f_on.append(ops.gemm(g_t, keep=(lora, xs, T), ws=self.ws))
                 e0 = min(lora.Rp, 64)
+                chain_after = y is not None and act == ACT_NONE
+                on_common = common
+                if lora.Rp > 64 and not chain_after:
+                    # fp32-output or activated sites (c3lier time_emb_proj): the slices beyond the first 64 columns are summed
+                    # FIRST into a bf16 image that the main launch adds through its residual operand (inside the activation)
+                    assert residual is None, "a LoRA rank above 64 on an activated / fp32-output site that also has a residual"
+                    pre = self.act(name + ".loraHi", rows, site.n)
+                    for c in range(64, lora.Rp, 64):
+                        g_c = gemm_args(T.ptr + self.eng.esz * c, lora.up_p.data_ptr() + self.eng.esz * c, pre.ptr, m=rows, n=site.n,
+                                        k=64, lda=T.ld, ldw=lora.Rp, ldc=pre.ld, residual=pre.ptr if c > 64 else None, ldr=pre.ld)
+                        self.f_on.append(ops.gemm(g_c, keep=(lora, T, pre), ws=self.ws))
+                    on_common = dict(common, residual=pre.ptr, ldr=pre.ld)
                 g_on = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, a_ext=T.ptr, w_ext=lora.up_p, ext_k=e0,
-                                 ld_aext=T.ld, ld_wext=lora.Rp, **common)
+                                 ld_aext=T.ld, ld_wext=lora.Rp, **on_common)
                 self.f_on.append(ops.gemm(g_on, keep=(site, lora, xs, residual, y), ws=self.ws))
-                for c in range(64, lora.Rp, 64):   # further 64-column slices of T . (scale up)^T, accumulated into y
-                    assert y is not None and act == ACT_NONE
+                for c in range(64, lora.Rp if chain_after else 0, 64):   # further 64-column slices of T . (scale up)^T, accumulated into y
                     g_c = gemm_args(T.ptr + self.eng.esz * c, lora.up_p.data_ptr() + self.eng.esz * c, y.ptr, m=rows, n=site.n, k=64, lda=T.ld,
                                     ldw=lora.Rp, ldc=y.ld, residual=y.ptr, ldr=y.ld)
                     self.f_on.append(ops.gemm(g_c, keep=(lora, T, y), ws=self.ws))

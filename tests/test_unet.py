@@ -574,7 +574,7 @@ def test_infer_xl_script_samples_with_a_trained_lora(dev, tmp_path):
     assert rel_err(lora.cpu(), base.cpu()) > 1e-3          # the LoRA really is applied
 
 
-@pytest.mark.parametrize("rank,c3lier", [(24, False), (32, True), (160, False)])
+@pytest.mark.parametrize("rank,c3lier", [(24, False), (32, True), (160, False), (96, True)])
 def test_lora_ranks_above_16_forward_backward(dev, rank, c3lier):
     """Ranks whose stacked columns exceed one K-extension tile (q|k|v: 3 x 24 = 72, 3 x 32 = 96 columns): the low-rank
     product runs as chained 64-wide extension steps, the weight gradients in 16-column slices -- vs the oracle LoRA."""
