@@ -766,6 +766,44 @@ def test_single_file_checkpoint_runs_through_the_hip_unet(dev, tmp_path):
     assert [l.lora_name for l in net.unet_loras] == [l.lora_name for l in net_src.unet_loras] and len(net.unet_loras) > 0
 
 
+def test_prompt_front_end_feeds_the_hip_unet(dev, tmp_path):
+    """N2 on both tiers: a diffusers-format folder with a real `transformers` CLIP text encoder (reduced size, synthetic BPE
+    vocabulary) -> `load_models` -> `encode_prompts` ON the UNet's device (train_lora.py:109-137) -> `concat_embeddings` ->
+    `predict_noise` through the HIP UNet (train_util.py:139-166): finite, prompt-dependent, and equal to feeding the same
+    embeddings computed on the CPU."""
+    import json
+    from safetensors.torch import save_file
+    from test_host import _write_synthetic_clip
+    from leco_amd import train_util
+    cfg = model_util.tiny_config()
+    unet0 = model_util.init_synthetic_(UNet2DConditionModel(cfg), 3)
+    folder = str(tmp_path / "model")
+    te = _write_synthetic_clip(folder, hidden=cfg.cross_attention_dim)
+    te.save_pretrained(os.path.join(folder, "text_encoder"))
+    os.makedirs(os.path.join(folder, "unet"))
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.__dict__.items()},
+              open(os.path.join(folder, "unet", "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in unet0.state_dict().items()},
+              os.path.join(folder, "unet", "diffusion_pytorch_model.safetensors"))
+    tok, enc, unet, sched = model_util.load_models(folder, "ddim")
+    unet = unet.to(dev, bf)
+    unet.requires_grad_(False)
+    e_cpu = train_util.encode_prompts(tok, enc, ["van gogh", "", "monet"])
+    enc = enc.to(dev)
+    e_dev = train_util.encode_prompts(tok, enc, ["van gogh", "", "monet"])
+    assert e_dev.device.type == dev.type and rel_err(e_dev.float().cpu(), e_cpu) < 1e-4
+    sched.set_timesteps(10)
+    lat = train_util.get_initial_latents(sched, 1, 128, 128, 1, generator=torch.Generator().manual_seed(5)).to(dev, bf)
+    preds = {}
+    for name, e in (("van gogh", e_dev[0:1]), ("monet", e_dev[2:3]), ("van gogh (cpu embeds)", e_cpu[0:1].to(dev))):
+        emb = train_util.concat_embeddings(e_dev[1:2].to(bf), e.to(bf), 1)
+        with torch.no_grad():
+            preds[name] = train_util.predict_noise(unet, sched, sched.timesteps[2], lat, emb, guidance_scale=3.0).float().cpu()
+    assert all(torch.isfinite(p).all() for p in preds.values())
+    assert rel_err(preds["van gogh"], preds["van gogh (cpu embeds)"]) < 2e-2
+    assert rel_err(preds["van gogh"], preds["monet"]) > 1e-3          # the prompt reaches the cross-attention
+
+
 def test_strict_reference_optimizer_reproduces_bf16_adamw(dev):
     """`--strict_reference`: parameters and AdamW state in the training precision (train_lora.py:72-89).  After fused
     steps the slab equals what torch.optim.AdamW computes on bf16 parameters fed the same (bf16-rounded) gradients -- bit
