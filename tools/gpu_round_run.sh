@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round artefacts on the GPU box (profiles/ files are copied from gpurun_out/ afterwards):
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round_run.sh [measure|tests|configs]'
-# measure: 1. kernel trace of the benchmark command (--no-dominant: the step's own launches only) -> rNN_step_kernel_stats.txt
+# measure: 1. kernel trace of the benchmark command at the driver's --steps 20 --warmup 5 (--no-dominant: the step's own launches only) -> rNN_step_kernel_stats.txt
 #             (its top row names the dominant kernel)
 #          2. counter passes (separate runs, --pmc only) over exactly the dominant kernel's launches of one step
 #             (`bench.py --dominant-only`) -> rNN_pmc_dominant_{mfma,fetch}.csv (headers carry the kernel-source hash that
