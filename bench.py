@@ -71,10 +71,10 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 900.0):
     times, losses = [], []
     t_all = time.perf_counter()
     for i, k in enumerate(ks):
-        # A second full step (the first still pays allocator / autograd warm-up: 135.6 s vs 122.2 s at prompt batch 2 on the
-        # GPU box, profiles/r04_bench.json) only when a step costs less than 100 s -- the CPU leg of a default run stays near
-        # 2.5 minutes; further ones only inside the budget
-        if len(times) >= 1 and (times[-1] > 100.0 or (len(times) >= 2 and time.perf_counter() - t_all + times[-1] * 1.3 > budget_s)):
+        # TWO full steps always (the first still pays allocator / autograd warm-up: 135.6 s vs 122.2 s at prompt
+        # batch 2 on the GPU box, profiles/r04_bench.json -- about 4.5 minutes of CPU work there); further ones only inside the
+        # budget
+        if len(times) >= 2 and time.perf_counter() - t_all + times[-1] * 1.3 > budget_s:
             break
         lat = torch.randn(bs, 4, 64, 64, generator=torch.Generator().manual_seed(1000 + i))
         t0 = time.perf_counter()
@@ -98,9 +98,7 @@ def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 900.0):
     return {"value": 1.0 / t_step, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{len(times)} full fp32 optimizer steps of the ported reference loop at prompt batch {bs} (the GPU run's: "
                       f"measured, not scaled from batch 1) with k = {list(ks[:len(times)])}: "
-                      f"{', '.join(f'{t:.1f} s' for t in times)}; the LAST one, evaluated at k = {k_mean:.1f} ({how})"
-                      + ("" if len(times) > 1 else "; ONE step only (each costs > 100 s here): it still carries the first step's "
-                         "allocator / autograd warm-up, ~10 % on this host (135.6 s vs 122.2 s for the second step in the round-4 run)"),
+                      f"{', '.join(f'{t:.1f} s' for t in times)}; the LAST one, evaluated at k = {k_mean:.1f} ({how})",
             "prompt_batch": bs,
             "steps_timed": len(times), "k": list(ks[:len(times)]), "step_seconds": times,
             "host_cpus": os.cpu_count(), "threads": torch.get_num_threads()}
@@ -202,7 +200,7 @@ def step_launches(st, k_mean):
     skip = ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step", "leco_fork", "leco_join")      # step state / stream edges; negligible time
     for plan, which, w in ((st["dplan"], "ctx_on", 1.0), (st["dplan"], "denoise", float(k_mean)), (st["fplan"], "fwd_off", 1.0),
                            (st["plan"], "fwd_on", 1.0), (st["plan"], "bwd", 1.0)):
-        out += [(op, w) for op in plan.lists[which] if op.name not in skip]
+        out += [(op, w, which) for op in plan.lists[which] if op.name not in skip]
     return out
 
 
@@ -250,10 +248,13 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
     committed counter passes over EXACTLY these launches (`rocprofv3 --pmc ... -- python bench.py --dominant-only`)."""
     launches = step_launches(st, k_mean)
     groups = {}                                   # shape key -> [op, names, flops, launches per step]
-    for op, w in launches:
+    per_list = {}                                 # list name -> {shape key: launches per run of that list}
+    for op, w, which in launches:
         names, key, fl, by = _launch_identity(op)
         g = groups.setdefault(key, [op, names, fl, 0.0, by])
         g[3] += w
+        d = per_list.setdefault(which, {})
+        d[key] = d.get(key, 0) + 1
     top = _profile_top_row()
     if only_replay:
         # counter pass: replay the dominant instantiation's launches with their per-step multiplicities, nothing else
@@ -267,8 +268,9 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
         torch.cuda.synchronize()
         return {"replayed": n, "kernel": want}
     per_name = {}
+    key_us = {}
     for key, (op, names, fl, w, by) in groups.items():
-        us = _time_launch_us(op)
+        us = key_us[key] = _time_launch_us(op)
         name = names[0] if len(names) == 1 else " + ".join(names)
         a = per_name.setdefault(name, [0.0, 0.0, 0.0, {}, 0.0])
         a[0] += w            # launches per step
@@ -301,16 +303,23 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
                                    "tflops": heavy[1][2] / heavy[1][1] / 1e6 if heavy[1][1] else 0.0}}
     out = describe_kernel(name)
     out.update({"profile_top_row": top, "live_top": live_name, "agrees_with_profile": bool(top and top["name"] == name)})
-    # The headline fraction divides the algorithmic FLOPs per launch by the kernel's average duration IN THE COMMITTED KERNEL
-    # TRACE of this command (launches in step order, cold L2 between different kernels) whenever that trace was taken on the
-    # running kernel sources; the isolated live timing stays as `frac_isolated` / `achieved_isolated`.
-    out["achieved_isolated"], out["frac_isolated"] = out["achieved"], out["frac"]
-    out["timing_source"] = "live isolated launches (no kernel trace of these kernel sources in profiles/)"
+    # The headline fraction is measured LIVE in this run: algorithmic FLOPs per launch / the kernel's launch-weighted average
+    # duration, HIP events on the compute stream around its launches (every distinct shape, weighted by how often a step
+    # issues it).  The committed kernel trace of the same command (launches in step order) is the cross-check: when it was
+    # taken on the running kernel sources its average duration rides along as `us_per_launch_trace` / `frac_trace` and the
+    # two must agree (round-4 verdict: the trace figure alone describes the box the trace was taken on, not this run).
+    out["timing_source"] = "live: HIP events around this run's own launches of the kernel (isolated, back-to-back repeats per shape)"
     if trace_current and top["avg_us"] > 0:
         out["us_per_launch_trace"] = top["avg_us"]
-        out["achieved"] = out["flops_per_launch"] / top["avg_us"] / 1e6
-        out["frac"] = out["achieved"] / (PEAK_BF16 / 1e12)
-        out["timing_source"] = f"avg duration of the row in {os.path.relpath(PROFILE_STATS, ROOT)} (rocprofv3 --kernel-trace of this command)"
+        out["achieved_trace"] = out["flops_per_launch"] / top["avg_us"] / 1e6
+        out["frac_trace"] = out["achieved_trace"] / (PEAK_BF16 / 1e12)
+        out["trace_source"] = f"avg duration of the row in {os.path.relpath(PROFILE_STATS, ROOT)} (rocprofv3 --kernel-trace of this command on kernel sources {cur})"
+    # isolated GPU time of the step's launch lists: a step with k denoising passes keeps the GPU busy for at least
+    # fixed + k x per_denoise_pass microseconds; (that sum) / (measured step time) is the step's busy fraction
+    list_us = {which: sum(n * key_us[key] for key, n in d.items()) for which, d in per_list.items()}
+    out["isolated_us"] = {"per_denoise_pass": list_us.get("denoise", 0.0),
+                          "fixed": sum(v for k_, v in list_us.items() if k_ != "denoise"), "by_list": list_us,
+                          "launches": {which: sum(d.values()) for which, d in per_list.items()}}
     if dump_shapes:
         # every shape the dominant kernel runs in a step: the numerator of the fraction can be recomputed from this table
         n, us, fl, shapes, by = per_name[name]
@@ -373,6 +382,8 @@ def main():
                          "command are taken with it, so the trace holds the step's own launches only)")
     ap.add_argument("--dump-shapes", default=None, metavar="FILE",
                     help="write the per-shape (launches, GFLOP, us) table of the dominant kernel to FILE (profiles/rNN_dominant_shapes.txt)")
+    ap.add_argument("--no-telemetry", action="store_true", help="no clock / power sampler thread beside the timed loop")
+    ap.add_argument("--telemetry-hz", type=float, default=10.0)
     ap.add_argument("--k", type=int, default=0, help="profiling only: fixed number of denoising passes per step "
                                                      "(0 = the seeded reference distribution; the headline number uses 0)")
     args = ap.parse_args()
@@ -478,24 +489,47 @@ def main():
         if not emu:
             torch.cuda.synchronize()
 
+    # clocks / power / throttle state before, during (sampler thread) and after the timed loop (tools/gpu_telemetry.py)
+    tele = None
+    if not emu and not args.no_telemetry and rank == 0:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from gpu_telemetry import Telemetry
+            tele = Telemetry(local, getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None))
+        except Exception as e:
+            tele = None
+            print(f"telemetry unavailable: {e!r}", file=sys.stderr)
+    tele_idle = tele.snapshot() if tele else None
     for i in range(args.warmup):
         one(i)
     barrier()
+    tele_before = tele.snapshot() if tele else None
+    if tele:
+        tele.start(args.telemetry_hz)
     if not emu:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0 = torch.cuda.Event(enable_timing=True)
+        step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     t0 = time.perf_counter()
     if not emu:
         e0.record()
     n_allreduce[0] = 0
-    losses = []
+    losses, host_done = [], []
     for i in range(args.warmup, args.warmup + args.steps):
         losses.append(one(i).clone())       # device-side copy of the loss scalar: no host sync in the timed loop
-    if not emu:
-        e1.record()
+        if not emu:
+            step_ev[i - args.warmup].record()       # one HIP event per step, on the compute stream
+        host_done.append(time.perf_counter() - t0)  # when the HOST had finished enqueueing this step
     collectives = n_allreduce[0]
     barrier()
     dt = time.perf_counter() - t0
+    t1_host = t0 + dt
+    if tele:
+        tele_samples = tele.stop()
+        tele_after = tele.snapshot()
+    e1 = step_ev[-1] if not emu else None
     dt_ev = e0.elapsed_time(e1) * 1e-3 if not emu else dt
+    gpu_done = [e0.elapsed_time(ev) * 1e-3 for ev in step_ev] if not emu else list(host_done)
+    step_ms = [(b - a) * 1e3 for a, b in zip([0.0] + gpu_done[:-1], gpu_done)]
     ks_same = True
     if world > 1:
         import torch.distributed as dist
@@ -535,11 +569,50 @@ def main():
     whole = {"achieved": achieved, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s", "frac": achieved / (PEAK_BF16 / 1e12),
              "note": "algorithmic FLOPs W_ref(k) = 2 bs F_fwd (k + 5 + a) summed over the timed steps / HIP-event time on the "
                      "compute stream (rank 0)"}
+    # ---- what the timed region looked like from the inside (round-4 verdict item 1): one HIP event per step, when the host
+    # had finished enqueueing each step, the per-step time normalised by the step's own work
+    a_share = F_FWD.get((args.arch, args.res), (0.0, ATTN_SHARE))[1]
+    fe = [k + 5 + a_share for k in timed_ks]                     # forward-equivalents of each timed step, W_ref(k) / (2 bs F_fwd)
+    per_fe = [m / f for m, f in zip(step_ms, fe)]
+    srt = sorted(step_ms)
+    half = max(1, len(per_fe) // 2)
+    out["timing"] = {
+        "step_ms": [round(x, 3) for x in step_ms], "k": timed_ks,
+        "step_ms_min_median_max": [srt[0], srt[len(srt) // 2], srt[-1]],
+        "sum_step_ms": sum(step_ms), "hip_event_ms": dt_ev * 1e3, "wall_ms": dt * 1e3,
+        "ms_per_forward_equivalent": [round(x, 4) for x in per_fe],
+        # a drift of the normalised step time along the loop = clocks (DVFS / power cap / temperature) moving under sustained load
+        "ms_per_forward_equivalent_first_half_vs_second_half": [sum(per_fe[:half]) / half, sum(per_fe[half:]) / max(1, len(per_fe) - half)],
+        # how far the host's enqueueing ran AHEAD of the GPU's completion of the same step: ~0 means the GPU waited for the host
+        "host_lead_ms": [round((g - h) * 1e3, 2) for g, h in zip(gpu_done, host_done)],
+        "host_enqueue_ms_per_step": host_done[-1] / args.steps * 1e3,
+        "note": "step_ms: differences of one HIP event per step on the compute stream (their sum is the headline's timed region); "
+                "host_lead_ms[i] = GPU completion time of step i - time the host returned from enqueueing it: positive = the GPU was "
+                "the bottleneck, near zero = the launch path was",
+    }
+    if tele:
+        out["telemetry"] = {"idle_before_warmup": tele_idle, "before_timed": tele_before, "after_timed": tele_after,
+                            "during_timed": Telemetry.summarize(tele_samples, t0, t1_host),
+                            "accumulated_over_timed": Telemetry.delta(tele_before, tele_after), "sampler_hz": args.telemetry_hz}
     try:
         if args.no_dominant or emu:
             raise RuntimeError("--no-dominant")
         st = fused._state[(args.bs, args.res // 8, args.res // 8)]
-        dom = dominant_kernel_roofline(st, sum(timed_ks) / len(timed_ks), dump_shapes=args.dump_shapes)
+        if tele:
+            tele.start(args.telemetry_hz)
+        try:
+            dom = dominant_kernel_roofline(st, sum(timed_ks) / len(timed_ks), dump_shapes=args.dump_shapes)
+        finally:
+            if tele:   # clocks while the launches were timed in isolation (bursts): the reference point for the loop's clocks
+                out["telemetry"]["during_isolated_launch_timing"] = Telemetry.summarize(tele.stop())
+        iso = dom.get("isolated_us")
+        if iso:
+            # busy fraction per step: isolated GPU time of the launches the step issues (fixed lists + k denoising passes) over
+            # the step's measured time.  Uniformly low with low clocks in `telemetry` = DVFS; dips on single steps = launch path
+            busy = [(iso["fixed"] + k * iso["per_denoise_pass"]) * 1e-3 / m for k, m in zip(timed_ks, step_ms)]
+            out["timing"]["gpu_busy_frac"] = [round(b, 4) for b in busy]
+            out["timing"]["gpu_busy_frac_mean"] = sum(busy) / len(busy)
+            out["timing"]["isolated_launch_sum_ms_per_step"] = sum(iso["fixed"] + k * iso["per_denoise_pass"] for k in timed_ks) * 1e-3 / len(timed_ks)
         # the roofline object is the DOMINANT KERNEL's (algorithmic FLOPs per launch / its average launch duration);
         # the whole-step figure rides along
         out["roofline"] = {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",

@@ -169,12 +169,12 @@ class FusedStep:
             self._state[key] = self._state.pop(key)      # most recently used last
         if st is None:
             while len(self._state) >= self.MAX_BUCKETS:   # dynamic_resolution: do not pin every bucket's buffers
-                old = next(iter(self._state))
-                self._state.pop(old)
+                old = self._state.pop(next(iter(self._state)))
                 eng = self.unet.engine()
-                ob, oh, ow = old
-                for pk in [k_ for k_ in eng.plans if k_[0] in (2 * ob, 6 * ob) and k_[1:3] == (oh, ow)]:
-                    eng.drop_plan(pk)
+                # exactly the evicted bucket's three plans: another resident bucket at the same (h, w) may own a plan whose
+                # batch collides (bs = 1 frozen pass and bs = 3 denoising pass are both UNet batch 6)
+                for pl in (old["plan"], old["dplan"], old["fplan"]):
+                    eng.drop_plan(pl.key)
             plan = self.unet.prepare((2 * bs, 4, h, w), lora_on=True)
             eng = self.unet.engine()
             # the k partial-denoising passes never see a backward: they run on their own forward-only plan
@@ -528,7 +528,7 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
     network = LoRANetwork(unet, rank=config.network.rank, multiplier=1.0, alpha=config.network.alpha,
                           train_method=config.network.training_method, target_replace_modules=modules,
                           strict_reference=strict_reference,
-                          strict_dtype=weight_dtype if weight_dtype != torch.float32 else torch.bfloat16).to(device, dtype=weight_dtype)
+                          strict_dtype=weight_dtype).to(device, dtype=weight_dtype)   # float32: the round trip is a no-op, like network.to(dtype=weight_dtype)
 
     if world > 1:
         # ... and from here on every rank draws its OWN prompt pair / resolution / crops / latents (the reference's
@@ -624,10 +624,14 @@ def train(config: RootConfig, prompts: List[PromptSettings], device: Optional[to
     for i in it:
         if i < start:
             continue
-        timesteps_to, cls, shared_hw = draw_shared()
-        if cls is None:
+        if shape_gen is None:
+            # single process: the reference's order on the ONE global CPU stream -- prompt pair, then timesteps_to, then
+            # (below) the resolution bucket and the latents (train_lora.py:148-156,162-177), so a seeded run reproduces the
+            # reference's (pair, k, resolution, latents) sequence
             pair = prompt_pairs[torch.randint(0, len(prompt_pairs), (1,)).item()]
+            timesteps_to, cls, shared_hw = draw_shared()
         else:
+            timesteps_to, cls, shared_hw = draw_shared()
             members = class_members[cls]
             pair = prompt_pairs[members[torch.randint(0, len(members), (1,)).item()]]
         height, width = pair.resolution, pair.resolution

@@ -359,6 +359,7 @@ class Plan:
         self.bwd: List[ops.Op] = self.lists["bwd"]
         self.bufs: Dict[str, torch.Tensor] = {}
         self.graphs: Dict[str, C.c_void_p] = {}
+        self.key: Optional[tuple] = None      # its key in Engine.plans (set by Engine.plan)
 
 
 class Engine:
@@ -533,8 +534,11 @@ class Engine:
             key = key + ("share", share)
         if key not in self.plans:
             with ops.f32_mode(self.f32):
+                # (the side workspace of forked sections is allocated by `PlanBuilder.forked()` on first use: 128 MB that
+                # training plans and LECO_FORK=0 -- the default -- never touch)
                 self.plans[key] = PlanBuilder(self, B, h, w, need_bwd, ws=self.workspace_slot(ws_slot), share=share,
-                                              ws_side=self.workspace_slot(ws_slot + 2)).build()
+                                              ws_side_slot=ws_slot + 2).build()
+                self.plans[key].key = key
         return self.plans[key]
 
     def workspace_slot(self, slot: int) -> torch.Tensor:
@@ -570,10 +574,10 @@ class Engine:
 
 class PlanBuilder:
     def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True, ws: Optional[torch.Tensor] = None,
-                 share: int = 1, ws_side: Optional[torch.Tensor] = None):
+                 share: int = 1, ws_side_slot: int = 2):
         self.eng, self.cfg, self.dev = eng, eng.cfg, eng.device
         self.share = share
-        self._ws_side = ws_side                                # split-K slabs of the launches of forked sections
+        self._ws_side_slot = ws_side_slot                      # split-K slabs of the launches of forked sections (lazily allocated)
         self.Bfull = B          # (self.B is lowered to B / share while the batch-shared prefix is built)
         self.ws = eng.workspace if ws is None else ws      # split-K slabs of this plan's launches
         self.B, self.h, self.w = B, h, w
@@ -634,7 +638,7 @@ class PlanBuilder:
     def forked(self):
         n_on, n_off = len(self.f_on), len(self.f_off)
         self.both(ops.Op("leco_fork", ()))
-        ws_main, self.ws = self.ws, (self._ws_side if self._ws_side is not None else self.eng.workspace_slot(2))
+        ws_main, self.ws = self.ws, self.eng.workspace_slot(self._ws_side_slot)
         try:
             yield
         finally:
@@ -1525,10 +1529,10 @@ class UNet2DConditionModel(nn.Module):
                 adopt_forward_patches(self)
             return
         if patched:
-            owned = {id(getattr(l, "fm", None)) for l in net.unet_loras}
+            owned = {id(l.fm) for l in net.unet_loras if getattr(l, "fm", None) is not None}
             for n, m in patched:
-                fm = getattr(m.__dict__["forward"], "__self__", None)
-                if id(fm) not in owned:
+                fm = getattr(m.__dict__["forward"], "__self__", None)     # a plain function / closure has no __self__
+                if fm is None or id(fm) not in owned:
                     raise RuntimeError(f"{n}.forward was re-assigned after a LoRA network had been attached, by something that is "
                                        "not part of that network: the launch plans would silently ignore it.")
 

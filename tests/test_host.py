@@ -180,6 +180,42 @@ def test_ldm_key_layout_known_names_and_counts():
     assert len(known and ldm) > 0
 
 
+@pytest.mark.parametrize("arch", ["sd15", "sd21", "sdxl"])
+def test_ldm_converter_against_the_public_checkpoint_key_list(arch):
+    """N1 pinned to something that is NOT `ckpt_convert`: tests/golden/ldm_unet_keys.json holds every UNet tensor name +
+    shape of the released single-file checkpoints (686 / 686 / 1680 tensors, 859 520 964 / 865 910 724 / 2 567 463 684
+    parameters -- the public totals), produced by oracle/ldm_unet_keys.py, a restatement of the CONSTRUCTOR of the public
+    LDM / SGM `UNetModel` that shares no code with the converter (whose map is derived from the diffusers block structure).
+    `detect_unet_config` must recognise the architecture from those shapes, `convert_ldm_unet` must map the full list
+    ONE-TO-ONE onto the state-dict keys of the fp32 oracle UNet (oracle/unet_ref.py, the diffusers-0.20 layout) and of the
+    HIP-backed module, every shape matching."""
+    import json
+    from leco_amd import ckpt_convert as cc
+    from leco_amd import unet as U
+    from oracle import ldm_unet_keys as L
+    from oracle import unet_ref as R
+    fixture = json.load(open(os.path.join(ROOT, "tests", "golden", "ldm_unet_keys.json")))[arch]
+    assert fixture == L.ldm_unet_keys(arch)                       # the committed generator made the committed list
+    n_pub, p_pub = L.PUBLIC_COUNTS[arch]
+    assert len(fixture) == n_pub and sum(L.numel(s) for s in fixture.values()) == p_pub
+    sd = {k: torch.empty(shape, device="meta") for k, shape in fixture.items()}
+    # what else a released file holds must be ignored: VAE, text encoder, EMA bookkeeping
+    sd["first_stage_model.decoder.conv_in.weight"] = torch.empty(512, 4, 3, 3, device="meta")
+    sd["model_ema.decay"] = torch.empty((), device="meta")
+    cfg = cc.detect_unet_config(sd)
+    assert cfg == getattr(U, arch + "_config")()
+    conv = cc.convert_ldm_unet(sd, cfg)
+    assert len(conv) == len(fixture)                               # no two checkpoint tensors land on one name
+    with torch.device("meta"):
+        want = {"oracle": R.UNet2DConditionModel(getattr(R, arch + "_config")()).state_dict(),
+                "hip module": U.UNet2DConditionModel(cfg).state_dict()}
+    for who, w in want.items():
+        assert set(conv) == set(w), (who, sorted(set(conv) ^ set(w))[:6])
+        bad = [k for k in w if tuple(conv[k].shape) != tuple(w[k].shape)]
+        assert not bad, (who, bad[:6])
+    assert set(cc.diffusers_unet_to_ldm(conv, cfg)) == set(fixture)
+
+
 def test_single_file_checkpoint_round_trip(tmp_path):
     from safetensors.torch import save_file
     from leco_amd import ckpt_convert as cc, model_util

@@ -214,3 +214,96 @@ def test_reference_lora_network_applied_to_this_unet_is_adopted(ref):
     assert rel(y0, ru(x, torch.tensor(500), encoder_hidden_states=ctx).sample) < 1e-4
     sa, sb = rnet.state_dict(), fnet.state_dict()
     assert list(sa) == list(sb) and all(rel(sb[k], sa[k]) < 1e-4 for k in sa if "lora_up" in k)
+
+
+# ---- N2: the prompt-encoding front end against the reference's OWN loader and glue -------------------------------------
+def _clip_folder(tmp_path, layers, with_projection_2=False):
+    """A real `transformers` CLIP text stack on disk in the diffusers folder layout (reduced width, synthetic BPE vocabulary):
+    tokenizer/, text_encoder/ (+ tokenizer_2/, text_encoder_2/ with a projection head for the XL glue)."""
+    import shutil
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host import _write_synthetic_clip
+    folder = str(tmp_path / f"clip{layers}")
+    te = _write_synthetic_clip(folder, hidden=64, layers=layers)
+    te.save_pretrained(os.path.join(folder, "text_encoder"))
+    te2 = None
+    if with_projection_2:
+        from transformers import CLIPTextModelWithProjection
+        shutil.copytree(os.path.join(folder, "tokenizer"), os.path.join(folder, "tokenizer_2"))
+        torch.manual_seed(1)
+        te2 = CLIPTextModelWithProjection(te.config.__class__(**{**te.config.to_dict(), "hidden_size": 128, "intermediate_size": 256,
+                                                                  "num_attention_heads": 2, "projection_dim": 96}))
+        te2.save_pretrained(os.path.join(folder, "text_encoder_2"))
+    return folder
+
+
+PROMPTS = ["van gogh", "", "a b c " * 60, "monet water lilies"]      # incl. the empty prompt and one that is truncated at 77
+
+
+@pytest.mark.parametrize("v2,clip_skip", [(False, None), (False, 2), (True, None), (True, 3)])
+def test_prompt_front_end_equals_the_reference_loader_and_glue(ref, tmp_path, monkeypatch, v2, clip_skip):
+    """N2 pinned to the reference: ITS `model_util.load_diffusers_model` (model_util.py:29-72; only the tokenizer's hub name is
+    pointed at the local folder and the stub UNet class gets a no-op `from_pretrained`) and ITS `train_util.text_tokenize /
+    text_encode / encode_prompts` (train_util.py:60-87) against this package's loader and glue on the same folder:
+    SD1 (12 layers) and SD2 (24 layers, penultimate layer by default), `clip_skip` None / 1 / 2 / 3 -- same layer count, same
+    weights, identical token ids and identical embeddings."""
+    from leco_amd import model_util, train_util
+    rmu = importlib.import_module("model_util")
+    assert rmu.__file__.startswith(REF)
+    folder = _clip_folder(tmp_path, 24 if v2 else 12)
+    monkeypatch.setattr(rmu, "TOKENIZER_V1_MODEL_NAME", folder)
+    monkeypatch.setattr(rmu, "TOKENIZER_V2_MODEL_NAME", folder)
+    monkeypatch.setattr(rmu.UNet2DConditionModel, "from_pretrained", classmethod(lambda cls, *a, **k: None), raising=False)
+    r_tok, r_enc, _ = rmu.load_diffusers_model(folder, v2=v2, clip_skip=clip_skip)
+    # (our loader also opens unet/: give it the smallest valid one)
+    import json
+    from safetensors.torch import save_file
+    from leco_amd.unet import UNet2DConditionModel
+    cfg = model_util.tiny_config()
+    os.makedirs(os.path.join(folder, "unet"))
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.__dict__.items()},
+              open(os.path.join(folder, "unet", "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in model_util.init_synthetic_(UNet2DConditionModel(cfg), 3).state_dict().items()},
+              os.path.join(folder, "unet", "diffusion_pytorch_model.safetensors"))
+    o_tok, o_enc, _ = model_util.load_diffusers_model(folder, v2=v2, clip_skip=clip_skip)
+    full = 24 if v2 else 12
+    expect = full - (clip_skip - 1) if clip_skip is not None else (23 if v2 else 12)       # model_util.py:46,60
+    assert r_enc.config.num_hidden_layers == o_enc.config.num_hidden_layers == expect
+    rs, os_ = r_enc.state_dict(), o_enc.state_dict()
+    assert list(rs) == list(os_) and all(torch.equal(rs[k], os_[k]) for k in rs)
+    rt, ot = ref["train_util"], train_util
+    tok_r, tok_o = rt.text_tokenize(r_tok, PROMPTS), ot.text_tokenize(o_tok, PROMPTS)
+    assert tok_r.shape == (len(PROMPTS), 77) and torch.equal(tok_r, tok_o)
+    with torch.no_grad():
+        assert torch.equal(rt.text_encode(r_enc, tok_r), ot.text_encode(o_enc, tok_o))
+        e_r, e_o = rt.encode_prompts(r_tok, r_enc, PROMPTS), ot.encode_prompts(o_tok, o_enc, PROMPTS)
+    assert e_r.shape == (len(PROMPTS), 77, 64) and torch.equal(e_r, e_o)
+    assert not torch.equal(e_o[0], e_o[1]) and torch.isfinite(e_o).all()
+
+
+@pytest.mark.parametrize("n_img", [1, 2])
+def test_prompt_front_end_xl_glue_equals_the_reference(ref, tmp_path, n_img):
+    """N2, XL: the reference's `text_encode_xl` / `encode_prompts_xl` (train_util.py:90-130: penultimate hidden state of both
+    encoders concatenated, pooled output of the second, `num_images_per_prompt` repeats) against this package's on real
+    `CLIPTextModel` + `CLIPTextModelWithProjection` objects loaded by `load_models_xl` from a folder."""
+    import json
+    from safetensors.torch import save_file
+    from leco_amd import model_util, train_util
+    from leco_amd.unet import UNet2DConditionModel
+    folder = _clip_folder(tmp_path, 4, with_projection_2=True)
+    cfg = model_util.tiny_xl_config()
+    os.makedirs(os.path.join(folder, "unet"))
+    json.dump({k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg.__dict__.items()},
+              open(os.path.join(folder, "unet", "config.json"), "w"))
+    save_file({k: v.contiguous() for k, v in model_util.init_synthetic_(UNet2DConditionModel(cfg), 3).state_dict().items()},
+              os.path.join(folder, "unet", "diffusion_pytorch_model.safetensors"))
+    toks, encs, _, _ = model_util.load_models_xl(folder, "ddim")
+    rt, ot = ref["train_util"], train_util
+    with torch.no_grad():
+        for tok, enc in zip(toks, encs):
+            ids = rt.text_tokenize(tok, PROMPTS)
+            a, b = rt.text_encode_xl(enc, ids, n_img), ot.text_encode_xl(enc, ids, n_img)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        (e_r, p_r), (e_o, p_o) = rt.encode_prompts_xl(toks, encs, PROMPTS, n_img), ot.encode_prompts_xl(toks, encs, PROMPTS, n_img)
+    assert e_r.shape == (len(PROMPTS) * n_img, 77, 64 + 128) and p_r.shape == (len(PROMPTS) * n_img, 96)
+    assert torch.equal(e_r, e_o) and torch.equal(p_r, p_o)

@@ -539,9 +539,67 @@ def test_plan_buckets_are_evicted_lru(dev):
         return {op.args[3] for op in plan.lists["fwd_off"] if op.name.endswith("gemm_ex") and op.args[3]}
     # (launches of forked sections -- conv_shortcut beside conv1 -- own a further slot per plan slot)
     assert ws_args(p0) <= {ws0, eng.workspace_slot(2).data_ptr()} and ws_args(p1) <= {ws1, eng.workspace_slot(3).data_ptr()} and ws1 in ws_args(p1)
+    own = [fs._state[(1, 8, 8)][n].key for n in ("plan", "dplan", "fplan")]
     fs._bucket(1, 16, 16)
-    fs._bucket(1, 16, 8)                       # (1, 8, 8) is the oldest now: gone with BOTH frozen plans
-    assert not resident(6, 8, 8, False) and (6, 8, 8, False, 1) not in eng.plans
+    fs._bucket(1, 16, 8)                       # (1, 8, 8) is the oldest now: gone with exactly ITS three plans ...
+    assert not any(k in eng.plans for k in own)
+    # ... while plans somebody built directly on the engine are not the bucket's to drop
+    assert (6, 8, 8, False) in eng.plans and (6, 8, 8, False, 1) in eng.plans
+    eng.drop_plan((6, 8, 8, False, 1))
+    assert (6, 8, 8, False, 1) not in eng.plans
+
+
+def test_bucket_eviction_drops_exactly_the_evicted_plans(dev):
+    """Prompt batch 1 and prompt batch 3 at one (h, w) collide on the UNet batch (frozen pass 6 x 1 = denoising pass 2 x 3):
+    evicting one bucket must drop ITS plans only (round-4 advice: the surviving bucket's frozen plan was destroyed)."""
+    m = hip_unet(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
+    fs = FusedStep(m, net, create_noise_scheduler("ddim"), N_STEPS, lr=1e-3)
+    fs.MAX_BUCKETS = 2
+    eng = m.engine()
+    st1 = fs._bucket(1, 8, 8)
+    st3 = fs._bucket(3, 8, 8)
+    assert st1["fplan"].key != st3["dplan"].key and st1["fplan"].key[0] == st3["dplan"].key[0] == 6
+    fs._bucket(1, 16, 8)                       # evicts the oldest bucket: (1, 8, 8)
+    assert list(fs._state) == [(3, 8, 8), (1, 16, 8)]
+    assert st3["dplan"].key in eng.plans and st3["fplan"].key in eng.plans and st3["plan"].key in eng.plans
+    assert st1["fplan"].key not in eng.plans and st1["dplan"].key not in eng.plans and len(st3["dplan"].lists["denoise"]) > 0
+
+
+def test_single_process_train_draws_in_the_reference_order(dev, tmp_path, monkeypatch):
+    """train_lora.py:148-177 draws, per iteration and all from the ONE global CPU stream: the prompt pair, then
+    `timesteps_to`, then (dynamic_resolution) the bucket, then the latents.  A seeded single-process run must reproduce that
+    sequence (round-4 advice: the shared-generator ordering of the data-parallel path had leaked into it)."""
+    from leco_amd import train as T
+    prompts = [prompt_util.PromptSettings(target=t, positive=t, unconditional="", neutral="", action="erase", guidance_scale=1.0,
+                                          resolution=128, dynamic_resolution=True, batch_size=1) for t in ("a", "b", "c")]
+    seen = []
+    monkeypatch.setattr(T.FusedStep, "step", lambda self, pair, k, latents, **kw: seen.append(
+        (pair.target.flatten()[0].item(), int(k), tuple(latents.shape), latents.flatten()[0].item())) or torch.zeros(1))
+    cfg = _tiny_train_config(tmp_path, "order", 4, )
+    cfg.train.max_denoising_steps = 10
+    torch.manual_seed(77)
+    with contextlib.redirect_stdout(io.StringIO()):
+        T.train(cfg, prompts, device=dev, use_graphs=False, progress=False)
+    # the same stream consumed in the reference's order
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, enc, _, sched = model_util.load_models("synthetic:tiny", "ddim")
+    from leco_amd import train_util
+    embeds = {t: enc([t])[0].to(bf).float() for t in ("a", "b", "c")}       # train() holds the text encoder in train.precision
+    torch.manual_seed(77)
+    # (model construction and the LoRA init consume the stream before the loop: replay them the same way)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = model_util.load_models("synthetic:tiny", "ddim")[2]
+        LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
+    want = []
+    for _ in range(4):
+        pi = torch.randint(0, 3, (1,)).item()
+        k = torch.randint(1, 10, (1,)).item()
+        h, w = train_util.get_random_resolution_in_bucket(128)
+        lat = train_util.get_initial_latents(sched, 1, h, w, 1)
+        want.append((embeds["abc"[pi]].flatten()[0].item(), k, tuple(lat.shape), lat.flatten()[0].item()))
+    assert seen == want
 
 
 def test_infer_xl_script_samples_with_a_trained_lora(dev, tmp_path):
