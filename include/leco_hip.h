@@ -308,6 +308,20 @@ int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream);
  * several samples (the two halves of predict_noise's cat([latents] * 2), train_util.py:151, before the first use of the
  * prompt embeddings) */
 int leco_repeat(const void* src, void* dst, int64_t bytes, int32_t reps, leco_stream_t stream);
+/* Step glue of the reference loop body as two launches (the tensors the reference moves with framework ops between its
+ * UNet calls, train_lora.py:175-199):
+ *   leco_step_begin: x2 = cat([scale x] * 2) in the activation dtype (bf16, or fp32 when x2_is_f32) -- the first UNet input
+ *     of `diffusion` (train_util.py:151-153,172-193; scale = scale_model_input of the first step, 1 for DDIM) -- and
+ *     *t_idx = 0 (the denoising pass counter; may be NULL).
+ *   leco_step_mid: after the k denoising passes the last UNet input IS cat([denoised] * 2); it becomes the input of the
+ *     LoRA-on target pass (dst_a, may be NULL) and, `reps_b` times back to back, of the batched LoRA-off passes (dst_b)
+ *     (train_lora.py:202-256); `current_timestep` (train_lora.py:195-199) is stored into both plans' timestep tables
+ *     (t_slot_*: the slot's address) and both step indices are pointed at that slot.  bytes: multiple of 16. */
+int leco_step_begin(const float* x, void* x2, int32_t x2_is_f32, float scale, int64_t half_n, int32_t* t_idx,
+                    leco_stream_t stream);
+int leco_step_mid(const void* src, void* dst_a, void* dst_b, int64_t bytes, int32_t reps_b, float t_cur,
+                  float* t_slot_a, float* t_slot_b, int32_t* t_idx_a, int32_t* t_idx_b, int32_t slot,
+                  leco_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Row-stripe fused transformer-block kernels (csrc/stripe.hip): forward-only, bf16, C = 320 (the 64^2 level of SD1.x /

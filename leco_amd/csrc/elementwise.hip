@@ -855,6 +855,52 @@ extern "C" int leco_repeat(const void* src, void* dst, int64_t bytes, int32_t re
     hipLaunchKernelGGL(repeat_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, LECO_STREAM, (const u32x4*)src, (u32x4*)dst, bytes / 16, reps);
     return check_launch("leco_repeat");
 }
+// ---- step glue (leco_amd/train.py::FusedStep.step): the tiny tensor copies between the launch plans of one optimizer step
+// (train_lora.py:175-199: initial latents -> cat([latents] * 2); denoised latents -> the inputs of the four remaining
+// passes + their timestep) as TWO launches instead of ~15 framework copies with a 10-25 us bubble each.
+template <typename T>
+__global__ __launch_bounds__(256) void step_begin_kernel(const float* x, T* x2, float scale, int64_t half_n, int* t_idx) {
+    if (t_idx && blockIdx.x == 0 && threadIdx.x == 0) *t_idx = 0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < half_n; e += (int64_t)gridDim.x * 256) {
+        const float v = x[e] * scale;
+        T o;
+        if constexpr (sizeof(T) == 4) o = v; else o = f2bf(v);
+        x2[e] = o;
+        x2[half_n + e] = o;
+    }
+}
+extern "C" int leco_step_begin(const float* x, void* x2, int32_t x2_is_f32, float scale, int64_t half_n, int32_t* t_idx,
+                               leco_stream_t stream) {
+    if (!x || !x2 || half_n <= 0) return fail(-EINVAL, "leco_step_begin: half_n=%lld", (long long)half_n);
+    if (x2_is_f32)
+        hipLaunchKernelGGL(step_begin_kernel<float>, dim3(grid_for(half_n)), dim3(256), 0, LECO_STREAM, x, (float*)x2, scale, half_n, (int*)t_idx);
+    else
+        hipLaunchKernelGGL(step_begin_kernel<bf16_t>, dim3(grid_for(half_n)), dim3(256), 0, LECO_STREAM, x, (bf16_t*)x2, scale, half_n, (int*)t_idx);
+    return check_launch("leco_step_begin");
+}
+__global__ __launch_bounds__(256) void step_mid_kernel(const u32x4* src, u32x4* dst_a, u32x4* dst_b, int64_t n16, int reps_b,
+                                                        float t_cur, float* t_a, float* t_b, int* i_a, int* i_b, int slot) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (t_a) *t_a = t_cur;
+        if (t_b) *t_b = t_cur;
+        if (i_a) *i_a = slot;
+        if (i_b) *i_b = slot;
+    }
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n16; e += (int64_t)gridDim.x * 256) {
+        const u32x4 v = src[e];
+        if (dst_a) dst_a[e] = v;
+        for (int r = 0; r < reps_b; ++r) dst_b[(int64_t)r * n16 + e] = v;
+    }
+}
+extern "C" int leco_step_mid(const void* src, void* dst_a, void* dst_b, int64_t bytes, int32_t reps_b, float t_cur,
+                             float* t_slot_a, float* t_slot_b, int32_t* t_idx_a, int32_t* t_idx_b, int32_t slot,
+                             leco_stream_t stream) {
+    if (!src || bytes <= 0 || bytes % 16 || reps_b < 0 || (reps_b && !dst_b))
+        return fail(-EINVAL, "leco_step_mid: bytes=%lld (multiple of 16), reps_b=%d", (long long)bytes, reps_b);
+    hipLaunchKernelGGL(step_mid_kernel, dim3(grid_for(bytes / 16)), dim3(256), 0, LECO_STREAM, (const u32x4*)src, (u32x4*)dst_a,
+                       (u32x4*)dst_b, bytes / 16, reps_b, t_cur, t_slot_a, t_slot_b, (int*)t_idx_a, (int*)t_idx_b, slot);
+    return check_launch("leco_step_mid");
+}
 extern "C" int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream) {
     hipError_t e = hipMemsetAsync(p, value, (size_t)bytes, LECO_STREAM);
     if (e != hipSuccess) return fail(-EIO, "leco_memset: %s", hipGetErrorString(e));

@@ -47,6 +47,8 @@ _SIGS = {
     "leco_cast_f32_bf16": [_vp, _vp, _i64, _vp],
     "leco_memset": [_vp, _i32, _i64, _vp],
     "leco_repeat": [_vp, _vp, _i64, _i32, _vp],
+    "leco_step_begin": [_vp, _vp, _i32, _f32, _i64, _vp, _vp],
+    "leco_step_mid": [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp],
     "leco_fork": [_vp], "leco_join": [_vp],
     "leco_lora_pack": [_vp, _i32, _vp],
     "leco_lora_wgrad_conv": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32,
@@ -323,6 +325,23 @@ def memset(t: torch.Tensor, value: int = 0) -> Op:
 def repeat(src: int, dst: int, nbytes: int, reps: int, keep=None) -> Op:
     """dst = `reps` back-to-back copies of the `nbytes` at src (raw device addresses)."""
     return Op("leco_repeat", (src, dst, nbytes, reps), keep=keep)
+
+
+def step_begin(x: torch.Tensor, x2: torch.Tensor, scale: float, half_n: int, t_idx: Optional[torch.Tensor]) -> Op:
+    """x2 = cat([scale x] * 2) in x2's dtype (bf16 / fp32), *t_idx = 0: the first UNet input of the denoising passes."""
+    return Op("leco_step_begin", (ptr(x), ptr(x2), 1 if x2.dtype == torch.float32 else 0, float(scale), half_n, ptr(t_idx)),
+              keep=(x, x2, t_idx))
+
+
+def step_mid(src: torch.Tensor, dst_a: Optional[torch.Tensor], dst_b: Optional[torch.Tensor], reps_b: int, t_cur: float,
+             plan_a, plan_b, slot: int) -> Op:
+    """dst_a = src, dst_b = `reps_b` copies of src; both plans' timestep slot `slot` = t_cur and their step index -> slot."""
+    nbytes = src.numel() * src.element_size()
+    ta = None if plan_a is None else plan_a.t_table.data_ptr() + 4 * slot
+    tb = None if plan_b is None else plan_b.t_table.data_ptr() + 4 * slot
+    return Op("leco_step_mid", (ptr(src), ptr(dst_a), ptr(dst_b), nbytes, reps_b, float(t_cur), ta, tb,
+                                None if plan_a is None else ptr(plan_a.t_idx), None if plan_b is None else ptr(plan_b.t_idx), slot),
+              keep=(src, dst_a, dst_b))
 
 
 def lora_pack(sites_dev: torch.Tensor, nsites: int) -> Op:

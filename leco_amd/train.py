@@ -149,6 +149,43 @@ class FusedStep:
         self.overlap = (os.environ.get("LECO_OVERLAP_FROZEN", "0") not in ("", "0") and dev.type == "cuda"
                         and torch.cuda.is_available())
         self._side = torch.cuda.Stream(device=dev) if self.overlap else None
+        self._pin = {}          # (numel, dtype) -> ring of pinned host staging buffers (`_h2d`)
+
+    # ---- host -> device copies that do not stall the host -------------------------------------------------------
+    N_PIN = 4
+
+    def _h2d(self, dst: torch.Tensor, src: torch.Tensor) -> None:
+        """``dst.copy_(src)`` for a CPU ``src`` without blocking the host.  A copy from PAGEABLE host memory is synchronous:
+        the call returns only after the stream has executed everything queued in front of it -- i.e. the whole previous
+        optimizer step (round-5 measurement: the host sat in the initial-latents copy of step i + 1 until step i had
+        finished on the GPU, so every host hiccup at a step boundary -- a loaded box, a slow wake-up -- was added to the
+        step time).  Staged through a small ring of pinned buffers the copy is asynchronous and the host runs up to
+        ``N_PIN`` steps ahead of the GPU."""
+        if self.dev.type != "cuda" or src.device.type != "cpu":
+            dst.copy_(src)
+            return
+        key = (src.numel(), src.dtype)
+        ring = self._pin.get(key)
+        if ring is None:
+            ring = self._pin[key] = {"buf": [torch.empty(src.numel(), dtype=src.dtype, pin_memory=True) for _ in range(self.N_PIN)],
+                                     "ev": [None] * self.N_PIN, "i": 0}
+        i = ring["i"]
+        ring["i"] = (i + 1) % self.N_PIN
+        if ring["ev"][i] is not None:
+            ring["ev"][i].synchronize()      # this slot's previous copy has left the host buffer (N_PIN steps ago)
+        buf = ring["buf"][i]
+        buf.copy_(src.reshape(-1))
+        dst.copy_(buf.view(dst.shape) if dst.is_contiguous() else buf.reshape(dst.shape), non_blocking=True)
+        ev = ring["ev"][i] = ring["ev"][i] or torch.cuda.Event()
+        ev.record()
+
+    @staticmethod
+    def _set_ctx(plan, ctx: torch.Tensor) -> None:
+        """plan.ctx <- ctx unless it already holds THIS tensor (the cached embeddings of a prompt pair never change: the
+        same pair on consecutive steps costs no copy)."""
+        if getattr(plan, "ctx_src", None) is not ctx:
+            plan.ctx.copy_(ctx)
+            plan.ctx_src = ctx
 
     def _scale_at(self, t_train: int) -> float:
         """scale_model_input factor at train timestep `t_train` of the 1000-step schedule (train_lora.py:195-199)."""
@@ -207,6 +244,8 @@ class FusedStep:
             # denoising passes of a step share one evaluation ("ctx_on"), the per-pass list skips those ops
             dplan.lists["ctx_on"] = [op for op in dplan.lists["fwd_on"] if op.tag == "ctx"]
             dplan.lists["denoise"] = [op for op in dplan.lists["fwd_on"] if op.tag != "ctx"] + tail
+            # the denoising plan is private to this object: its timestep table is the scheduler's, once
+            dplan.t_table[:self.n_steps].copy_(self.ts_f)
             self._state[key] = st
         return st
 
@@ -261,21 +300,22 @@ class FusedStep:
         net.multiplier = 1.0
         unet.prepare((2 * bs, 4, h, w), lora_on=True)   # re-packs LoRA operands if the slab changed
         x = st["x"]
-        x.copy_(latents.to(self.dev, torch.float32))
+        if latents.device.type == "cpu":
+            self._h2d(x, latents.to(torch.float32))
+        else:
+            x.copy_(latents)
         dplan = st["dplan"]
-        x_first = x * self.first_scale if self.generic else x        # scale_model_input of the first step
-        dplan.x_in.copy_(torch.cat([x_first, x_first]).to(self.adt))
+        # first UNet input cat([scale_model_input(x)] * 2) + pass counter = 0: one launch (leco_step_begin)
+        ops.step_begin(x, dplan.x_in, self.first_scale if self.generic else 1.0, st["half_n"], dplan.t_idx).run()
         if self.generic and st["hist"] is not None:
             st["hist"].zero_()
-        dplan.ctx.copy_(self._ctx(pair, "target", bs))
+        self._set_ctx(dplan, self._ctx(pair, "target", bs))
         xl = self.unet.cfg.addition_embed_type == "text_time"
         if xl:
             ids = add_time_ids.reshape(1, 6).to(self.dev, torch.float32)
             for pl in (dplan, plan):
                 pl.time_ids.copy_(ids.repeat(2 * bs, 1).reshape(-1))
                 pl.text_embeds.copy_(self._pooled(pair, "target", bs))
-        dplan.t_table[:n].copy_(self.ts_f)
-        dplan.t_idx.zero_()
         self._run(dplan, "ctx_on")
         for i in range(k):
             if self.generic and st["noise"] is not None:
@@ -288,27 +328,25 @@ class FusedStep:
         # 2. frozen predictions at the "current" timestep (train_lora.py:195-237)
         trace.push("frozen predictions")
         t_cur = int(self.sched.num_train_timesteps - 1 - int(k * self.sched.num_train_timesteps / n))
+        fplan = st["fplan"]
         if self.generic:
             # sigma-space schedulers: the UNet input of the remaining passes is x / sqrt(sigma(t_cur)^2 + 1)
             sc = self._scale_at(t_cur)
-            self.coef[n, 6:7].copy_(torch.tensor([sc], dtype=torch.float32), non_blocking=True)
+            self._h2d(self.coef[n, 6:7], torch.tensor([sc], dtype=torch.float32))
             with ops.f32_mode(unet.engine().f32):
                 ops.cfg_sched_step(None, x, plan.x_in, self.coef, self.fin_idx, 0.0, st["half_n"]).run()
+            src_x2, dst_a = plan.x_in, None
         else:
-            plan.x_in.copy_(dplan.x_in)
-        plan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])
-        plan.t_idx.copy_(self.slot_idx)
+            src_x2, dst_a = dplan.x_in, plan.x_in      # the last denoising pass left cat([denoised] * 2) as its next input
+        # inputs + `current_timestep` of the four remaining passes (train_lora.py:195-256): one launch (leco_step_mid)
+        ops.step_mid(src_x2, dst_a, fplan.x_in, 3, float(t_cur), plan, fplan, self.single_slot).run()
         net.multiplier = 0
-        fplan = st["fplan"]
-        fplan.x_in.copy_(plan.x_in.repeat(3, 1, 1, 1))
-        fplan.ctx.copy_(self._ctx3(pair, bs))
+        self._set_ctx(fplan, self._ctx3(pair, bs))
         if xl:
             fplan.time_ids.copy_(ids.repeat(6 * bs, 1).reshape(-1))
             fplan.text_embeds.copy_(torch.cat([self._pooled(pair, w_, bs) for w_ in ("positive", "neutral", "unconditional")]))
-        fplan.t_table[self.single_slot:self.single_slot + 1].copy_(self.all_t[t_cur:t_cur + 1])
-        fplan.t_idx.copy_(self.slot_idx)
         if self.overlap:      # inputs of both passes are in place: fork
-            plan.ctx.copy_(self._ctx(pair, "target", bs))
+            self._set_ctx(plan, self._ctx(pair, "target", bs))
             cur = torch.cuda.current_stream()
             self._side.wait_stream(cur)
             with torch.cuda.stream(self._side):
@@ -320,7 +358,7 @@ class FusedStep:
         trace.push("target forward")
         net.multiplier = 1.0
         if not self.overlap:
-            plan.ctx.copy_(self._ctx(pair, "target", bs))
+            self._set_ctx(plan, self._ctx(pair, "target", bs))
         self._run(plan, "fwd_on")
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self._side)      # join before the loss reads the frozen predictions
@@ -352,8 +390,8 @@ class FusedStep:
         self.opt_step += 1
         b1, b2 = self.betas
         lr = self.lr if lr is None else lr
-        net.hyper.copy_(torch.tensor([lr, 1 - b1 ** self.opt_step, 1 - b2 ** self.opt_step, 1.0 / self.world]),
-                        non_blocking=True)
+        self._h2d(net.hyper, torch.tensor([lr, 1 - b1 ** self.opt_step, 1 - b2 ** self.opt_step, 1.0 / self.world],
+                                          dtype=torch.float32))
         if isinstance(self.optimizer, str) and self.optimizer in ("adam", "adamw"):
             ops.adamw(net.slab.detach(), net.grad, net.exp_avg, net.exp_avg_sq, net.shadow, net.hyper, b1, b2, self.eps,
                       self.wd, net.slab.numel()).run()

@@ -360,6 +360,7 @@ class Plan:
         self.bufs: Dict[str, torch.Tensor] = {}
         self.graphs: Dict[str, C.c_void_p] = {}
         self.key: Optional[tuple] = None      # its key in Engine.plans (set by Engine.plan)
+        self.ctx_src = None                   # the tensor `ctx` was last filled from (FusedStep skips identical refills)
 
 
 class Engine:
@@ -1543,6 +1544,7 @@ class UNet2DConditionModel(nn.Module):
         plan = self.prepare(sample.shape, lora_on)
         plan.x_in.copy_(sample)
         plan.ctx.copy_(encoder_hidden_states)
+        plan.ctx_src = None
         t = torch.as_tensor(timestep)
         plan.t_table[:1].copy_(t.reshape(-1)[:1].to(torch.float32))
         plan.t_idx.zero_()

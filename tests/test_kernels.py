@@ -619,6 +619,36 @@ def test_conv_in_out(dev, B, H, W, Co, C):
     assert rel_err(dxh.cpu().permute(0, 3, 1, 2), xx.grad) < TOLBF
 
 
+@pytest.mark.parametrize("adt", [bf, torch.float32])
+def test_step_glue_launches(dev, adt):
+    """leco_step_begin / leco_step_mid (the tensor moves between the launch plans of a step, train_lora.py:175-199) against
+    the framework ops they replace, bit for bit."""
+    class P:        # the two fields of a launch plan the op touches
+        def __init__(self):
+            self.t_table = torch.zeros(1024, device=dev)
+            self.t_idx = torch.full((1,), 7, dtype=torch.int32, device=dev)
+    torch.manual_seed(4)
+    bs, n = 2, 4 * 8 * 24
+    x = torch.randn(bs * n, device=dev)
+    x2 = torch.zeros(2 * bs * n, dtype=adt, device=dev)
+    t_idx = torch.full((1,), 5, dtype=torch.int32, device=dev)
+    ops.step_begin(x, x2, 0.37, bs * n, t_idx).run()
+    _sync(dev)
+    want = (x * 0.37).to(adt)
+    assert torch.equal(x2.cpu(), torch.cat([want, want]).cpu()) and t_idx.item() == 0
+    a, b = torch.zeros_like(x2), torch.zeros(3 * x2.numel(), dtype=adt, device=dev)
+    pa, pb = P(), P()
+    ops.step_mid(x2, a, b, 3, 439.0, pa, pb, 512).run()
+    _sync(dev)
+    assert torch.equal(a.cpu(), x2.cpu()) and torch.equal(b.cpu(), x2.repeat(3).cpu())
+    for q in (pa, pb):
+        assert q.t_idx.item() == 512 and q.t_table[512].item() == 439.0 and q.t_table.sum().item() == 439.0
+    a.zero_()
+    ops.step_mid(x2, None, b, 1, 3.0, None, pb, 9).run()       # generic schedulers: only the batched frozen pass is filled
+    _sync(dev)
+    assert a.abs().sum().item() == 0 and pb.t_idx.item() == 9 and pb.t_table[9].item() == 3.0 and pa.t_idx.item() == 512
+
+
 def test_timestep_ddim_loss_adamw(dev):
     from oracle.unet_ref import timestep_sinusoid
     torch.manual_seed(9)
