@@ -188,6 +188,12 @@ def _launch_identity(op):
         A = op.keep[0]
         return ([f"xblock_head_kernel<{A.c}>"], (op.name, A.m, A.c, 1 if A.gn_cstats else 0, 1 if A.proj_in.dn else 0),
                 A.m * 2.0 * A.c * A.c * 4, 2.0 * (A.m * A.c * 5 + 4 * A.c * A.c))
+    if op.name == "leco_xgemm":
+        A = op.keep[0]
+        ext = 32 if A.lin.dn else 0
+        bm = 32 if A.k == 1280 else 64
+        return ([f"xgemm_kernel<{bm}, {A.k}>"], (op.name, A.m, A.n, A.k, ext, 1 if A.residual else 0),
+                2.0 * A.m * A.n * (A.k + ext), 2.0 * (A.m * A.k + A.n * A.k + A.m * A.n * (2 if A.residual else 1)))
     if op.name == "leco_attention_bwd":
         B, H, sq, skv, d = a[26], a[27], a[28], a[29], a[30]
         return ["attention_bwd(3 kernels)"], (op.name, B, H, sq, skv, d), 10.0 * B * H * sq * skv * d, 2.0 * B * H * d * (4 * sq + 4 * skv)

@@ -347,6 +347,27 @@ typedef struct leco_xlin {     /* one Linear of a stripe chain: y = x W^T + bias
                                   cache lines per load instead of 16 half lines); needs ldw == K */
 } leco_xlin;
 
+/* A-stationary GEMM for the short-K / small-M Linears of the transformer blocks (csrc/xgemm.hip; forward-only plans):
+ *   c = a lin.w^T (+ (a lin.dn^T)(lin.up)^T) + lin.bias (+ residual)
+ * -- attn{1,2}.to_q / to_out.0, the fused q|k|v projection, Transformer2DModel.proj_in / proj_out below the 64^2 level
+ * (diffusers' BasicTransformerBlock / Transformer2DModel via train_util.py:156-160; LoRA term lora.py:102-106).  The
+ * workgroup's BM x K activation tile is staged in LDS once, lin.w streams global -> VGPR in MFMA fragment order
+ * (lin.packed must be 1, lin.ldw == k), the LoRA down-projection rides along in the same K sweep.
+ * Shapes: n % 128 == 0, k in {320, 640, 1280} (leco_xgemm_supported); BM = leco_xgemm_rows(k) rows per workgroup. */
+typedef struct leco_xgemm_args {
+    int32_t m, n, k;
+    const void* a;             /* bf16 [m][k], row stride lda (multiple of 8) */
+    int64_t lda;
+    leco_xlin lin;
+    const void* residual;      /* bf16 [m][n] or NULL, row stride ldr (multiple of 4) */
+    int64_t ldr;
+    void* c;                   /* bf16 [m][n], row stride ldc (multiple of 4) */
+    int64_t ldc;
+} leco_xgemm_args;
+int leco_xgemm_supported(int32_t m, int32_t n, int32_t k);
+int leco_xgemm_rows(int32_t k);
+int leco_xgemm(const leco_xgemm_args* a, leco_stream_t stream);
+
 /* 1 if the stripe kernels cover this shape (else the caller keeps the per-op launches) */
 int leco_xblock_supported(int32_t c, int32_t heads, int32_t skv, int32_t rows_per_sample);
 

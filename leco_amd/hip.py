@@ -64,6 +64,11 @@ class XLin(C.Structure):          # mirrors `leco_xlin`
                 ("up", C.c_void_p), ("ld_up", C.c_int64), ("t_rows", C.c_int32), ("packed", C.c_int32)]
 
 
+class XGemmArgs(C.Structure):          # mirrors `leco_xgemm_args`
+    _fields_ = [("m", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("a", C.c_void_p), ("lda", C.c_int64), ("lin", XLin),
+                ("residual", C.c_void_p), ("ldr", C.c_int64), ("c", C.c_void_p), ("ldc", C.c_int64)]
+
+
 class XBlockTailArgs(C.Structure):     # mirrors `leco_xblock_tail_args`
     _fields_ = [
         ("m", C.c_int32), ("c", C.c_int32), ("heads", C.c_int32), ("skv", C.c_int32), ("rows_per_sample", C.c_int32),

@@ -58,6 +58,7 @@ _SIGS = {
     "leco_lora_wgrad": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _i64, _vp],
     "leco_xattn_prep": [_vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _vp],
     "leco_xblock_tail": [_vp, _vp],
+    "leco_xgemm": [_vp, _vp],
     "leco_xblock_head": [_vp, _vp],
 }
 # fp32 compute mode (csrc/f32.hip): the same argument lists behind `leco_f32_` entry points; activations / weights /
@@ -397,6 +398,24 @@ def xblock_tail(args: "hip.XBlockTailArgs", keep=None) -> Op:
 def xblock_head(args: "hip.XBlockHeadArgs", keep=None) -> Op:
     """GroupNorm apply + proj_in + LayerNorm + q|k|v of a Transformer2DModel's first block as ONE launch (`leco_xblock_head_args`)."""
     return Op("leco_xblock_head", (C.cast(C.pointer(args), _vp),), keep=(args, keep))
+
+
+def xgemm_supported(m: int, n: int, k: int) -> bool:
+    f = hip.lib().leco_xgemm_supported
+    f.argtypes, f.restype = [_i32, _i32, _i32], C.c_int
+    return bool(f(m, n, k))
+
+
+def xgemm(a_ptr: int, lda: int, lin: "hip.XLin", c_ptr: int, ldc: int, m: int, n: int, k: int, residual: Optional[int] = None,
+          ldr: int = 0, keep=None) -> Op:
+    """c = a lin.w^T (+ LoRA) + bias (+ residual) on the A-stationary kernel (include/leco_hip.h `leco_xgemm_args`)."""
+    A = hip.XGemmArgs()
+    A.m, A.n, A.k = m, n, k
+    A.a, A.lda = a_ptr, lda
+    A.lin = lin
+    A.residual, A.ldr = residual, ldr
+    A.c, A.ldc = c_ptr, ldc
+    return Op("leco_xgemm", (C.cast(C.pointer(A), _vp),), keep=(A, lin, keep))
 
 
 def deterministic_default() -> bool:

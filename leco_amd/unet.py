@@ -708,6 +708,9 @@ class PlanBuilder:
             y.cstats = self.stat_slice(site.n, stats_hw)
             if y.cstats is not None:
                 common.update(col_stats=y.cstats, stats_rows=stats_hw, stats_atom=self.stat_atom)
+        if (y is not None and y.cstats is None and out_f32 is None and self.xgemm_ok(site, xs, amode, rows, rowbias, act)
+                and bias == "site"):
+            return self._gemm_fwd_x(site, xs[0], y, rows, residual, rg_in)
         a0, lda0 = xs[0].ptr, xs[0].ld
         yptr = y.ptr if y is not None else None
         ldc = y.ld if y is not None else site.n
@@ -754,6 +757,35 @@ class PlanBuilder:
             y.rg = rg_in or lora is not None
             if y.rg:
                 self.tape.append(lambda: self.gemm_bwd(site, xs, y, T, conv, amode, rows, residual))
+        return y
+
+    # ---- A-stationary GEMM (csrc/xgemm.hip) for the short-K / small-M Linears of the forward-only plans ------------------
+    def xgemm_ok(self, site: GemmSite, xs, amode, rows: int, rowbias, act) -> bool:
+        """The launch can go to `leco_xgemm`: forward-only bf16 plan, plain single-source operand, no per-sample bias /
+        activation, a shape the kernel covers and (LoRA sites) the <= 32-column fused down-projection images.
+        ``LECO_XGEMM=0`` keeps the LDS-ring kernel; ``LECO_XGEMM_MAX_M`` bounds the row count it is used for.  Measured on
+        MI355X (profiles/r05_bench_xgemm_var*.txt): the A-stationary kernel wins only where the ring GEMM cannot fill its
+        tiles -- M = 256 (the 8^2 level at UNet batch 4): 7.5 vs 10.1 us; at M = 1024 it ties (13.9 - 15.8 vs 14.7 us) and
+        from M = 3072 on it loses 1.3 - 1.5x: weight fragments streamed global -> VGPR, 16 bytes per lane, top out near
+        330 TFLOP/s, below what the LDS ring reaches once its tiles are full.  Hence the default bound of 256 rows."""
+        import os
+        if self.need_bwd or self.eng.f32 or os.environ.get("LECO_XGEMM", "1") in ("", "0"):
+            return False
+        if amode != A_PLAIN or len(xs) != 1 or rowbias is not None or act != ACT_NONE or site.conv3:
+            return False
+        if rows > int(os.environ.get("LECO_XGEMM_MAX_M", "256")) or not ops.xgemm_supported(rows, site.n, site.k):
+            return False
+        lo = site.lora
+        return lo is None or (lo.Rp == 32 and lo.dn_s is not None and lo.up_p is not None)
+
+    def _gemm_fwd_x(self, site: GemmSite, x: TRef, y: TRef, rows: int, residual: Optional[TRef], rg_in: bool) -> TRef:
+        for lora_on, lst in ((True, self.f_on), (False, self.f_off)):
+            lin, kp = self._xlin(site, lora_on)
+            lst.append(ops.xgemm(x.ptr, x.ld, lin, y.ptr, y.ld, rows, site.n, site.k,
+                                 residual=residual.ptr if residual is not None else None,
+                                 ldr=residual.ld if residual is not None else 0, keep=(kp, x, y, residual)))
+        self._last_T = None
+        y.rg = rg_in or site.lora is not None
         return y
 
     def _gemm_fwd_geglu(self, site: GemmSite, x: TRef, name: str, rows: int) -> TRef:

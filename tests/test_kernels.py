@@ -619,6 +619,50 @@ def test_conv_in_out(dev, B, H, W, Co, C):
     assert rel_err(dxh.cpu().permute(0, 3, 1, 2), xx.grad) < TOLBF
 
 
+@pytest.mark.parametrize("m,n,k,rank,res", [(200, 256, 320, 4, True), (96, 128, 640, 0, True), (160, 384, 640, 8, False),
+                                            (72, 256, 1280, 4, True), (64, 128, 1280, 0, False)])
+def test_xgemm_a_stationary_linear(dev, m, n, k, rank, res):
+    """leco_xgemm (csrc/xgemm.hip): c = a W^T (+ (a down^T)(scale up)^T) + bias (+ residual) with W in MFMA fragment order,
+    against fp32 torch on the same bf16 operands; row counts that are not a multiple of the tile, both stack heights of the
+    fused down-projection (rank 4 x 3 groups -> 16 rows; rank 8 x 3 -> 32 rows), every supported K."""
+    torch.manual_seed(m + n + k)
+    a = (torch.randn(m, k) * 0.5).to(bf)
+    w = (torch.randn(n, k) / math.sqrt(k)).to(bf)
+    bias = torch.randn(n) * 0.1
+    r = torch.randn(m, n).to(bf) if res else None
+    ref = a.float() @ w.float().t() + bias
+    dn = up = None
+    t_rows = 0
+    if rank:
+        R = 3 * rank                                   # q|k|v-style stacking: 3 groups
+        t_rows = 16 if R <= 16 else 32
+        dn = torch.zeros(t_rows, k)
+        dn[:R] = torch.randn(R, k) / math.sqrt(k)
+        up = torch.zeros(n, 32)
+        up[:, :R] = torch.randn(n, R) * 0.2
+        dn, up = dn.to(bf), up.to(bf)
+        T = (a.float() @ dn.float().t()).to(bf).float()          # the kernel rounds T to bf16 before the K-extension
+        ref = ref + T @ up.float()[:, :t_rows].t()
+    if res:
+        ref = ref + r.float()
+    ad, wd = a.to(dev), hip.pack_fragments(w).to(dev)
+    c = torch.zeros(m, n, dtype=bf, device=dev)
+    # (`leco_xlin` holds raw addresses: every operand tensor must stay alive until the launch has run)
+    bd, dnd, upd = bias.to(dev), None if dn is None else dn.to(dev), None if up is None else up.to(dev)
+    lin = hip.xlin(wd, bd, dnd, upd, t_rows, packed=True)
+    rd = r.to(dev) if res else None
+    keep = (ad, wd, c, bd, dnd, upd, rd)
+    assert ops.xgemm_supported(m, n, k) and not ops.xgemm_supported(m, n + 64, k) and not ops.xgemm_supported(m, n, 768)
+    ops.xgemm(ad.data_ptr(), k, lin, c.data_ptr(), n, m, n, k, residual=None if rd is None else rd.data_ptr(), ldr=n, keep=keep).run()
+    _sync(dev)
+    assert rel_err(c.float().cpu(), ref) < TOLBF
+    # rows beyond m are never written: a guard row behind the output stays untouched
+    c2 = torch.full((m + 8, n), 7.0, dtype=bf, device=dev)
+    ops.xgemm(ad.data_ptr(), k, lin, c2.data_ptr(), n, m, n, k, keep=keep).run()
+    _sync(dev)
+    assert (c2[m:].float() == 7.0).all() and torch.isfinite(c2.float()).all()
+
+
 @pytest.mark.parametrize("adt", [bf, torch.float32])
 def test_step_glue_launches(dev, adt):
     """leco_step_begin / leco_step_mid (the tensor moves between the launch plans of a step, train_lora.py:175-199) against

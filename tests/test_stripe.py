@@ -349,3 +349,57 @@ def test_batch_shared_prefix_gives_the_same_prediction(dev, share):
     _sync(dev)
     assert rel_err(y_s, y_p) < 1e-6, rel_err(y_s, y_p)
     assert rel_err(y_s[0], y_s[1]) > 1e-3          # (the copies really differ through their prompts)
+
+
+@pytest.mark.parametrize("rank,linear", [(4, False), (0, True)])
+def test_forward_only_plans_run_the_a_stationary_gemm_and_match_the_ring_gemm(dev, rank, linear, monkeypatch):
+    """A UNet with 320- and 640-channel transformer levels below the stripe kernels' reach (LECO_STRIPE=0 keeps level 0 on the
+    per-op chain too): the forward-only plan sends attn{1,2}.to_q / to_out.0, q|k|v, proj_in / proj_out and the 1x1
+    shortcuts to `leco_xgemm` (csrc/xgemm.hip, K = 320 / 640); its prediction equals the LDS-ring GEMM plan's (LECO_XGEMM=0)
+    to bf16 rounding, LoRA on and off -- conv and Linear flavours of proj_in / proj_out."""
+    import contextlib
+    import io
+    from leco_amd import model_util
+    from leco_amd.lora import LoRANetwork
+    from leco_amd.unet import UNet2DConditionModel, UNetConfig
+    torch.manual_seed(9)
+    monkeypatch.setenv("LECO_STRIPE", "0")
+    monkeypatch.setenv("LECO_XGEMM_MAX_M", "4096")      # (default 256 rows: where the kernel measured faster on MI355X)
+    cfg = UNetConfig(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+                     up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D"), layers_per_block=1, attention_head_dim=8,
+                     cross_attention_dim=64, sample_size=8, use_linear_projection=linear)
+    m = model_util.init_synthetic_(UNet2DConditionModel(cfg), seed=3).to(dev, bf)
+    m.requires_grad_(False)
+    if rank:
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = LoRANetwork(m, rank=rank, multiplier=1.0, alpha=1.0)
+        with torch.no_grad():
+            for l in net.unet_loras:
+                l.lora_up.weight.normal_(0, 0.02)
+        net.mark_updated()
+    B, h, w = 2, 8, 8
+    x = torch.randn(B, 4, h, w).to(dev, bf); ctx = torch.randn(B, 77, 64).to(dev, bf)
+    eng = m.engine()
+    if rank:
+        net.multiplier = 1.0
+        m.prepare((B, 4, h, w), lora_on=True)
+    xp = eng.plan(B, h, w, need_bwd=False)
+    names = [op.name for op in xp.lists["fwd_on"]]
+    n_x = names.count("leco_xgemm")
+    # the four 640-channel transformers (down 1, mid, up 0 x 2): q|k|v, to_out.0, to_q, to_out.0, proj_in, proj_out each
+    # (the 320-channel level has N = 320, not a multiple of the 128-column tile: it stays on the ring GEMM / the stripe kernels)
+    assert n_x >= 4 * 6, names
+    y_on, y_off = _run_plan(m, xp, "fwd_on", x, ctx), _run_plan(m, xp, "fwd_off", x, ctx)
+    # the training plan (it must stash T for the LoRA weight gradients) keeps the ring GEMM
+    assert "leco_xgemm" not in [op.name for op in eng.plan(B, h, w).lists["fwd_on"]]
+    monkeypatch.setenv("LECO_XGEMM", "0")
+    eng.plans.clear()
+    rp = eng.plan(B, h, w, need_bwd=False)
+    assert "leco_xgemm" not in [op.name for op in rp.lists["fwd_on"]]
+    p_on, p_off = _run_plan(m, rp, "fwd_on", x, ctx), _run_plan(m, rp, "fwd_off", x, ctx)
+    _sync(dev)
+    e_on, e_off = rel_err(y_on, p_on), rel_err(y_off, p_off)
+    print(f"xgemm vs ring-gemm plan ({n_x} launches moved): LoRA on {e_on:.3g}, off {e_off:.3g}; on-vs-off {rel_err(p_on, p_off):.3g}")
+    assert e_on < 1e-2 and e_off < 1e-2
+    if rank:
+        assert rel_err(p_on, p_off) > 1e-3 and rel_err(y_on, y_off) > 1e-3     # the LoRA term is really there

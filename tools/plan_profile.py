@@ -60,6 +60,11 @@ def describe(op):
     if op.name == "leco_xblock_head":
         A = op.keep[0]
         return f"xblock_head M={A.m} C={A.c}" + (" +gn" if A.gn_cstats else ""), A.m * 2.0 * A.c * A.c * 4, 2.0 * A.m * A.c * 5
+    if op.name == "leco_xgemm":
+        A = op.keep[0]
+        ext = 32 if A.lin.dn else 0
+        key = f"xgemm plain M={A.m} N={A.n} K={A.k}" + (f" +lora{ext}(fusedT)" if ext else "") + (" +res" if A.residual else "")
+        return key, 2.0 * A.m * A.n * (A.k + ext), 2.0 * (A.m * A.k + A.n * A.k + A.m * A.n)
     return op.name[5:], 0.0, 0.0
 
 
