@@ -1,5 +1,7 @@
 // hipGraph capture helpers of the C ABI (a UNet pass = one graph launch).
 #include <errno.h>
+#include <stdlib.h>
+#include <string.h>
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -7,7 +9,15 @@
 using namespace leco;
 
 extern "C" int leco_graph_begin_capture(leco_stream_t stream) {
-    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeThreadLocal);
+    // LECO_CAPTURE_MODE=global|relaxed: experiment switch for the ROCm 7.2 capture crash; default
+    // thread-local (another thread -- torch's autograd worker -- may keep making runtime calls while this thread captures)
+    static const hipStreamCaptureMode mode = [] {
+        const char* e = getenv("LECO_CAPTURE_MODE");
+        if (e && !strcmp(e, "global")) return hipStreamCaptureModeGlobal;
+        if (e && !strcmp(e, "relaxed")) return hipStreamCaptureModeRelaxed;
+        return hipStreamCaptureModeThreadLocal;
+    }();
+    hipError_t e = hipStreamBeginCapture((hipStream_t)stream, mode);
     if (e != hipSuccess) return fail(-EIO, "hipStreamBeginCapture: %s", hipGetErrorString(e));
     return 0;
 }

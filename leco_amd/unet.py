@@ -1516,11 +1516,19 @@ class UNet2DConditionModel(nn.Module):
         g = plan.graphs.get(which)
         cur = torch.cuda.current_stream()
         if g is None:
-            side = getattr(self, "_capture_stream", None)
-            if side is None:
-                side = self._capture_stream = torch.cuda.Stream()
-            side.wait_stream(cur)
-            sp = side.cuda_stream
+            import os
+            if os.environ.get("LECO_CAPTURE_STREAM") == "lib":
+                # experiment switch (ROCm 7.2 capture crash): capture on the library's own stream
+                # instead of one from torch's pool
+                sp = ops.side_stream()
+                lib.leco_fork.argtypes, lib.leco_fork.restype = [C.c_void_p], C.c_int
+                hip.check(lib.leco_fork(cur.cuda_stream), "capture edge")
+            else:
+                side = getattr(self, "_capture_stream", None)
+                if side is None:
+                    side = self._capture_stream = torch.cuda.Stream()
+                side.wait_stream(cur)
+                sp = side.cuda_stream
             if any(op.side for op in oplist):
                 ops.side_stream()       # forked sections: the library's side stream exists before the capture begins
             hip.check(lib.leco_graph_begin_capture(sp), "graph begin")

@@ -128,12 +128,19 @@ def _check_step(arch, res, bs, rank, k, **kw):
     try:
         return _check_step_on(dev, m, arch, res, bs, rank, k, **kw)
     finally:        # several multi-GB models run in one process: give graphs and buffers back before the next one
-        m.release()
+        # (LECO_FS_KEEP: experiment switches of the capture-crash hunt, DESIGN.md section 6 -- "release": keep the graph
+        # execs, "cache": keep torch's cached blocks)
+        keep = os.environ.get("LECO_FS_KEEP", "")
+        if "release" not in keep:
+            m.release()
+        else:
+            globals().setdefault("_alive", []).append(m)
         del m
         import gc
         gc.collect()
         torch.cuda.synchronize()
-        torch.cuda.empty_cache()
+        if "cache" not in keep:
+            torch.cuda.empty_cache()
 
 
 def _check_step_on(dev, m, arch, res, bs, rank, k, c3lier=False, v_pred=False, gscale=1.0, action="erase", seed=1234,

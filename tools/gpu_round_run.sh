@@ -10,7 +10,7 @@
 #          4. every launch of the denoising pass in isolation   -> rNN_plan_denoise.txt;  smoke()
 # tests:   the GPU test tier                                    -> rNN_gpu_tests.log
 # configs: BASELINE configs 3-5: launch-shape tuning + bench    -> rNN_bench_*.json, rNN_tune_*.txt
-RN=${ROUND:-r04}
+RN=${ROUND:-r05}
 R=$PWD; O=$R/gpurun_out; mkdir -p $O; export TMPDIR=/tmp
 what=${1:-measure}
 if [ "$what" = "measure" ]; then
@@ -39,7 +39,8 @@ cd $R
 cut -c1-1800 $O/${RN}_bench.json; head -14 $O/${RN}_step_kernel_stats.txt; head -4 $O/${RN}_pmc_dominant_mfma.csv; head -4 $O/${RN}_pmc_dominant_fetch.csv; tail -3 /tmp/pmc_dm.log; cat $O/${RN}_smoke.log
 fi
 if [ "$what" = "tests" ]; then
-  ( timeout 1300 python -m pytest tests -q -m gpu -s 2>&1 | grep -vE "^W2026|Warn|warn|hipGraph|\^~|^ +[0-9]+ \|" | tail -150 ) > $O/${RN}_gpu_tests.log 2>&1
+  timeout 1300 python -m pytest tests -q -m gpu -s > /tmp/gpu_tests_full.log 2>&1; echo "pytest rc=$?" >> /tmp/gpu_tests_full.log
+  { grep -vE "^W2026|Warn|warn|hipGraph|\^~|^ +[0-9]+ \|" /tmp/gpu_tests_full.log | tail -150; grep -E " passed| failed|^FAILED|^ERROR|pytest rc=" /tmp/gpu_tests_full.log | tail -12; } > $O/${RN}_gpu_tests.log 2>&1
   tail -5 $O/${RN}_gpu_tests.log
 fi
 if [ "$what" = "configs" ]; then

@@ -20,6 +20,34 @@ for i in range(3 if arch == "tiny" else 2):
     m.use_graphs = True
     if shared is not None:
         m._capture_stream = shared
+    if mode.startswith("fused"):
+        # the case DESIGN.md section 6 describes: a whole FusedStep (three plans, five graphs) on a SECOND multi-GB model
+        import contextlib, io
+        from leco_amd import prompt_util, train_util
+        from leco_amd.lora import LoRANetwork
+        from leco_amd.scheduler import create_noise_scheduler
+        from leco_amd.train import FusedStep
+        with contextlib.redirect_stdout(io.StringIO()):
+            net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0).to(dev)
+        sched = create_noise_scheduler("ddim")
+        e = {p_: torch.randn(1, 77, cdim, generator=torch.Generator().manual_seed(len(p_))).to(dev, torch.bfloat16) for p_ in ("a", "")}
+        st = prompt_util.PromptSettings(target="a", positive="a", unconditional="", neutral="", action="erase", guidance_scale=1.0,
+                                        resolution=hw * 8, batch_size=1)
+        pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), e["a"], e["a"], e[""], e[""], st)
+        fs = FusedStep(m, net, sched, 50, lr=1e-4)
+        for _ in range(2):
+            loss = fs.step(pair, 2, train_util.get_initial_latents(sched, 1, hw * 8, hw * 8, 1))
+        torch.cuda.synchronize()
+        print(mode, "model", i, "fused step ok", float(loss.item()), flush=True)
+        if mode == "fused_release":
+            m.release()
+            del fs, net
+            torch.cuda.empty_cache()
+        if mode == "fused_keep":
+            globals().setdefault("alive", []).append((m, fs, net))
+        del m
+        gc.collect()
+        continue
     if mode == "eager_first":
         m.use_graphs = False
         y = m(x, torch.tensor(10), encoder_hidden_states=ctx).sample
