@@ -39,6 +39,22 @@ for i in range(3 if arch == "tiny" else 2):
             loss = fs.step(pair, 2, train_util.get_initial_latents(sched, 1, hw * 8, hw * 8, 1))
         torch.cuda.synchronize()
         print(mode, "model", i, "fused step ok", float(loss.item()), flush=True)
+        if mode in ("fused_mm", "fused_conv", "fused_bwd"):
+            # candidate triggers between two capture phases: the vendor GEMM (hipBLASLt / rocBLAS), the vendor convolution
+            # (MIOpen), an autograd backward (torch's autograd worker thread)
+            a_ = torch.randn(2048, 2048, device=dev)
+            if mode == "fused_mm":
+                for dt in (torch.float32, torch.bfloat16):
+                    (a_.to(dt) @ a_.to(dt)).sum().item()
+            elif mode == "fused_conv":
+                xi = torch.randn(2, 64, 64, 64, device=dev)
+                wt = torch.randn(64, 64, 3, 3, device=dev)
+                torch.nn.functional.conv2d(xi, wt, padding=1).sum().item()
+            else:
+                q = a_.clone().requires_grad_(True)
+                (q * q).sum().backward()
+                q.grad.sum().item()
+            print(mode, "model", i, "torch work between the captures done", flush=True)
         if mode == "fused_release":
             m.release()
             del fs, net
