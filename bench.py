@@ -192,7 +192,7 @@ def _launch_identity(op):
         A = op.keep[0]
         ext = 32 if A.lin.dn else 0
         bm = 32 if A.k == 1280 else 64
-        return ([f"xgemm_kernel<{bm}, {A.k}>"], (op.name, A.m, A.n, A.k, ext, 1 if A.residual else 0),
+        return ([f"xgemm_kernel<{bm}, {A.k}, {os.environ.get('LECO_XGEMM_VAR', '1')}>"], (op.name, A.m, A.n, A.k, ext, 1 if A.residual else 0),
                 2.0 * A.m * A.n * (A.k + ext), 2.0 * (A.m * A.k + A.n * A.k + A.m * A.n * (2 if A.residual else 1)))
     if op.name == "leco_attention_bwd":
         B, H, sq, skv, d = a[26], a[27], a[28], a[29], a[30]

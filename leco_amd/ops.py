@@ -22,6 +22,7 @@ _SIGS = {
     "leco_groupnorm_fwd": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
     "leco_groupnorm_bwd": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
     "leco_groupnorm_apply_stats": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
+    "leco_groupnorm_fwd_splitk": [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
     "leco_colstats": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "leco_layernorm_fwd": [_vp, _i64, _vp, _vp, _f32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     "leco_layernorm_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp],
@@ -51,6 +52,7 @@ _SIGS = {
     "leco_step_mid": [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp],
     "leco_fork": [_vp], "leco_join": [_vp],
     "leco_lora_pack": [_vp, _i32, _vp],
+    "leco_lnfold_pack": [_vp, _i32, _vp],
     "leco_lora_wgrad_conv": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32,
                              _i32, _i32, _vp, _i64, _vp],
     "leco_rowgroup_sum": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp],
@@ -343,6 +345,10 @@ def step_mid(src: torch.Tensor, dst_a: Optional[torch.Tensor], dst_b: Optional[t
     return Op("leco_step_mid", (ptr(src), ptr(dst_a), ptr(dst_b), nbytes, reps_b, float(t_cur), ta, tb,
                                 None if plan_a is None else ptr(plan_a.t_idx), None if plan_b is None else ptr(plan_b.t_idx), slot),
               keep=(src, dst_a, dst_b))
+
+
+def lnfold_pack(sites_dev: torch.Tensor, nsites: int) -> Op:
+    return Op("leco_lnfold_pack", (ptr(sites_dev), nsites), keep=(sites_dev,))
 
 
 def lora_pack(sites_dev: torch.Tensor, nsites: int) -> Op:

@@ -241,7 +241,7 @@ class UNetOutput:
 class TRef:
     """A row-major [rows][cols] activation view (row stride ``ld``; bf16, or fp32 in the fp32 compute mode) inside a
     device buffer."""
-    __slots__ = ("t", "ptr", "ld", "rows", "cols", "rg", "gparts", "name", "cstats")
+    __slots__ = ("t", "ptr", "ld", "rows", "cols", "rg", "gparts", "name", "cstats", "pend")
 
     def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None, offset: int = 0,
                  rg: bool = False, name: str = ""):
@@ -253,6 +253,7 @@ class TRef:
         self.gparts: List["TRef"] = []
         self.name = name
         self.cstats: Optional[int] = None   # device address of fp32 [B][cols][2] {sum, sumsq} left by the producer, or None
+        self.pend: Optional[dict] = None    # the tensor only exists as UNFINISHED split-K slabs (gemm_fwd(defer_finish=True))
 
     def cols_view(self, c0: int, c1: int) -> "TRef":
         v = TRef(self.t, self.rows, c1 - c0, self.ld, 0, self.rg, self.name)
@@ -688,7 +689,11 @@ class PlanBuilder:
     def gemm_fwd(self, site: GemmSite, x: Union[TRef, Tuple[TRef, TRef]], name: str, *, conv=None, amode=A_PLAIN,
                  rows: int, residual: Optional[TRef] = None, rowbias=None, rows_per_group=0, ld_rowbias=0,
                  act=ACT_NONE, out: Optional[TRef] = None, out_f32: Optional[torch.Tensor] = None,
-                 bias="site", ldc32_override: int = 0, geglu: bool = False, stats_hw: int = 0) -> TRef:
+                 bias="site", ldc32_override: int = 0, geglu: bool = False, stats_hw: int = 0,
+                 defer_finish: bool = False) -> TRef:
+        """``defer_finish`` (forward-only plans, no LoRA on the site): if the launch shape splits K, leave the fp32 partial
+        slabs in the workspace and hand their description to the consumer in ``y.pend`` instead of running the finishing
+        pass -- the caller guarantees that the ONLY reader of y is a `groupnorm(..., pend=y.pend)` emitted right behind."""
         if geglu:
             return self._gemm_fwd_geglu(site, x, name, rows)
         xs = x if isinstance(x, tuple) else (x,)
@@ -715,6 +720,12 @@ class PlanBuilder:
         yptr = y.ptr if y is not None else None
         ldc = y.ld if y is not None else site.n
         g_off = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, **common)
+        if defer_finish and lora is None and y is not None and y.cstats is None and residual is None and act == ACT_NONE:
+            y.pend = self._deferred_splitk(g_off, (site, xs, y), bias_t, rowbias, ld_rowbias)
+            if y.pend is not None:
+                self._last_T = None
+                y.rg = rg_in
+                return y
         self.f_off.append(ops.gemm(g_off, keep=(site, xs, residual, y), ws=self.ws))
         T = None
         self._last_T = None
@@ -758,6 +769,27 @@ class PlanBuilder:
             if y.rg:
                 self.tape.append(lambda: self.gemm_bwd(site, xs, y, T, conv, amode, rows, residual))
         return y
+
+    def _deferred_splitk(self, g: "hip.GemmArgs", keep, bias_t, rowbias, ld_rowbias) -> Optional[dict]:
+        """Emits the launch of `g` WITHOUT its split-K finishing pass (`leco_gemm_args.no_finish`) when the launch shape the
+        tuner / the C cost model picks splits K; returns what `leco_groupnorm_fwd_splitk` needs, or None (nothing emitted)."""
+        import re
+        from . import tune
+        if self.ws is None:
+            return None
+        tile, split = tune.choose(g, self.ws)
+        ws_ptr, ws_bytes = self.ws.data_ptr(), self.ws.numel() * self.ws.element_size()
+        first = hip.gemm_describe(g, tile, split, ws_ptr, ws_bytes).split(" ; ")[0]
+        m = re.search(r"split=(\d+)", first)
+        eff = int(m.group(1)) if m else 1
+        if first.startswith("conv_patch_kernel"):
+            eff = min(eff, g.k // 9 // 64)          # splits beyond the channel-chunk count write nothing (conv_patch.hip)
+        if eff <= 1:
+            return None
+        g.no_finish = 1
+        for lst in (self.f_off, self.f_on):
+            lst.append(ops.Op("leco_gemm_ex", (C.byref(g), tile, split, ws_ptr, ws_bytes), keep=(g, keep, self.ws)))
+        return dict(splits=eff, ws=self.ws, bias=bias_t, rowbias=rowbias, ld_rowbias=ld_rowbias)
 
     # ---- A-stationary GEMM (csrc/xgemm.hip) for the short-K / small-M Linears of the forward-only plans ------------------
     def xgemm_ok(self, site: GemmSite, xs, amode, rows: int, rowbias, act) -> bool:
@@ -942,6 +974,15 @@ class PlanBuilder:
         y = self.act(name, rows, Cc, rg=any(t.rg for t in xs))
         stats = self.buf(name + ".stats", (self.B * G * 2 * 257,), torch.float32)
         x1 = xs[1] if len(xs) == 2 else None
+        if len(xs) == 1 and xs[0].pend is not None:
+            # the producer left unfinished split-K slabs: sum + bias + time-embedding bias + bf16 rounding happen in this
+            # kernel's loader (leco_groupnorm_fwd_splitk) -- no finishing launch, no pre-norm tensor in memory
+            pd = xs[0].pend
+            assert not self.need_bwd
+            self.both(ops.Op("leco_groupnorm_fwd_splitk", (
+                hip.ptr(pd["ws"]), pd["splits"], hip.ptr(pd["bias"]), pd["rowbias"], pd["ld_rowbias"], gamma.data_ptr(), beta.data_ptr(),
+                self.B, hw, Cc, G, eps, act, stats.data_ptr(), y.ptr, y.ld), keep=(xs, y, stats, pd)))
+            return y
         if all(t.cstats is not None for t in xs) and (Cc // G) % self.stat_atom == 0 and xs[0].cols % self.stat_atom == 0:
             # the producers left per-(sample, channel) statistics: one apply pass, no reduction over the tensor
             self.both(ops.Op("leco_groupnorm_apply_stats", (
@@ -1067,9 +1108,15 @@ class PlanBuilder:
             self.gemm_fwd(tsite, self.emb_silu, rname + ".temb", rows=self.B,
                           out_f32=temb[:, off:off + cout], ldc32_override=eng.temb_total)
             temb_T = self._last_T
-        h1 = self.gemm_fwd(eng.sites[rname + ".conv1"], n1, rname + ".h1", conv=conv, amode=A_CONV3_S1, rows=rows,
+        # forward-only plans: conv1's output is read by norm2 alone -- when the launch splits K, norm2 finishes it
+        import os
+        site1 = eng.sites[rname + ".conv1"]
+        fin_in_gn = (not self.need_bwd and not eng.f32 and tsite is None and site1.lora is None
+                     and os.environ.get("LECO_GN_FINISH", "1") not in ("", "0")
+                     and bool(hip.lib().leco_groupnorm_single_launch(self.B, hw, m.out_channels, self.cfg.norm_num_groups)))
+        h1 = self.gemm_fwd(site1, n1, rname + ".h1", conv=conv, amode=A_CONV3_S1, rows=rows,
                            rowbias=temb.data_ptr() + 4 * off, rows_per_group=hw, ld_rowbias=eng.temb_total, bias=None,
-                           stats_hw=hw)
+                           stats_hw=hw, defer_finish=fin_in_gn)
         if tsite is not None and h1.rg:
             def temb_bwd():
                 out = self.plan.bwd

@@ -663,6 +663,60 @@ def test_xgemm_a_stationary_linear(dev, m, n, k, rank, res):
     assert (c2[m:].float() == 7.0).all() and torch.isfinite(c2.float()).all()
 
 
+@pytest.mark.parametrize("conv,B,hw,C,K,split", [(False, 2, 64, 64, 512, 2), (False, 3, 16, 320, 1024, 4), (True, 2, 64, 64, 64 * 9, 1),
+                                                 (True, 2, 64, 128, 128 * 9, 2), (True, 4, 256, 128, 256 * 9, 4)])
+def test_groupnorm_finishes_a_split_k_convolution(dev, conv, B, hw, C, K, split):
+    """`leco_gemm_args.no_finish` + `leco_groupnorm_fwd_splitk`: the GroupNorm(+SiLU) that is the ONLY reader of a split-K
+    launch's output (ResnetBlock2D.conv1 -> norm2 in the forward-only plans) sums the fp32 slabs + bias + time-embedding row
+    bias in its loader.  Bit-identical to the unfused pair (finishing pass, then leco_groupnorm_fwd); the plain GEMM kernels
+    and the patch-staged convolution as producers."""
+    torch.manual_seed(B * hw + C)
+    m = B * hw
+    side = int(math.isqrt(hw))
+    cin = K // 9 if conv else K
+    a = (torch.randn(m, cin) * 0.5).to(bf).to(dev)
+    w = (torch.randn(C, K) / math.sqrt(K)).to(bf).to(dev)
+    bias = (torch.randn(C) * 0.1).to(dev)
+    rowbias = (torch.randn(B, C) * 0.3).to(dev)
+    gamma, beta = (1 + 0.1 * torch.randn(C)).to(dev), (0.1 * torch.randn(C)).to(dev)
+    ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev)
+    stats = torch.zeros(B * 32 * 2 * 257, dtype=torch.float32, device=dev)
+    kw = dict(m=m, n=C, k=K, bias=bias, rowbias=rowbias, rows_per_group=hw, ld_rowbias=C)
+    if conv:
+        kw.update(a_mode=hip.A_CONV3_S1, conv=(B, side, side, side, side), lda=cin)
+    tile = 9 if conv else 3              # the 128 x 128 patch kernel / the 64 x 64 ring GEMM
+    sp = max(split, 2)
+    ws_b = ws.numel() * 4
+
+    def run(no_finish):
+        y = torch.zeros(m, C, dtype=bf, device=dev)
+        g = hip.gemm_args(a, w, y, **kw)
+        g.no_finish = 1 if no_finish else 0
+        ops.Op("leco_gemm_ex", (C_.byref(g), tile, sp, ws.data_ptr(), ws_b), keep=(g, a, w, y)).run()
+        return y
+    import ctypes as C_
+    y = run(False)
+    out_ref = torch.zeros(m, C, dtype=bf, device=dev)
+    ops.Op("leco_groupnorm_fwd", (y.data_ptr(), C, None, 0, 0, gamma.data_ptr(), beta.data_ptr(), B, hw, C, 32, 1e-5, 1,
+                                  stats.data_ptr(), out_ref.data_ptr(), C)).run()
+    _sync(dev)
+    ws.zero_()
+    y2 = run(True)
+    import re
+    first = hip.gemm_describe(hip.gemm_args(a, w, y2, **kw), tile, sp, ws.data_ptr(), ws_b).split(" ; ")[0]
+    eff = int(re.search(r"split=(\d+)", first).group(1))          # what the planner reads (unet.py::_deferred_splitk)
+    if eff <= 1:         # the launch shape does not split (one channel chunk): nothing to defer, the planner never sets the flag
+        return
+    _sync(dev)
+    assert float(y2.float().abs().sum()) == 0.0                  # nothing was finished into c
+    out = torch.zeros(m, C, dtype=bf, device=dev)
+    ops.Op("leco_groupnorm_fwd_splitk", (ws.data_ptr(), eff, bias.data_ptr(), rowbias.data_ptr(), C, gamma.data_ptr(),
+                                         beta.data_ptr(), B, hw, C, 32, 1e-5, 1, stats.data_ptr(), out.data_ptr(), C)).run()
+    _sync(dev)
+    assert torch.isfinite(out.float()).all() and float(out.float().abs().mean()) > 0.05
+    assert torch.equal(out.cpu(), out_ref.cpu())
+
+
 @pytest.mark.parametrize("adt", [bf, torch.float32])
 def test_step_glue_launches(dev, adt):
     """leco_step_begin / leco_step_mid (the tensor moves between the launch plans of a step, train_lora.py:175-199) against

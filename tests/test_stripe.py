@@ -403,3 +403,33 @@ def test_forward_only_plans_run_the_a_stationary_gemm_and_match_the_ring_gemm(de
     assert e_on < 1e-2 and e_off < 1e-2
     if rank:
         assert rel_err(p_on, p_off) > 1e-3 and rel_err(y_on, y_off) > 1e-3     # the LoRA term is really there
+
+
+def test_forward_only_plans_finish_split_k_convolutions_inside_groupnorm(dev, monkeypatch):
+    """ResnetBlock2D.conv1 -> norm2 in the forward-only plans: where conv1's launch shape splits K, norm2's kernel sums the fp32
+    slabs itself (`leco_gemm_args.no_finish` + `leco_groupnorm_fwd_splitk`): one launch and one trip through memory less per
+    ResnetBlock2D.  Same bits as the finishing pass + GroupNorm pair (LECO_GN_FINISH=0); never in a plan with a backward."""
+    from leco_amd import tune
+    torch.manual_seed(21)
+    # every patch-staged convolution of this small model takes the 128 x 128 tile with two K slices (the real table's
+    # entries for the 16^2 / 8^2 levels look like this)
+    real_choose = tune.choose
+    monkeypatch.setattr(tune, "choose", lambda g, ws: (9, 2) if (g.a_mode == 1 and ws is not None and g.k // 9 // 64 >= 2) else real_choose(g, ws))
+    m = _stripe_unet(dev)
+    B, h, w = 2, 8, 8
+    x = torch.randn(B, 4, h, w).to(dev, bf); ctx = torch.randn(B, 77, 64).to(dev, bf)
+    eng = m.engine()
+    fused = eng.plan(B, h, w, need_bwd=False)
+    names = [op.name for op in fused.lists["fwd_off"]]
+    n_res = sum(1 for nm, mod in m.named_modules() if nm.endswith(".conv1"))
+    assert names.count("leco_groupnorm_fwd_splitk") == n_res >= 4, (names.count("leco_groupnorm_fwd_splitk"), n_res)
+    assert "leco_groupnorm_fwd_splitk" not in [op.name for op in eng.plan(B, h, w).lists["fwd_off"]]
+    y = _run_plan(m, fused, "fwd_off", x, ctx)
+    monkeypatch.setenv("LECO_GN_FINISH", "0")
+    eng.plans.clear()
+    plain = eng.plan(B, h, w, need_bwd=False)
+    assert "leco_groupnorm_fwd_splitk" not in [op.name for op in plain.lists["fwd_off"]]
+    assert len(plain.lists["fwd_off"]) == len(names)            # (the finishing launch is not a list entry: same length)
+    p_ = _run_plan(m, plain, "fwd_off", x, ctx)
+    _sync(dev)
+    assert torch.isfinite(y).all() and torch.equal(y, p_)
