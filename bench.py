@@ -157,7 +157,8 @@ def _launch_identity(op):
         parts = hip.gemm_describe(g, a[1], a[2], a[3], a[4]).split(" ; ")
         names = [p.split(" grid=")[0] for p in parts]
         ext = g.ext_k if (g.a_ext or g.t_w) else 0
-        key = (op.name, g.m, g.n, g.k, g.a_mode, ext, bool(g.t_w), bool(g.residual), g.act, g.batch, g.h_in, g.h_out, a[1], a[2])
+        key = (op.name, g.m, g.n, g.k, g.a_mode, ext, bool(g.t_w), bool(g.residual), g.act, g.batch, g.h_in, g.h_out, a[1], a[2],
+               bool(g.ln_s), bool(g.no_finish))
         kin = g.k // 9 if g.a_mode else g.k
         rows_in = g.m if g.a_mode == 0 else g.batch * g.h_in * g.w_in
         # algorithmic operand bytes: every input / weight / output element once (bf16), + the residual read
@@ -367,6 +368,43 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
     return out
 
 
+def box_calibration(dev):
+    """Three one-second measurements that characterise THIS box independently of the kernels under test (round 5: leases of
+    one pool ran the identical step 16.5 % apart with nothing in clocks / power / throttle flags to show for it): a copy that
+    streams HBM, a copy that stays in the memory-side cache, the vendor library's large bf16 GEMM.  Reported, never used."""
+    out = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    def timed(fn, reps):
+        for _ in range(2):
+            fn()
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+    try:
+        a = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        b = torch.empty_like(a)
+        out["hbm_copy_gb_s"] = 2 * a.numel() / timed(lambda: b.copy_(a), 10) / 1e9          # read + write
+        c, d = a[:32 << 20], b[:32 << 20]
+        out["cache_resident_copy_gb_s"] = 2 * c.numel() / timed(lambda: d.copy_(c), 50) / 1e9
+        del a, b, c, d
+        x = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+        y = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+        out["vendor_gemm_8192_bf16_tflops"] = 2 * 8192 ** 3 / timed(lambda: torch.matmul(x, y), 10) / 1e12
+        del x, y
+        pr = torch.cuda.get_device_properties(dev)
+        out["device"] = {"name": pr.name, "compute_units": pr.multi_processor_count, "total_memory_gb": round(pr.total_memory / 2 ** 30, 1),
+                         "clock_rate_mhz": getattr(pr, "clock_rate", 0) / 1e3, "memory_clock_rate_mhz": getattr(pr, "memory_clock_rate", 0) / 1e3,
+                         "l2_cache_mb": getattr(pr, "L2_cache_size", 0) / 2 ** 20, "gcn_arch": getattr(pr, "gcnArchName", "")}
+        torch.cuda.empty_cache()
+    except Exception as e:      # never in the way of the number
+        out["error"] = repr(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -506,6 +544,7 @@ def main():
             tele = None
             print(f"telemetry unavailable: {e!r}", file=sys.stderr)
     tele_idle = tele.snapshot() if tele else None
+    box = box_calibration(dev) if (not emu and rank == 0 and not args.no_telemetry) else None
     for i in range(args.warmup):
         one(i)
     barrier()
@@ -596,6 +635,8 @@ def main():
                 "host_lead_ms[i] = GPU completion time of step i - time the host returned from enqueueing it: positive = the GPU was "
                 "the bottleneck, near zero = the launch path was",
     }
+    if box is not None:
+        out["box_calibration"] = box
     if tele:
         out["telemetry"] = {"idle_before_warmup": tele_idle, "before_timed": tele_before, "after_timed": tele_after,
                             "during_timed": Telemetry.summarize(tele_samples, t0, t1_host),

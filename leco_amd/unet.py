@@ -352,6 +352,26 @@ class GemmSite:
 # =============================================================================================
 # the engine
 # =============================================================================================
+class LnFoldState:
+    """Pack-time operands of `leco_gemm_args.ln_s` for one (Linear, preceding LayerNorm) pair: W' = bf16(gamma (.) W),
+    s[n] = sum_k W'[n][k] (of the ROUNDED weights: what the MFMA multiplies), c[n] = sum_k beta[k] W[n][k] + bias[n]; the
+    stacked lora_down image dn_ln / sd / cd is (re)built on the device by `leco_lnfold_pack`."""
+
+    def __init__(self, eng: "Engine", site: "GemmSite", norm_name: str, geglu: bool):
+        gamma, beta = eng.norm_p[norm_name]
+        w, b = site.w_geglu if geglu else (site.w, site.bias)
+        self.lora, self.k = site.lora, site.k
+        self.gamma, self.beta = gamma, beta
+        self.w = (w.float() * gamma[None, :]).to(bf16).contiguous()
+        self.s = self.w.float().sum(1).contiguous()
+        c = w.float() @ beta
+        self.c = (c + b.float() if b is not None else c).contiguous()
+        dev = w.device
+        self.dn_ln = torch.zeros(16, site.k, dtype=bf16, device=dev)
+        self.sd = torch.zeros(16, dtype=torch.float32, device=dev)
+        self.cd = torch.zeros(16, dtype=torch.float32, device=dev)
+
+
 class Plan:
     def __init__(self):
         # named launch lists; callers may add their own (e.g. the fused denoising pass)
@@ -519,7 +539,30 @@ class Engine:
             self._pack_scale = multiplier
         with ops.f32_mode(self.f32):
             ops.lora_pack(self._pack_dev, len(self.lora_sites)).run()
+        self.lnfold_repack()
         net._packed_version = net.version
+
+    # ---- LayerNorm folded into its consuming Linear (leco_gemm_args.ln_s; forward-only LoRA-on passes) ---------------
+    def lnfold_state(self, site: "GemmSite", norm_name: str, geglu: bool) -> "LnFoldState":
+        """Operands of the fold for (Linear site, the LayerNorm in front of it): built once, the LoRA half re-packed with
+        every `refresh_lora`."""
+        reg = self.__dict__.setdefault("_lnf", {})
+        key = (site.name, norm_name, geglu)
+        if key not in reg:
+            reg[key] = LnFoldState(self, site, norm_name, geglu)
+            tab = (hip.LnFoldSite * len(reg))()
+            for i, st in enumerate(reg.values()):
+                tab[i].dn_s, tab[i].gamma, tab[i].beta = st.lora.dn_s.data_ptr(), st.gamma.data_ptr(), st.beta.data_ptr()
+                tab[i].dn_ln, tab[i].sd, tab[i].cd, tab[i].k = st.dn_ln.data_ptr(), st.sd.data_ptr(), st.cd.data_ptr(), st.k
+            self._lnf_host = tab
+            self._lnf_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+            self.lnfold_repack()         # the new entry is valid at once (plans may be built between two re-packs)
+        return reg[key]
+
+    def lnfold_repack(self) -> None:
+        reg = self.__dict__.get("_lnf")
+        if reg:
+            ops.lnfold_pack(self._lnf_dev, len(reg)).run()
 
     # ---- plan construction ---------------------------------------------------------------------
     def plan(self, B: int, h: int, w: int, need_bwd: bool = True, ws_slot: int = 0, share: int = 1) -> Plan:
@@ -1112,7 +1155,7 @@ class PlanBuilder:
         import os
         site1 = eng.sites[rname + ".conv1"]
         fin_in_gn = (not self.need_bwd and not eng.f32 and tsite is None and site1.lora is None
-                     and os.environ.get("LECO_GN_FINISH", "1") not in ("", "0")
+                     and os.environ.get("LECO_GN_FINISH", "0") not in ("", "0")      # measured neutral on MI355X: off
                      and bool(hip.lib().leco_groupnorm_single_launch(self.B, hw, m.out_channels, self.cfg.norm_num_groups)))
         h1 = self.gemm_fwd(site1, n1, rname + ".h1", conv=conv, amode=A_CONV3_S1, rows=rows,
                            rowbias=temb.data_ptr() + 4 * off, rows_per_group=hw, ld_rowbias=eng.temb_total, bias=None,
@@ -1234,6 +1277,49 @@ class PlanBuilder:
             lst.append(ops.xblock_tail(A, keep=keep))
         return out
 
+    def lnfold_ok(self, site: GemmSite, kind: str) -> bool:
+        """LayerNorm -> Linear as one launch (leco_gemm_args.ln_s) in the LoRA-on list of a forward-only bf16 plan: needs the
+        16-row fused down-projection with a free row for the ones-row (groups * rank <= 15).  LECO_LNFOLD=0 switches it
+        off, a comma list of {qkv, q, ff} restricts it to those consumers (A/B measurements)."""
+        import os
+        # DEFAULT OFF.  Measured on MI355X (profiles/r05_plan_denoise_{base,ln}.txt, r05_bench_fuse_*.json, r05_bench_lnfold_*.json):
+        # launch by launch the q|k|v / to_q consumers grow by 0.8 - 5 us where the LayerNorm launch they absorb costs 8 (the GEGLU
+        # projection, with four times the columns and no registers to spare in its two-workgroups-per-CU form, grows by 8 - 15 us),
+        # 31 launches and 0.09 ms less per pass in isolation -- but the whole step moved by +0.2 % on one lease (all three
+        # folds) and by -1.5 % on another (q|k|v + to_q only, two interleaved A/B pairs).  Not a win that survives a step.
+        sel = os.environ.get("LECO_LNFOLD", "0")
+        if self.need_bwd or self.eng.f32 or sel in ("", "0") or (sel not in ("1", "all") and kind not in sel.split(",")):
+            return False
+        lo = site.lora
+        return lo is not None and lo.Rp == 32 and lo.R16 == 16 and lo.R <= 15
+
+    def ln_linear(self, norm_name: str, site: GemmSite, x: TRef, ln_name: str, name: str, rows: int, kind: str,
+                  geglu: bool = False) -> TRef:
+        """y = Linear(LayerNorm(x)) [GEGLU].  Both lists get the two-launch chain; where the fold applies, the LoRA-ON list's
+        pair (what the k denoising passes replay) is replaced by ONE launch on the raw rows."""
+        n_on = len(self.f_on)
+        l = self.layernorm(norm_name, x, ln_name)
+        y = self.gemm_fwd(site, l, name, rows=rows, geglu=geglu)
+        std = self.f_on[n_on:]
+        if not self.lnfold_ok(site, kind) or len(std) != 2 or std[0].name != "leco_layernorm_fwd" or std[1].name != "leco_gemm_ex":
+            return y
+        gstd, tile, split = std[1].keep[0], std[1].args[1], std[1].args[2]
+        if split > 1 or not gstd.t_w or gstd.t_rows != 16 or gstd.a1 or gstd.rowbias or gstd.residual or gstd.col_stats:
+            return y
+        st = self.eng.lnfold_state(site, norm_name, geglu)
+        g = hip.GemmArgs.from_buffer_copy(gstd)
+        g.a0, g.lda0 = x.ptr, x.ld
+        g.w, g.t_w = st.w.data_ptr(), st.dn_ln.data_ptr()
+        g.bias, g.t_out = None, None
+        g.ln_s, g.ln_c, g.ln_sd, g.ln_cd, g.ln_eps = st.s.data_ptr(), st.c.data_ptr(), st.sd.data_ptr(), st.cd.data_ptr(), 1e-5
+        # the 4-wave / two-workgroups-per-CU form of the 128 x 128 tile has no registers to spare for the statistics
+        # (268 > 256: it would run one workgroup per CU): those launches take the 8-wave form
+        if "gemm_kernel<128, 128, false, 2, 2," in hip.gemm_describe(g, tile, 1):
+            tile = 6
+        del self.f_on[n_on:]
+        self.f_on.append(ops.Op("leco_gemm_ex", (C.byref(g), tile, 1, None, 0), keep=(g, st, site, x, y, std[1].keep)))
+        return y
+
     def basic_block(self, bname: str, hcur: TRef, ctx: TRef, heads: int, hw: int, tname: str = "", last: bool = False,
                     x_res: Optional[TRef] = None, qkv: Optional[TRef] = None) -> Tuple[TRef, bool]:
         """Returns (output, done): `done` = the output already is the Transformer2DModel's (proj_out + residual applied by the
@@ -1243,8 +1329,7 @@ class PlanBuilder:
         S = eng.sites
         fused = bool(tname) and self.stripe_ok(bname, tname, Cc, heads, hw, ctx.rows // self.Bfull)
         if qkv is None:
-            l1 = self.layernorm(bname + ".norm1", hcur, bname + ".l1")
-            qkv = self.gemm_fwd(S[bname + ".attn1.qkv"], l1, bname + ".qkv", rows=rows)
+            qkv = self.ln_linear(bname + ".norm1", S[bname + ".attn1.qkv"], hcur, bname + ".l1", bname + ".qkv", rows, "qkv")
         a1 = self.attention(qkv, qkv, heads, hw, hw, bname + ".a1")
         if fused:
             n_on, n_off = len(self.f_on), len(self.f_off)
@@ -1253,8 +1338,7 @@ class PlanBuilder:
                 op.tag = "ctx"
             return self.block_tail_fused(bname, tname, a1, hcur, kv, heads, hw, last, x_res), last
         h1 = self.gemm_fwd(S[bname + ".attn1.to_out.0"], a1, bname + ".h1", rows=rows, residual=hcur)
-        l2 = self.layernorm(bname + ".norm2", h1, bname + ".l2")
-        q2 = self.gemm_fwd(S[bname + ".attn2.to_q"], l2, bname + ".q2", rows=rows)
+        q2 = self.ln_linear(bname + ".norm2", S[bname + ".attn2.to_q"], h1, bname + ".l2", bname + ".q2", rows, "q")
         # K/V of cross-attention depend only on the prompt embeddings (and the LoRA weights): tag their ops
         # so that callers replaying the same prompt (the k denoising passes of a step) can run them once
         n_on, n_off = len(self.f_on), len(self.f_off)
@@ -1263,11 +1347,11 @@ class PlanBuilder:
             op.tag = "ctx"
         a2 = self.attention(q2, kv, heads, hw, ctx.rows // self.B, bname + ".a2")
         h2 = self.gemm_fwd(S[bname + ".attn2.to_out.0"], a2, bname + ".h2", rows=rows, residual=h1)
-        l3 = self.layernorm(bname + ".norm3", h2, bname + ".l3")
         ff1 = S[bname + ".ff.net.0.proj"]
         if not self.need_bwd and not eng.f32 and ff1.geglu_ok and (ff1.lora is None or (ff1.lora.Rp == 32 and ff1.lora.up_pg is not None)):
-            gg = self.gemm_fwd(ff1, l3, bname + ".geglu", rows=rows, geglu=True)
+            gg = self.ln_linear(bname + ".norm3", ff1, h2, bname + ".l3", bname + ".geglu", rows, "ff", geglu=True)
             return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2), False
+        l3 = self.layernorm(bname + ".norm3", h2, bname + ".l3")
         u = self.gemm_fwd(ff1, l3, bname + ".u", rows=rows)
         gg = self.act(bname + ".geglu", rows, 4 * Cc, rg=u.rg)
         self.both(ops.Op("leco_geglu_fwd", (u.ptr, u.ld, gg.ptr, gg.ld, rows, 4 * Cc), keep=(u, gg)))

@@ -167,6 +167,34 @@ class Telemetry:
                     out[f"{nm}_clk_locked"] = ci.get("clk_locked")
             except Exception:
                 pass
+        # what distinguishes one box of a pool from another beyond the shader clock: fabric / SoC clocks, partition modes,
+        # the ASIC itself (round 5: two leases ran every kernel of the same step 16.5 % apart at the SAME memory clock, the
+        # slower one at a HIGHER shader clock and LOWER power)
+        for nm, ct in (("soc", "SOC"), ("df", "DF")):
+            try:
+                ci = smi.amdsmi_get_clock_info(self.h, getattr(smi.AmdSmiClkType, ct))
+                out[f"{nm}_clk_mhz"] = {k: ci.get(k) for k in ("clk", "min_clk", "max_clk") if _num(ci.get(k)) is not None}
+            except Exception:
+                pass
+        try:
+            m2 = self._metrics()
+            for k in ("current_socclk", "average_socclk_frequency", "vram_max_bandwidth", "pcie_link_width", "pcie_link_speed",
+                      "num_partition", "xgmi_link_width", "xgmi_link_speed"):
+                if _num(m2.get(k)) is not None:
+                    out[k] = m2[k]
+            socs = [c for c in (m2.get("current_socclks") or []) if _num(c)]
+            if socs:
+                out["current_socclks"] = socs
+        except Exception:
+            pass
+        for key, fn in (("compute_partition", "amdsmi_get_gpu_compute_partition"), ("memory_partition", "amdsmi_get_gpu_memory_partition"),
+                        ("asic", "amdsmi_get_gpu_asic_info"), ("vram", "amdsmi_get_gpu_vram_info"), ("vbios", "amdsmi_get_gpu_vbios_info"),
+                        ("driver", "amdsmi_get_gpu_driver_info"), ("perf_level", "amdsmi_get_gpu_perf_level")):
+            try:
+                v = getattr(smi, fn)(self.h)
+                out[key] = {k: (x if isinstance(x, (int, float, str, bool)) else str(x)) for k, x in v.items()} if isinstance(v, dict) else str(v)
+            except Exception:
+                pass
         try:
             v = smi.amdsmi_get_violation_status(self.h)
             out["violation_status"] = {k: x for k, x in v.items() if ("active" in k or "per_" in k) and _num(x) is not None and x}
