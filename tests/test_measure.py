@@ -35,12 +35,12 @@ def test_describe_names_the_instantiation_the_dispatcher_would_launch():
     # large plain 128x128 grids run as 4-wave workgroups (two per CU); explicit tile ids pin either form
     g = _args(16384, 2560, 320)
     assert "gemm_kernel<128, 128, false, 2, 2, 0, false>" in hip.gemm_describe(g, 0, 0, wsp, wsb)
-    assert "gemm_kernel<128, 128, false, 4, 4, 0>" in hip.gemm_describe(g, 6, 1)
+    assert "gemm_kernel<128, 128, false, 4, 4, 0, false>" in hip.gemm_describe(g, 6, 1)
     assert "gemm_kernel<128, 128, false, 2, 2, 0, false>" in hip.gemm_describe(g, 5, 1)
     # fused LoRA down-projection on a deep-K small-M shape: the unsplit 64x64 grid keeps it fused (one kernel)
     x = torch.zeros(8, 8, dtype=bf)
     g = _args(1024, 1280, 5120, w_ext=x, ext_k=32, t_w=x, t_rows=16, t_out=x)
-    assert hip.gemm_describe(g, 0, 0, wsp, wsb) == "gemm_kernel<64, 64, false, 4, 2, 1> grid=320 split=1"
+    assert hip.gemm_describe(g, 0, 0, wsp, wsb) == "gemm_kernel<64, 64, false, 4, 2, 1, false> grid=320 split=1"
 
 
 def test_tuner_keys_candidates_and_table():
