@@ -62,3 +62,16 @@ except Exception as e: print(sys.argv[1], 'FAILED', e)
 PY
 done
 fi
+if [ "$what" = "configs_quick" ]; then      # BASELINE configs 3-5 with the committed launch-shape table (no re-tuning)
+( timeout 200 python bench.py --arch sd21 --res 768 --v-pred --steps 6 --warmup 2 --no-cpu-baseline --no-dominant 2>/dev/null | tail -1 ) > $O/${RN}_bench_sd21_768.json
+( timeout 300 python bench.py --arch sdxl --res 1024 --bs 1 --rank 16 --steps 6 --warmup 2 --no-cpu-baseline --no-dominant 2>/dev/null | tail -1 ) > $O/${RN}_bench_sdxl_1024.json
+( timeout 200 python bench.py --bs 4 --rank 8 --c3lier --steps 6 --warmup 2 --no-cpu-baseline --no-dominant 2>/dev/null | tail -1 ) > $O/${RN}_bench_sd15_c3lier_bs4.json
+for f in ${RN}_bench_sd21_768 ${RN}_bench_sdxl_1024 ${RN}_bench_sd15_c3lier_bs4; do python - $O/$f.json <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read()); b=d.get('box_calibration',{})
+    print(sys.argv[1].split('/')[-1], round(d['value'],3),'steps/s', round(d['ms_per_step'],1),'ms k_mean',d['config']['k_mean'],'whole-step frac',round(d['roofline']['whole_step']['frac'],3),'loss',d['config']['loss'], 'box', {k: round(v,1) for k,v in b.items() if isinstance(v,(int,float))})
+except Exception as e: print(sys.argv[1], 'FAILED', e)
+PY
+done
+fi
