@@ -255,30 +255,31 @@ class FusedStep:
 
     def _ctx(self, pair: PromptEmbedsPair, which: str, bs: int) -> torch.Tensor:
         key = (id(pair), which, bs)
-        c = self._ctx_cache.get(key)
-        if c is None:
+        hit = self._ctx_cache.get(key)
+        if hit is None:
             c = train_util.concat_embeddings(self._text(pair.unconditional), self._text(getattr(pair, which)), bs)
             c = c.to(self.dev, self.adt).contiguous()
-            self._ctx_cache[key] = c
-        return c
+            # (the entry holds the pair itself: its id cannot be re-used by another pair while the cached tensor lives, and
+            # `_set_ctx` may compare cached tensors by identity)
+            hit = self._ctx_cache[key] = (pair, c)
+        return hit[1]
 
     def _pooled(self, pair: PromptEmbedsPair, which: str, bs: int) -> torch.Tensor:
         """SDXL add_text_embeddings = concat(uncond.pooled, cond.pooled) (train_lora_xl.py:214-218)."""
         key = (id(pair), "pooled." + which, bs)
-        c = self._ctx_cache.get(key)
-        if c is None:
+        hit = self._ctx_cache.get(key)
+        if hit is None:
             c = train_util.concat_embeddings(pair.unconditional.pooled_embeds, getattr(pair, which).pooled_embeds, bs)
-            c = c.to(self.dev, self.adt).contiguous()
-            self._ctx_cache[key] = c
-        return c
+            hit = self._ctx_cache[key] = (pair, c.to(self.dev, self.adt).contiguous())
+        return hit[1]
 
     def _ctx3(self, pair: PromptEmbedsPair, bs: int) -> torch.Tensor:
         key = (id(pair), "frozen3", bs)
-        c = self._ctx_cache.get(key)
-        if c is None:
+        hit = self._ctx_cache.get(key)
+        if hit is None:
             c = torch.cat([self._ctx(pair, w, bs) for w in ("positive", "neutral", "unconditional")]).contiguous()
-            self._ctx_cache[key] = c
-        return c
+            hit = self._ctx_cache[key] = (pair, c)
+        return hit[1]
 
     def _run(self, plan, which: str):
         self.unet._run(plan, which)
