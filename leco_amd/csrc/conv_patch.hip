@@ -44,6 +44,13 @@ namespace {
 
 constexpr int BK = 64;
 
+// Tuning aid (tools/ablate_conv.py builds a side library with -DLECO_CONV_ABLATE=<bit mask>): 1 = no steady-state fragment
+// reads (the LDS -> register traffic of the tap loop), 2 = no MFMAs.  Results are garbage with any bit set; only the timing
+// is meaningful.  0 in the product build.
+#ifndef LECO_CONV_ABLATE
+#define LECO_CONV_ABLATE 0
+#endif
+
 struct PatchRt {
     int tiles_n, tiles_x, tiles_g;   // grid.x = tiles_g * tiles_x * tiles_n
     int split_k;                     // > 1: raw fp32 partials to ws[split][M][N], epilogue by splitk_finish
@@ -309,8 +316,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             const int pbn = tap == 8 ? pb ^ 1 : pb;
             const unsigned char* abuf = lds + OFF_A + pbn * PBUF;
             const unsigned char* wbuf = lds + snext * WTILE + wl0;
-            read_a1(pb, afB);
-            read_w(slot, 1, wfB);
+            if (!(LECO_CONV_ABLATE & 1)) {
+                read_a1(pb, afB);
+                read_w(slot, 1, wfB);
+            }
             // byte offsets of the NEXT step's activation fragments: VALU work beside the MFMAs of set A, so that the reads
             // themselves can go out right behind the barrier
             constexpr int khn = (tap + 1) % 9 / 3, kwn = (tap + 1) % 9 % 3;
@@ -330,13 +339,16 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
                     barrier_keep_dma();       // ... for every wave; all waves are done with tile t's slot (completes set B)
                     landed(afB, wfB);
                     // first fragment reads of the next step (ks = 0) right behind the barrier
+                    if (!(LECO_CONV_ABLATE & 1)) {
 #pragma unroll
-                    for (int q = 0; q < FM; ++q) afA[q] = lds_read16_async(abuf + aoff[q]);
+                        for (int q = 0; q < FM; ++q) afA[q] = lds_read16_async(abuf + aoff[q]);
 #pragma unroll
-                    for (int q = 0; q < FN; ++q) wfA[q] = lds_read16_async(wbuf + q * (16 * BK * 2));
+                        for (int q = 0; q < FN; ++q) wfA[q] = lds_read16_async(wbuf + q * (16 * BK * 2));
+                    }
                     sched_fence();
                 }
-                if (m < P) acc[i][j] = mfma16(wfA[j], afA[i], acc[i][j]);
+                if (LECO_CONV_ABLATE & 2) { if (m == 0) acc[i][j][0] += __uint_as_float((unsigned)(wfA[j][0] ^ afA[i][0] ^ wfB[j][0] ^ afB[i][0])); }
+                else if (m < P) acc[i][j] = mfma16(wfA[j], afA[i], acc[i][j]);
                 else acc[i][j] = mfma16(wfB[j], afB[i], acc[i][j]);
 #pragma unroll
                 for (int d = 0; d < ND; ++d)
