@@ -38,6 +38,22 @@ cd $R
 ( timeout 100 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3 ) > $O/${RN}_smoke.log 2>&1
 cut -c1-1800 $O/${RN}_bench.json; head -14 $O/${RN}_step_kernel_stats.txt; head -4 $O/${RN}_pmc_dominant_mfma.csv; head -4 $O/${RN}_pmc_dominant_fetch.csv; tail -3 /tmp/pmc_dm.log; cat $O/${RN}_smoke.log
 fi
+if [ "$what" = "trace" ]; then      # the kernel trace + the dominant kernel's counter passes only (after a source change that does not alter the product build)
+cd /tmp
+timeout 420 rocprofv3 --kernel-trace --stats -d /tmp/prof -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dominant > /tmp/prof.log 2>&1
+DB=$(find /tmp/prof -name "*.db" | head -1)
+{ echo "# cd /tmp && rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-dominant   (tools/gpu_round_run.sh; the driver's own --steps/--warmup, so the k sequence and launch mix are the benchmark's)"
+  echo "# SD1.5 bs=2 512^2 rank-4 LECO step; summarised from the rocpd database with tools/rocpd_stats.py"
+  echo "# csrc_sha1=$(cd $R && python -c 'import bench; print(bench.kernel_sources_hash())')"
+  python $R/tools/rocpd_stats.py $DB 60; } > $O/${RN}_step_kernel_stats.txt 2>&1
+cp $O/${RN}_step_kernel_stats.txt $R/profiles/${RN}_step_kernel_stats.txt
+timeout 100 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pmc_dm -o dom -- python $R/bench.py --dominant-only --no-cpu-baseline > /tmp/pmc_dm.log 2>&1
+python $R/tools/pmc_summary.py /tmp/pmc_dm > $O/${RN}_pmc_dominant_mfma.csv 2>&1
+timeout 100 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d /tmp/pmc_df -o dom -- python $R/bench.py --dominant-only --no-cpu-baseline > /tmp/pmc_df.log 2>&1
+python $R/tools/pmc_summary.py /tmp/pmc_df > $O/${RN}_pmc_dominant_fetch.csv 2>&1
+cd $R
+head -16 $O/${RN}_step_kernel_stats.txt; head -4 $O/${RN}_pmc_dominant_mfma.csv; head -4 $O/${RN}_pmc_dominant_fetch.csv
+fi
 if [ "$what" = "tests" ]; then
   timeout 1300 python -m pytest tests -q -m gpu -s > /tmp/gpu_tests_full.log 2>&1; echo "pytest rc=$?" >> /tmp/gpu_tests_full.log
   { grep -vE "^W2026|Warn|warn|hipGraph|\^~|^ +[0-9]+ \|" /tmp/gpu_tests_full.log | tail -150; grep -E " passed| failed|^FAILED|^ERROR|pytest rc=" /tmp/gpu_tests_full.log | tail -12; } > $O/${RN}_gpu_tests.log 2>&1
