@@ -2,7 +2,9 @@
 #include <hip/hip_runtime.h>
 
 #include <sys/mman.h>
+#if !defined(__x86_64__)
 #include <ucontext.h>
+#endif
 
 #include <atomic>
 #include <condition_variable>
@@ -18,13 +20,47 @@ namespace {
 constexpr size_t kStack = 256 * 1024;
 constexpr int kMaxThreads = 1024;
 
+// Work-item switch.  glibc's swapcontext saves and restores the signal mask with a system call on every switch,
+// and a kernel with a few hundred barriers / cross-lane gathers per workgroup switches millions of times per launch:
+// on x86-64 the switch is the six callee-saved registers and the stack pointer, nothing else (no work-item changes
+// the signal mask or the floating-point control words).  Other hosts keep ucontext.
+#if defined(__x86_64__)
+struct Ctx { void* sp; };
+extern "C" void leco_emu_switch(Ctx* from, Ctx* to);
+asm(R"(
+    .text
+    .globl leco_emu_switch
+    .type leco_emu_switch,@function
+leco_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq (%rsi), %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size leco_emu_switch, .-leco_emu_switch
+)");
+#else
+struct Ctx { ucontext_t uc; };
+static inline void leco_emu_switch(Ctx* from, Ctx* to) { swapcontext(&from->uc, &to->uc); }
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Ctx ctx;
     bool done;
 };
 
 struct Runner {
-    ucontext_t sched;
+    Ctx sched;
     Fiber fibers[kMaxThreads];
     char* stacks = nullptr;
     int n = 0, cur = 0;
@@ -51,7 +87,32 @@ void trampoline() {
     Runner* r = tl_runner;
     (*r->body)();
     r->fibers[r->cur].done = true;
-    // returns to uc_link (scheduler)
+#if defined(__x86_64__)
+    leco_emu_switch(&r->fibers[r->cur].ctx, &r->sched);     // a finished work-item is never resumed
+    __builtin_trap();
+#endif
+    // ucontext: returns to uc_link (scheduler)
+}
+
+void make_fiber(Runner* r, int i) {
+    Fiber& f = r->fibers[i];
+    f.done = false;
+    char* top = r->stacks + (size_t)(i + 1) * kStack;       // 16-byte aligned (kStack is, the mapping is)
+#if defined(__x86_64__)
+    // What leco_emu_switch pops on the first switch in: six zeroed callee-saved registers, then `ret` into the
+    // trampoline with the stack as a `call` would have left it (rsp % 16 == 8; the slot above is a null return address).
+    void** sp = (void**)top - 8;
+    for (int k = 0; k < 6; ++k) sp[k] = nullptr;
+    sp[6] = (void*)&trampoline;
+    sp[7] = nullptr;
+    f.ctx.sp = sp;
+#else
+    getcontext(&f.ctx.uc);
+    f.ctx.uc.uc_stack.ss_sp = top - kStack;
+    f.ctx.uc.uc_stack.ss_size = kStack;
+    f.ctx.uc.uc_link = &r->sched.uc;
+    makecontext(&f.ctx.uc, trampoline, 0);
+#endif
 }
 
 void set_tid(Runner* r, int i) {
@@ -63,7 +124,7 @@ void set_tid(Runner* r, int i) {
 void yield_fiber() {
     Runner* r = tl_runner;
     int me = r->cur;
-    swapcontext(&r->fibers[me].ctx, &r->sched);
+    leco_emu_switch(&r->fibers[me].ctx, &r->sched);
 }
 
 void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
@@ -74,15 +135,7 @@ void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
     r->body = &body;
     r->block_arrived = 0;
     for (int w = 0; w < kMaxThreads / 64; ++w) r->wave_arrived[w] = 0;
-    for (int i = 0; i < r->n; ++i) {
-        Fiber& f = r->fibers[i];
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = r->stacks + (size_t)i * kStack;
-        f.ctx.uc_stack.ss_size = kStack;
-        f.ctx.uc_link = &r->sched;
-        f.done = false;
-        makecontext(&f.ctx, trampoline, 0);
-    }
+    for (int i = 0; i < r->n; ++i) make_fiber(r, i);
     int live = r->n;
     long spins = 0;
     while (live > 0) {
@@ -90,7 +143,7 @@ void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
             if (r->fibers[i].done) continue;
             r->cur = i;
             set_tid(r, i);
-            swapcontext(&r->sched, &r->fibers[i].ctx);
+            leco_emu_switch(&r->sched, &r->fibers[i].ctx);
             if (r->fibers[i].done) --live;
         }
         if (++spins > 200000000L) { fprintf(stderr, "emu: deadlock (divergent barrier?)\n"); abort(); }

@@ -7,8 +7,8 @@
 // with host clang++ and `-I tests/emu`, which makes `#include <hip/hip_runtime.h>` and
 // `#include <leco_prims.h>` resolve to this directory instead of ROCm / csrc/prims.
 //
-// Execution model: one workgroup at a time per OS thread; its work-items are ucontext
-// fibers scheduled round-robin.  __syncthreads() and the wave64 collectives (MFMA,
+// Execution model: one workgroup at a time per OS thread; its work-items are fibers
+// (a register-only context switch on x86-64, ucontext elsewhere: emu_runtime.cpp) scheduled round-robin.  __syncthreads() and the wave64 collectives (MFMA,
 // shuffles) are rendezvous points; the last arriver of a wave collective performs it for
 // the whole wave.  Lane<->matrix-element maps follow cdna_hip_programming.md section 3.
 #pragma once
