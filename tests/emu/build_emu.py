@@ -58,5 +58,16 @@ def build(verbose=False):
     return lib
 
 
+def build_selftest():
+    """tests/emu/selftest_sched.cpp + the fiber runtime as a stand-alone program (the work-item schedules' own test)."""
+    os.makedirs(OUT, exist_ok=True)
+    srcs = [os.path.join(HERE, "selftest_sched.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
+    exe = os.path.join(OUT, "selftest_sched." + hashlib.sha1("".join(_digest(x) for x in srcs).encode()).hexdigest()[:16])
+    if not os.path.exists(exe):
+        subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O2", "-pthread", "-Wno-unknown-attributes", "-Wno-unused-value",
+                        "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC, *srcs, "-o", exe], check=True)
+    return exe
+
+
 if __name__ == "__main__":
     print(build(verbose="-v" in sys.argv))

@@ -64,6 +64,8 @@ struct Runner {
     Fiber fibers[kMaxThreads];
     char* stacks = nullptr;
     int n = 0, cur = 0;
+    unsigned long events = 0;        // completed rendezvous + finished work-items (progress, for the greedy schedules)
+    unsigned long rng = 0x9E3779B97F4A7C15ul;
     int block_arrived = 0;
     unsigned block_gen = 0;
     int wave_arrived[kMaxThreads / 64] = {};
@@ -83,10 +85,31 @@ struct Runner {
 };
 thread_local Runner* tl_runner = nullptr;
 
+// Work-item schedules.  Any interleaving of the waves of a workgroup between its barriers is legal on the hardware, so
+// every kernel must give the same result under each of them: round-robin (default: the waves advance in near lockstep, one
+// rendezvous per sweep), reverse, random (random wave order, a wave may run a few rendezvous ahead) and greedy /
+// greedy_reverse (one wave runs as far as it can -- to the next block barrier -- before the next one moves at all: the
+// extreme skew that exposes an LDS buffer reused without a barrier).  LECO_EMU_SCHED selects.
+enum { kRoundRobin = 0, kReverse, kRandom, kGreedy, kGreedyReverse };
+int sched_mode() {
+    static const int m = [] {
+        const char* e = getenv("LECO_EMU_SCHED");
+        if (!e || !*e || !strcmp(e, "rr")) return (int)kRoundRobin;
+        if (!strcmp(e, "reverse")) return (int)kReverse;
+        if (!strcmp(e, "random")) return (int)kRandom;
+        if (!strcmp(e, "greedy")) return (int)kGreedy;
+        if (!strcmp(e, "greedy_reverse")) return (int)kGreedyReverse;
+        fprintf(stderr, "emu: unknown LECO_EMU_SCHED=%s\n", e);
+        abort();
+    }();
+    return m;
+}
+
 void trampoline() {
     Runner* r = tl_runner;
     (*r->body)();
     r->fibers[r->cur].done = true;
+    ++r->events;
 #if defined(__x86_64__)
     leco_emu_switch(&r->fibers[r->cur].ctx, &r->sched);     // a finished work-item is never resumed
     __builtin_trap();
@@ -138,13 +161,44 @@ void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
     for (int i = 0; i < r->n; ++i) make_fiber(r, i);
     int live = r->n;
     long spins = 0;
+    auto resume = [&](int i) {
+        if (r->fibers[i].done) return;
+        r->cur = i;
+        set_tid(r, i);
+        leco_emu_switch(&r->sched, &r->fibers[i].ctx);
+        if (r->fibers[i].done) --live;
+    };
+    const int mode = sched_mode();
+    const int nw = (r->n + 63) / 64;
+    auto sweep_wave = [&](int w, bool down) {
+        int lo = w * 64, hi = lo + 64 < r->n ? lo + 64 : r->n;
+        if (down) for (int i = hi - 1; i >= lo; --i) resume(i);
+        else for (int i = lo; i < hi; ++i) resume(i);
+    };
     while (live > 0) {
-        for (int i = 0; i < r->n; ++i) {
-            if (r->fibers[i].done) continue;
-            r->cur = i;
-            set_tid(r, i);
-            leco_emu_switch(&r->sched, &r->fibers[i].ctx);
-            if (r->fibers[i].done) --live;
+        if (mode == kRoundRobin) {
+            for (int i = 0; i < r->n; ++i) resume(i);
+        } else if (mode == kReverse) {
+            for (int i = r->n - 1; i >= 0; --i) resume(i);
+        } else if (mode == kRandom) {
+            int order[kMaxThreads / 64];
+            for (int w = 0; w < nw; ++w) order[w] = w;
+            for (int w = nw - 1; w > 0; --w) {
+                r->rng ^= r->rng << 13; r->rng ^= r->rng >> 7; r->rng ^= r->rng << 17;
+                int j = (int)(r->rng % (unsigned long)(w + 1));
+                int t = order[w]; order[w] = order[j]; order[j] = t;
+            }
+            for (int w = 0; w < nw; ++w) {
+                r->rng ^= r->rng << 13; r->rng ^= r->rng >> 7; r->rng ^= r->rng << 17;
+                int reps = 1 + (int)((r->rng >> 20) % 4);       // a wave may get a few rendezvous ahead of the others
+                for (int k = 0; k < reps; ++k) sweep_wave(order[w], (r->rng >> (8 + k)) & 1);
+            }
+        } else {    // greedy: one wave runs until it can only wait for the others (a block barrier), then the next
+            for (int k = 0; k < nw; ++k) {
+                int w = mode == kGreedy ? k : nw - 1 - k;
+                unsigned long before;
+                do { before = r->events; sweep_wave(w, false); } while (r->events != before);
+            }
         }
         if (++spins > 200000000L) { fprintf(stderr, "emu: deadlock (divergent barrier?)\n"); abort(); }
     }
@@ -222,6 +276,7 @@ void sync_block() {
     if (++r->block_arrived == r->n) {
         r->block_arrived = 0;
         r->block_gen = g + 1;
+        ++r->events;
     } else {
         while (r->block_gen == g) yield_fiber();
     }
@@ -240,6 +295,7 @@ const unsigned char* wave_gather(const void* in, int bytes) {
     if (++r->wave_arrived[w] == wave_n) {
         r->wave_arrived[w] = 0;
         r->wave_gen[w] = g + 1;
+        ++r->events;
     } else {
         while (r->wave_gen[w] == g) yield_fiber();
     }

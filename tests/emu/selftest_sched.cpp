@@ -1,0 +1,59 @@
+// TEST INFRASTRUCTURE ONLY -- self-test of the emulator's work-item schedules (LECO_EMU_SCHED, emu_runtime.cpp).
+// Built and run by tests/test_host.py::test_emulator_schedules_*.  Two kernels, four waves each:
+//   order_kernel   records the order in which the waves pass three wave rendezvous: round-robin interleaves them
+//                  (0 1 2 3 0 1 2 3 ...), greedy lets a wave run to its end first (0 0 0 1 1 1 ...), the reversed
+//                  schedules mirror that;
+//   reuse_kernel   reuses one LDS slot per wave across iterations and, with `fenced == 0`, leaves out the barrier
+//                  between the last read of an iteration and the first write of the next one: a real race on the
+//                  hardware.  Near-lockstep round-robin never sees it; the greedy schedules must.
+// Prints "order: ..." and "reuse fenced=F: ok|RACE" lines.
+#include <hip/hip_runtime.h>
+#include <leco_prims.h>
+
+#include <cstdio>
+
+using namespace leco;
+
+__global__ void order_kernel(unsigned* cnt, int* order) {
+    const int wave = threadIdx.x >> 6;
+    for (int it = 0; it < 3; ++it) {
+        float v = leco::shfl_xor((float)threadIdx.x, 1);          // a wave rendezvous
+        if ((threadIdx.x & 63) == 0 && v >= 0.f) order[atomicAdd(cnt, 1u)] = wave;
+    }
+}
+
+__global__ void reuse_kernel(int* out, int fenced) {
+    __shared__ float slot[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float acc = 0.f;
+    for (int it = 0; it < 4; ++it) {
+        float mine = leco::shfl_xor((float)(100 * it + wave), 1);  // every lane of the wave holds 100 it + wave
+        if (lane == 0) slot[wave] = mine;
+        __syncthreads();
+        float nb = slot[(wave + 1) & 3];                          // the neighbour wave's value of THIS iteration
+        acc += leco::shfl_xor(nb, 1);
+        if (fenced) __syncthreads();                               // without it the neighbour may already hold it + 1
+    }
+    if (lane == 0) out[wave] = (int)acc;
+}
+
+int main() {
+    unsigned cnt = 0;
+    int order[12];
+    for (int& v : order) v = -1;
+    unsigned* pc = &cnt;
+    int* po = order;
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(256), 0, 0, pc, po);
+    printf("order:");
+    for (int v : order) printf(" %d", v);
+    printf("\n");
+    for (int fenced = 1; fenced >= 0; --fenced) {
+        int out[4] = {0, 0, 0, 0};
+        int* pout = out;
+        hipLaunchKernelGGL(reuse_kernel, dim3(1), dim3(256), 0, 0, pout, fenced);
+        bool ok = true;
+        for (int w = 0; w < 4; ++w) ok = ok && out[w] == 600 + 4 * ((w + 1) & 3);      // sum over it of 100 it + (w + 1) % 4
+        printf("reuse fenced=%d: %s\n", fenced, ok ? "ok" : "RACE");
+    }
+    return 0;
+}

@@ -272,6 +272,42 @@ def test_gemm_dma_protocol_under_late_completion():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_emulator_schedules_order_the_waves_and_expose_a_missing_barrier():
+    """The emulator's work-item schedules (LECO_EMU_SCHED, tests/emu/emu_runtime.cpp) on their own test program
+    (tests/emu/selftest_sched.cpp): the order in which four waves pass three rendezvous under each schedule, and an LDS
+    slot reused without the closing barrier -- a race the near-lockstep round-robin order cannot see and the greedy /
+    random orders must."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    exe = build_emu.build_selftest()
+
+    def run(mode):
+        r = subprocess.run([exe], env=dict(os.environ, LECO_EMU_SCHED=mode, LECO_EMU_THREADS="1"),
+                           capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        lines = dict(l.split(": ", 1) for l in r.stdout.strip().splitlines())
+        return [int(x) for x in lines["order"].split()], lines["reuse fenced=1"], lines["reuse fenced=0"]
+
+    assert run("rr") == ([0, 1, 2, 3] * 3, "ok", "ok")              # lockstep: blind to the missing barrier
+    assert run("reverse") == ([3, 2, 1, 0] * 3, "ok", "ok")
+    assert run("greedy") == ([0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3], "ok", "RACE")
+    assert run("greedy_reverse") == ([3, 3, 3, 2, 2, 2, 1, 1, 1, 0, 0, 0], "ok", "RACE")
+    order, fenced, unfenced = run("random")
+    assert sorted(order) == sorted([0, 1, 2, 3] * 3) and order != [0, 1, 2, 3] * 3 and fenced == "ok"
+
+
+@pytest.mark.parametrize("sched", ["greedy", "greedy_reverse", "random"])
+def test_kernels_give_the_same_results_under_every_wave_schedule(sched):
+    """Any interleaving of a workgroup's waves between its barriers is legal on the hardware: the whole kernel test
+    file must pass when one wave runs as far ahead of the others as the barriers allow (either end first) and under a
+    random wave order, not only in the default near-lockstep order -- an LDS buffer refilled or reused without a
+    barrier shows up here as a wrong result (see the self-test above)."""
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels.py"), "-q", "-x",
+                        "-m", "not gpu", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=dict(os.environ, LECO_EMU_SCHED=sched), capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def _write_synthetic_clip(folder, hidden=64, layers=3):
     """A tiny but real transformers CLIP text stack on disk: tokenizer files + text_encoder/ (HF format)."""
     import json
