@@ -445,7 +445,7 @@ def main():
 
     from leco_amd import model_util, prompt_util, train_util
     from leco_amd.lora import LoRANetwork
-    from leco_amd.train import FusedStep, init_distributed
+    from leco_amd.train import FusedStep, init_distributed, shutdown_distributed
 
     # LECO_BENCH_EMU=1 (tests/test_dist.py only): the same launch / rendezvous / timing / JSON plumbing with the host
     # emulator of the kernel sources on CPU tensors and gloo -- a dry run of the multi-GPU path for boxes without GPUs.
@@ -584,6 +584,12 @@ def main():
         all_ks = [None] * world
         dist.all_gather_object(all_ks, ks)
         ks_same = all(x == all_ks[0] for x in all_ks)
+        # that was the last collective: take the process group down HERE, at the same point on every rank, instead of
+        # leaving it to interpreter exit at different times (ranks != 0 return now, rank 0 goes on alone for a minute
+        # with the per-launch timing; an implicit teardown of a communicator whose peers are gone is where torch's
+        # c10d back ends abort -- seen once as "terminate called without an active exception" on rank 1 of the gloo
+        # dry run, which makes torchrun kill rank 0)
+        shutdown_distributed()
     losses = [float(l.item()) for l in losses]
     finite = all(math.isfinite(l) for l in losses)
     if rank != 0:

@@ -26,6 +26,7 @@ from __future__ import annotations
 import ast
 import math
 import os
+import sys
 from pathlib import Path
 from typing import List, Optional
 
@@ -57,6 +58,22 @@ def init_distributed(backend: Optional[str] = None):
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
+
+
+def shutdown_distributed():
+    """Counterpart of `init_distributed` for the entry points that own the process (the train CLIs, bench.py): called by
+    every rank after its last collective, it takes the process group down at the same point on all of them (barrier, then
+    `destroy_process_group`) instead of leaving that to interpreter exit at different times -- rank 0 still writes files
+    (or times launches) after the others are done, and an implicit teardown of a communicator whose peers have already
+    gone is where the c10d back ends abort.  Never raises."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    try:
+        dist.barrier(**({"device_ids": [torch.cuda.current_device()]} if dist.get_backend() == "nccl" else {}))
+        dist.destroy_process_group()
+    except Exception as e:
+        print(f"process-group teardown: {e!r}", file=sys.stderr)
 
 
 class StrictReferenceOptimizer:
@@ -719,3 +736,4 @@ def main(args, xl: bool = False):
     train(config, prompts, xl=xl, resume_from=getattr(args, "resume", None),
           save_state=bool(getattr(args, "save_state", False)),
           strict_reference=bool(getattr(args, "strict_reference", False)))
+    shutdown_distributed()

@@ -31,14 +31,26 @@ def _digest(path):
     return h.hexdigest()[:16]
 
 
-def build(verbose=False):
+ASAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+
+
+def build(verbose=False, asan=None):
+    """asan=True (or LECO_EMU_ASAN=1): the AddressSanitizer build, libleco_emu_asan.so -- the kernels' global-memory
+    accesses are checked against the tensors' allocations.  The interpreter has to run with LD_PRELOAD=ASAN_RT
+    (tools/emu_asan.py does that)."""
+    if asan is None:
+        asan = os.environ.get("LECO_EMU_ASAN") == "1"
     os.makedirs(OUT, exist_ok=True)
     flags = ["-std=c++17", "-O2", "-fPIC", "-pthread", "-Wno-unknown-attributes", "-Wno-unused-value",
              "-Wno-unknown-pragmas", "-Wno-pass-failed",
              "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    tag = ""
+    if asan:
+        flags += ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g1"]
+        tag = ".asan"
 
     def one(src):
-        obj = os.path.join(OUT, os.path.basename(src) + "." + _digest(src) + ".o")
+        obj = os.path.join(OUT, os.path.basename(src) + "." + _digest(src) + tag + ".o")
         if not os.path.exists(obj):
             cmd = [CLANG, "-x", "c++", *flags, "-c", src, "-o", obj]
             if verbose:
@@ -48,11 +60,12 @@ def build(verbose=False):
 
     with ThreadPoolExecutor(8) as ex:
         objs = list(ex.map(one, sources()))
-    lib = os.path.join(OUT, "libleco_emu.so")
-    stamp = os.path.join(OUT, "link.stamp")
+    lib = os.path.join(OUT, "libleco_emu_asan.so" if asan else "libleco_emu.so")
+    stamp = os.path.join(OUT, "link" + tag + ".stamp")
     key = " ".join(objs)
     if not os.path.exists(lib) or not os.path.exists(stamp) or open(stamp).read() != key:
-        subprocess.run([CLANG, "-shared", "-pthread", "-o", lib, *objs], check=True)
+        subprocess.run([CLANG, "-shared", "-pthread", *(["-fsanitize=address", "-shared-libasan"] if asan else []),
+                        "-o", lib, *objs], check=True)
         with open(stamp, "w") as f:
             f.write(key)
     return lib

@@ -12,6 +12,19 @@
 #include <thread>
 #include <vector>
 
+// AddressSanitizer build (tests/emu/build_emu.py build(asan=True), tools/emu_asan.py): the work-item switches are announced
+// to the sanitizer, and a stack is unpoisoned before it is reused for the next workgroup's work-item.
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#include <sanitizer/asan_interface.h>
+#include <sanitizer/common_interface_defs.h>
+#define LECO_EMU_ASAN 1
+#endif
+#endif
+#ifndef LECO_EMU_ASAN
+#define LECO_EMU_ASAN 0
+#endif
+
 namespace emu {
 thread_local emu_uint3 t_idx, b_idx;
 thread_local dim3 b_dim, g_dim;
@@ -57,10 +70,14 @@ static inline void leco_emu_switch(Ctx* from, Ctx* to) { swapcontext(&from->uc, 
 struct Fiber {
     Ctx ctx;
     bool done;
+    void* fake = nullptr;           // sanitizer's fake-stack handle while the work-item is switched out
 };
 
 struct Runner {
     Ctx sched;
+    void* sched_fake = nullptr;     // sanitizer: the scheduler's fake stack / real stack bounds (learnt by the first work-item)
+    const void* sched_bottom = nullptr;
+    size_t sched_size = 0;
     Fiber fibers[kMaxThreads];
     char* stacks = nullptr;
     int n = 0, cur = 0;
@@ -107,9 +124,15 @@ int sched_mode() {
 
 void trampoline() {
     Runner* r = tl_runner;
+#if LECO_EMU_ASAN
+    __sanitizer_finish_switch_fiber(nullptr, &r->sched_bottom, &r->sched_size);
+#endif
     (*r->body)();
     r->fibers[r->cur].done = true;
     ++r->events;
+#if LECO_EMU_ASAN
+    __sanitizer_start_switch_fiber(nullptr, r->sched_bottom, r->sched_size);      // nullptr: this work-item's stack dies
+#endif
 #if defined(__x86_64__)
     leco_emu_switch(&r->fibers[r->cur].ctx, &r->sched);     // a finished work-item is never resumed
     __builtin_trap();
@@ -121,6 +144,9 @@ void make_fiber(Runner* r, int i) {
     Fiber& f = r->fibers[i];
     f.done = false;
     char* top = r->stacks + (size_t)(i + 1) * kStack;       // 16-byte aligned (kStack is, the mapping is)
+#if LECO_EMU_ASAN
+    __asan_unpoison_memory_region(top - kStack, kStack);
+#endif
 #if defined(__x86_64__)
     // What leco_emu_switch pops on the first switch in: six zeroed callee-saved registers, then `ret` into the
     // trampoline with the stack as a `call` would have left it (rsp % 16 == 8; the slot above is a null return address).
@@ -147,11 +173,20 @@ void set_tid(Runner* r, int i) {
 void yield_fiber() {
     Runner* r = tl_runner;
     int me = r->cur;
+#if LECO_EMU_ASAN
+    __sanitizer_start_switch_fiber(&r->fibers[me].fake, r->sched_bottom, r->sched_size);
+#endif
     leco_emu_switch(&r->fibers[me].ctx, &r->sched);
+#if LECO_EMU_ASAN
+    __sanitizer_finish_switch_fiber(r->fibers[me].fake, nullptr, nullptr);
+#endif
 }
+
+thread_local unsigned long tl_block_serial = 0;
 
 void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
     r->ensure();
+    ++tl_block_serial;
     r->n = block.x * block.y * block.z;
     if (r->n > kMaxThreads) { fprintf(stderr, "emu: block too large\n"); abort(); }
     r->bdim = block;
@@ -165,7 +200,13 @@ void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
         if (r->fibers[i].done) return;
         r->cur = i;
         set_tid(r, i);
+#if LECO_EMU_ASAN
+        __sanitizer_start_switch_fiber(&r->sched_fake, r->stacks + (size_t)i * kStack, kStack);
+#endif
         leco_emu_switch(&r->sched, &r->fibers[i].ctx);
+#if LECO_EMU_ASAN
+        __sanitizer_finish_switch_fiber(r->sched_fake, nullptr, nullptr);
+#endif
         if (r->fibers[i].done) --live;
     };
     const int mode = sched_mode();
@@ -283,6 +324,13 @@ void sync_block() {
 }
 
 int lane() { return tl_runner->cur & 63; }
+
+unsigned long block_serial() { return tl_block_serial; }
+
+bool lds_poison() {
+    static const bool on = [] { const char* e = getenv("LECO_EMU_LDS"); return e && !strcmp(e, "poison"); }();
+    return on;
+}
 
 const unsigned char* wave_gather(const void* in, int bytes) {
     Runner* r = tl_runner;

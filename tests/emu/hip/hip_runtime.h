@@ -49,6 +49,8 @@ void sync_block();
 constexpr int kSlot = 64;
 const unsigned char* wave_gather(const void* in, int bytes);
 int lane();
+unsigned long block_serial();      // number of the workgroup this OS thread is running (1, 2, ...)
+bool lds_poison();                 // LECO_EMU_LDS=poison
 void launch(dim3 grid, dim3 block, const std::function<void()>& body);
 }  // namespace emu
 

@@ -156,8 +156,17 @@ static inline void lds_tie(bf16x8&) {}
 static inline void opaque(int&) {}
 static inline void sched_fence() {}
 static inline void barrier_keep_dma() { emu::sync_block(); }
+// The hardware hands a workgroup whatever its predecessor left in LDS.  LECO_EMU_LDS=poison fills the dynamic LDS with a
+// NaN pattern (0x7FC0: a NaN as bf16 and, doubled, as fp32) at each workgroup's first touch, so a read of never-written LDS
+// that reaches a result shows up as a NaN instead of passing on a zeroed / left-over buffer.
 static inline unsigned char* dyn_lds() {
     static thread_local __attribute__((aligned(16))) unsigned char buf[160 * 1024];
+    static thread_local unsigned long seen = 0;
+    if (emu::lds_poison() && seen != emu::block_serial()) {
+        seen = emu::block_serial();
+        unsigned short* p = (unsigned short*)buf;
+        for (int i = 0; i < 80 * 1024; ++i) p[i] = 0x7FC0;
+    }
     return buf;
 }
 #define LECO_CONST_AS

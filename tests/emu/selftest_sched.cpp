@@ -6,7 +6,9 @@
 //   reuse_kernel   reuses one LDS slot per wave across iterations and, with `fenced == 0`, leaves out the barrier
 //                  between the last read of an iteration and the first write of the next one: a real race on the
 //                  hardware.  Near-lockstep round-robin never sees it; the greedy schedules must.
-// Prints "order: ..." and "reuse fenced=F: ok|RACE" lines.
+//   lds_probe_kernel reads dynamic LDS it never wrote: 0x7fc0 (the NaN fill) under LECO_EMU_LDS=poison, otherwise whatever
+//                  the previous workgroup on this OS thread left (0 / 1 here).
+// Prints "order: ...", "reuse fenced=F: ok|RACE" and "lds: ..." lines.
 #include <hip/hip_runtime.h>
 #include <leco_prims.h>
 
@@ -37,6 +39,13 @@ __global__ void reuse_kernel(int* out, int fenced) {
     if (lane == 0) out[wave] = (int)acc;
 }
 
+__global__ void lds_probe_kernel(unsigned* out) {
+    const unsigned short* lds = (const unsigned short*)dyn_lds();
+    if (threadIdx.x == 0) out[blockIdx.x] = lds[blockIdx.x + 7];     // never written
+    __syncthreads();
+    if (threadIdx.x == 0) ((unsigned short*)dyn_lds())[blockIdx.x + 8] = 1;   // what the NEXT workgroup would find
+}
+
 int main() {
     unsigned cnt = 0;
     int order[12];
@@ -55,5 +64,9 @@ int main() {
         for (int w = 0; w < 4; ++w) ok = ok && out[w] == 600 + 4 * ((w + 1) & 3);      // sum over it of 100 it + (w + 1) % 4
         printf("reuse fenced=%d: %s\n", fenced, ok ? "ok" : "RACE");
     }
+    unsigned probe[4] = {0, 0, 0, 0};
+    unsigned* pp = probe;
+    hipLaunchKernelGGL(lds_probe_kernel, dim3(4), dim3(64), 0, 0, pp);
+    printf("lds: %x %x %x %x\n", probe[0], probe[1], probe[2], probe[3]);
     return 0;
 }

@@ -227,8 +227,9 @@ def _shape_worker(rank, world, port, q, out_dir):
     with contextlib.redirect_stdout(io.StringIO()):
         T.train(cfg, prompts, device=torch.device("cpu"), use_graphs=False, progress=False)
     q.put((rank, seen))
-    dist.barrier()
-    dist.destroy_process_group()
+    T.shutdown_distributed()            # what the train CLIs / bench.py end with: barrier + destroy, on every rank
+    assert not dist.is_initialized()
+    T.shutdown_distributed()            # and it is a no-op without a process group
 
 
 def test_train_under_dp_runs_the_same_shape_class_on_every_rank(tmp_path):

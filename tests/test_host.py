@@ -294,18 +294,46 @@ def test_emulator_schedules_order_the_waves_and_expose_a_missing_barrier():
     assert run("greedy_reverse") == ([3, 3, 3, 2, 2, 2, 1, 1, 1, 0, 0, 0], "ok", "RACE")
     order, fenced, unfenced = run("random")
     assert sorted(order) == sorted([0, 1, 2, 3] * 3) and order != [0, 1, 2, 3] * 3 and fenced == "ok"
+    # LECO_EMU_LDS=poison: never-written dynamic LDS reads as the NaN fill, not as the previous workgroup's leftovers
+    lds = lambda **env: subprocess.run([exe], env=dict(os.environ, LECO_EMU_THREADS="1", **env), capture_output=True,
+                                       text=True, timeout=60).stdout.strip().splitlines()[-1]
+    assert lds() == "lds: 0 1 1 1" and lds(LECO_EMU_LDS="poison") == "lds: 7fc0 7fc0 7fc0 7fc0"
 
 
-@pytest.mark.parametrize("sched", ["greedy", "greedy_reverse", "random"])
-def test_kernels_give_the_same_results_under_every_wave_schedule(sched):
+@pytest.mark.parametrize("sched,lds", [("greedy", "poison"), ("greedy_reverse", ""), ("random", "poison")])
+def test_kernels_give_the_same_results_under_every_wave_schedule(sched, lds):
     """Any interleaving of a workgroup's waves between its barriers is legal on the hardware: the whole kernel test
     file must pass when one wave runs as far ahead of the others as the barriers allow (either end first) and under a
     random wave order, not only in the default near-lockstep order -- an LDS buffer refilled or reused without a
-    barrier shows up here as a wrong result (see the self-test above)."""
+    barrier shows up here as a wrong result (see the self-test above).  Two of the three runs also start every
+    workgroup on NaN-filled dynamic LDS (what the hardware leaves there is the previous workgroup's)."""
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels.py"), "-q", "-x",
-                        "-m", "not gpu", "-p", "no:cacheprovider"],
-                       cwd=ROOT, env=dict(os.environ, LECO_EMU_SCHED=sched), capture_output=True, text=True, timeout=1200)
+                        "-m", "not gpu", "-p", "no:cacheprovider"], cwd=ROOT,
+                       env=dict(os.environ, LECO_EMU_SCHED=sched, LECO_EMU_LDS=lds), capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_kernel_sources_are_clean_under_address_sanitizer():
+    """tools/emu_asan.py: the kernel test file with the kernel sources compiled under AddressSanitizer and the
+    interpreter's allocator replaced by the sanitizer's (red zones around every CPU tensor): any global-memory access of a
+    kernel outside the operand it belongs to aborts the run with the .hip source line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    if not os.path.exists(build_emu.ASAN_RT):
+        pytest.skip("no AddressSanitizer runtime in this toolchain")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_asan.py")], cwd=ROOT, capture_output=True,
+                       text=True, timeout=1800)
+    assert r.returncode == 0 and "AddressSanitizer" not in r.stderr, r.stdout[-1500:] + r.stderr[-3000:]
+    # and the sanitizer is live in that configuration: a deliberately short output tensor is reported
+    probe = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); import build_emu; "
+             "from leco_amd import hip, ops; hip._use_library(build_emu.build()); "
+             "x = torch.randn(1000); y = torch.empty(800, dtype=torch.bfloat16); "
+             "ops.run_plan([ops.cast_f32_bf16(x, y, 1000)])"
+             % (ROOT, os.path.join(ROOT, "tests", "emu")))
+    env = dict(os.environ, LECO_EMU_ASAN="1", LD_PRELOAD=build_emu.ASAN_RT,
+               ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0")
+    r = subprocess.run([sys.executable, "-c", probe], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "heap-buffer-overflow" in r.stderr and "cast_f32_bf16_kernel" in r.stderr, r.stderr[-3000:]
 
 
 def _write_synthetic_clip(folder, hidden=64, layers=3):

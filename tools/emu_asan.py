@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE -- run CPU-tier tests with the kernel sources compiled under AddressSanitizer.
+
+    python tools/emu_asan.py [pytest arguments]          (default: tests/test_kernels.py -m "not gpu" -x -q)
+
+The host emulator (tests/emu/) compiles the unmodified leco_amd/csrc/*.hip for the CPU; with -fsanitize=address every
+global-memory access of a kernel is checked against the allocation of the tensor it belongs to (the interpreter runs
+with the sanitizer runtime preloaded, so torch's CPU tensors carry red zones): a read or write past the end of an
+operand -- silent on the GPU inside the caching allocator's blocks -- aborts with the kernel's source line.  LDS is a
+static buffer and is not covered (LECO_EMU_LDS=poison covers never-written LDS).
+"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+
+
+def main():
+    import build_emu
+    build_emu.build(asan=True)
+    args = sys.argv[1:] or [os.path.join(ROOT, "tests", "test_kernels.py"), "-m", "not gpu", "-x", "-q"]
+    env = dict(os.environ, LECO_EMU_ASAN="1", LD_PRELOAD=build_emu.ASAN_RT,
+               ASAN_OPTIONS=os.environ.get("ASAN_OPTIONS", "detect_leaks=0:detect_stack_use_after_return=0:"
+                                                           "abort_on_error=1:allocator_may_return_null=1"))
+    os.execve(sys.executable, [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", *args], env)
+
+
+if __name__ == "__main__":
+    main()
