@@ -245,6 +245,27 @@ void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
     }
 }
 
+// Workgroup dispatch order (LECO_EMU_BLOCKS=reverse|random; default: ascending linear index, as the hardware dispatches).
+// Completion order is arbitrary on the hardware, and kernels that pass data between workgroups (split-K "last arriver
+// reduces", statistics summed with atomics) must not depend on it: `reverse` starts with the last workgroup, `random` walks
+// a fixed pseudo-random permutation (b * p + 7 mod total, p coprime to total).
+long block_order(long b, long total) {
+    static const int mode = [] {
+        const char* e = getenv("LECO_EMU_BLOCKS");
+        if (!e || !*e || !strcmp(e, "linear")) return 0;
+        if (!strcmp(e, "reverse")) return 1;
+        if (!strcmp(e, "random")) return 2;
+        fprintf(stderr, "emu: unknown LECO_EMU_BLOCKS=%s\n", e);
+        abort();
+    }();
+    if (mode == 0 || total < 2) return b;
+    if (mode == 1) return total - 1 - b;
+    auto gcd = [](long a, long c) { while (c) { long t = a % c; a = c; c = t; } return a; };
+    long p = (long)(total * 0.6180339887) | 1;
+    while (gcd(p, total) != 1) p += 2;
+    return (long)(((unsigned long)b * (unsigned long)p + 7ul) % (unsigned long)total);
+}
+
 // ---- persistent worker pool ------------------------------------------------
 struct Pool {
     std::vector<std::thread> th;
@@ -284,6 +305,7 @@ struct Pool {
             for (;;) {
                 long b = next.fetch_add(1);
                 if (b >= total) break;
+                b = block_order(b, total);
                 b_idx.x = b % grid.x;
                 b_idx.y = (b / grid.x) % grid.y;
                 b_idx.z = b / ((long)grid.x * grid.y);

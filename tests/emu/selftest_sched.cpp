@@ -8,7 +8,8 @@
 //                  hardware.  Near-lockstep round-robin never sees it; the greedy schedules must.
 //   lds_probe_kernel reads dynamic LDS it never wrote: 0x7fc0 (the NaN fill) under LECO_EMU_LDS=poison, otherwise whatever
 //                  the previous workgroup on this OS thread left (0 / 1 here).
-// Prints "order: ...", "reuse fenced=F: ok|RACE" and "lds: ..." lines.
+//   block_order_kernel records the workgroup dispatch order (LECO_EMU_BLOCKS, one OS thread).
+// Prints "order: ...", "reuse fenced=F: ok|RACE", "lds: ..." and "blocks: ..." lines.
 #include <hip/hip_runtime.h>
 #include <leco_prims.h>
 
@@ -46,6 +47,10 @@ __global__ void lds_probe_kernel(unsigned* out) {
     if (threadIdx.x == 0) ((unsigned short*)dyn_lds())[blockIdx.x + 8] = 1;   // what the NEXT workgroup would find
 }
 
+__global__ void block_order_kernel(unsigned* cnt, int* order) {
+    if (threadIdx.x == 0) order[atomicAdd(cnt, 1u)] = (int)blockIdx.x;
+}
+
 int main() {
     unsigned cnt = 0;
     int order[12];
@@ -68,5 +73,13 @@ int main() {
     unsigned* pp = probe;
     hipLaunchKernelGGL(lds_probe_kernel, dim3(4), dim3(64), 0, 0, pp);
     printf("lds: %x %x %x %x\n", probe[0], probe[1], probe[2], probe[3]);
+    unsigned bcnt = 0;
+    int border[6] = {-1, -1, -1, -1, -1, -1};
+    unsigned* pbc = &bcnt;
+    int* pbo = border;
+    hipLaunchKernelGGL(block_order_kernel, dim3(6), dim3(64), 0, 0, pbc, pbo);
+    printf("blocks:");
+    for (int v : border) printf(" %d", v);
+    printf("\n");
     return 0;
 }

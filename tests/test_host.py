@@ -295,21 +295,30 @@ def test_emulator_schedules_order_the_waves_and_expose_a_missing_barrier():
     order, fenced, unfenced = run("random")
     assert sorted(order) == sorted([0, 1, 2, 3] * 3) and order != [0, 1, 2, 3] * 3 and fenced == "ok"
     # LECO_EMU_LDS=poison: never-written dynamic LDS reads as the NaN fill, not as the previous workgroup's leftovers
-    lds = lambda **env: subprocess.run([exe], env=dict(os.environ, LECO_EMU_THREADS="1", **env), capture_output=True,
-                                       text=True, timeout=60).stdout.strip().splitlines()[-1]
-    assert lds() == "lds: 0 1 1 1" and lds(LECO_EMU_LDS="poison") == "lds: 7fc0 7fc0 7fc0 7fc0"
+    def line(key, **env):
+        r = subprocess.run([exe], env=dict(os.environ, LECO_EMU_THREADS="1", **env), capture_output=True, text=True, timeout=60)
+        return [l for l in r.stdout.splitlines() if l.startswith(key)][0]
+    assert line("lds") == "lds: 0 1 1 1" and line("lds", LECO_EMU_LDS="poison") == "lds: 7fc0 7fc0 7fc0 7fc0"
+    # LECO_EMU_BLOCKS: workgroup dispatch order (ascending like the hardware's by default; reversed; a fixed permutation)
+    assert line("blocks") == "blocks: 0 1 2 3 4 5" and line("blocks", LECO_EMU_BLOCKS="reverse") == "blocks: 5 4 3 2 1 0"
+    perm = [int(x) for x in line("blocks", LECO_EMU_BLOCKS="random").split()[1:]]
+    assert sorted(perm) == list(range(6)) and perm != list(range(6))
 
 
-@pytest.mark.parametrize("sched,lds", [("greedy", "poison"), ("greedy_reverse", ""), ("random", "poison")])
-def test_kernels_give_the_same_results_under_every_wave_schedule(sched, lds):
+@pytest.mark.parametrize("sched,lds,blocks", [("greedy", "poison", "reverse"), ("greedy_reverse", "", "linear"),
+                                              ("random", "poison", "random")])
+def test_kernels_give_the_same_results_under_every_wave_schedule(sched, lds, blocks):
     """Any interleaving of a workgroup's waves between its barriers is legal on the hardware: the whole kernel test
     file must pass when one wave runs as far ahead of the others as the barriers allow (either end first) and under a
     random wave order, not only in the default near-lockstep order -- an LDS buffer refilled or reused without a
     barrier shows up here as a wrong result (see the self-test above).  Two of the three runs also start every
-    workgroup on NaN-filled dynamic LDS (what the hardware leaves there is the previous workgroup's)."""
+    workgroup on NaN-filled dynamic LDS (what the hardware leaves there is the previous workgroup's) and dispatch the
+    workgroups of a launch last-first / in a scrambled order (kernels that hand data from workgroup to workgroup --
+    split-K last-arriver reductions, atomically summed statistics -- must not care)."""
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels.py"), "-q", "-x",
                         "-m", "not gpu", "-p", "no:cacheprovider"], cwd=ROOT,
-                       env=dict(os.environ, LECO_EMU_SCHED=sched, LECO_EMU_LDS=lds), capture_output=True, text=True, timeout=1200)
+                       env=dict(os.environ, LECO_EMU_SCHED=sched, LECO_EMU_LDS=lds, LECO_EMU_BLOCKS=blocks),
+                       capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
