@@ -251,3 +251,38 @@ def test_train_under_dp_runs_the_same_shape_class_on_every_rank(tmp_path):
     assert len(res[0]) == len(res[1]) == 4
     assert [s for s, _ in res[0]] == [s for s, _ in res[1]], "ranks ran different (batch, h, w) shapes in the same step"
     assert len({s for s, _ in res[0]}) >= 2, "the schedule should visit more than one shape class"
+
+
+_DET_PROBE = """
+import hashlib, os, sys
+import torch
+sys.path.insert(0, %r)
+import test_dist as D
+D._setup()
+fs, net, pair = D._make(1)
+fs.step(pair, 2, torch.randn(1, 4, 32, 32, generator=torch.Generator().manual_seed(100)))
+h = lambda t: hashlib.sha1(t.detach()[:net.numel].contiguous().numpy().tobytes()).hexdigest()
+print("DET", h(net.grad), h(net.slab))
+"""
+
+
+def test_deterministic_mode_is_independent_of_workgroup_and_wave_order():
+    """LECO_DETERMINISTIC=1 (+ LECO_GN_FUSED=0) promises a bitwise reproducible step: no result may depend on the order
+    in which workgroups or waves happen to run.  One optimizer step of the tiny model on a 32 x 32 latent (large enough
+    that the DEFAULT mode's fp32 atomics make the slabs differ between exactly these two runs) in separate interpreters --
+    ascending workgroups / lockstep waves on 8 emulator threads vs a scrambled workgroup order, random wave schedule and
+    3 threads -- must leave bit-identical gradient and parameter slabs."""
+    import subprocess
+    base = dict(os.environ, LECO_DETERMINISTIC="1", LECO_GN_FUSED="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        base.pop(k, None)
+
+    def run(**env):
+        r = subprocess.run([sys.executable, "-c", _DET_PROBE % os.path.join(ROOT, "tests")], cwd=ROOT, env=dict(base, **env),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        return [l for l in r.stdout.splitlines() if l.startswith("DET")][0]
+
+    a = run(LECO_EMU_THREADS="8")
+    b = run(LECO_EMU_THREADS="3", LECO_EMU_BLOCKS="random", LECO_EMU_SCHED="random")
+    assert a == b, (a, b)
