@@ -34,20 +34,30 @@ def _digest(path):
 ASAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
 
 
-def build(verbose=False, asan=None):
+def build(verbose=False, asan=None, ubsan=None):
     """asan=True (or LECO_EMU_ASAN=1): the AddressSanitizer build, libleco_emu_asan.so -- the kernels' global-memory
     accesses are checked against the tensors' allocations.  The interpreter has to run with LD_PRELOAD=ASAN_RT
-    (tools/emu_asan.py does that)."""
+    (tools/emu_asan.py does that).  ubsan=True (or LECO_EMU_UBSAN=1): the UndefinedBehaviorSanitizer build,
+    libleco_emu_ubsan.so (static-array bounds, shifts, signed overflow, float-to-int range; reports go to stderr and the
+    run continues; no preload needed) -- tools/emu_asan.py --ubsan."""
     if asan is None:
         asan = os.environ.get("LECO_EMU_ASAN") == "1"
+    if ubsan is None:
+        ubsan = os.environ.get("LECO_EMU_UBSAN") == "1" and not asan
     os.makedirs(OUT, exist_ok=True)
     flags = ["-std=c++17", "-O2", "-fPIC", "-pthread", "-Wno-unknown-attributes", "-Wno-unused-value",
              "-Wno-unknown-pragmas", "-Wno-pass-failed",
              "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    tag = ""
+    tag, link = "", []
     if asan:
-        flags += ["-fsanitize=address", "-shared-libasan", "-fno-omit-frame-pointer", "-g1"]
+        link = ["-fsanitize=address", "-shared-libasan"]
+        flags += link + ["-fno-omit-frame-pointer", "-g1"]
         tag = ".asan"
+    elif ubsan:
+        # alignment: the kernels' vector loads of 2-byte-aligned bf16 rows are legal on the GPU (and memcpy-like on x86)
+        link = ["-fsanitize=undefined,bounds,float-cast-overflow", "-fno-sanitize=alignment,vptr,function", "-shared-libsan"]
+        flags += link + ["-fno-omit-frame-pointer", "-g1"]
+        tag = ".ubsan"
 
     def one(src):
         obj = os.path.join(OUT, os.path.basename(src) + "." + _digest(src) + tag + ".o")
@@ -60,12 +70,12 @@ def build(verbose=False, asan=None):
 
     with ThreadPoolExecutor(8) as ex:
         objs = list(ex.map(one, sources()))
-    lib = os.path.join(OUT, "libleco_emu_asan.so" if asan else "libleco_emu.so")
+    lib = os.path.join(OUT, "libleco_emu%s.so" % tag.replace(".", "_"))
     stamp = os.path.join(OUT, "link" + tag + ".stamp")
     key = " ".join(objs)
     if not os.path.exists(lib) or not os.path.exists(stamp) or open(stamp).read() != key:
-        subprocess.run([CLANG, "-shared", "-pthread", *(["-fsanitize=address", "-shared-libasan"] if asan else []),
-                        "-o", lib, *objs], check=True)
+        rpath = ["-Wl,-rpath," + os.path.dirname(ASAN_RT)] if ubsan else []
+        subprocess.run([CLANG, "-shared", "-pthread", *link, *rpath, "-o", lib, *objs], check=True)
         with open(stamp, "w") as f:
             f.write(key)
     return lib

@@ -2,6 +2,8 @@
 """TEST INFRASTRUCTURE -- run CPU-tier tests with the kernel sources compiled under AddressSanitizer.
 
     python tools/emu_asan.py [pytest arguments]          (default: tests/test_kernels.py -m "not gpu" -x -q)
+    python tools/emu_asan.py --ubsan [pytest arguments]  (UndefinedBehaviorSanitizer: static-array bounds, shifts, signed
+                                                          overflow, float-to-int range; "runtime error:" lines on stderr)
 
 The host emulator (tests/emu/) compiles the unmodified leco_amd/csrc/*.hip for the CPU; with -fsanitize=address every
 global-memory access of a kernel is checked against the allocation of the tensor it belongs to (the interpreter runs
@@ -18,8 +20,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
 
 def main():
     import build_emu
+    argv = sys.argv[1:]
+    if argv and argv[0] == "--ubsan":       # UndefinedBehaviorSanitizer instead: reports on stderr, the run continues
+        build_emu.build(ubsan=True)
+        args = argv[1:] or [os.path.join(ROOT, "tests", "test_kernels.py"), "-m", "not gpu", "-q"]
+        env = dict(os.environ, LECO_EMU_UBSAN="1", UBSAN_OPTIONS=os.environ.get("UBSAN_OPTIONS", "print_stacktrace=0"))
+        os.execve(sys.executable, [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", "-s", *args], env)
     build_emu.build(asan=True)
-    args = sys.argv[1:] or [os.path.join(ROOT, "tests", "test_kernels.py"), "-m", "not gpu", "-x", "-q"]
+    args = argv or [os.path.join(ROOT, "tests", "test_kernels.py"), "-m", "not gpu", "-x", "-q"]
     env = dict(os.environ, LECO_EMU_ASAN="1", LD_PRELOAD=build_emu.ASAN_RT,
                ASAN_OPTIONS=os.environ.get("ASAN_OPTIONS", "detect_leaks=0:detect_stack_use_after_return=0:"
                                                            "abort_on_error=1:allocator_may_return_null=1"))
