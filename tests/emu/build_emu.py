@@ -32,9 +32,10 @@ def _digest(path):
 
 
 ASAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+TSAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.tsan-x86_64.so"
 
 
-def build(verbose=False, asan=None, ubsan=None):
+def build(verbose=False, asan=None, ubsan=None, tsan=None):
     """asan=True (or LECO_EMU_ASAN=1): the AddressSanitizer build, libleco_emu_asan.so -- the kernels' global-memory
     accesses are checked against the tensors' allocations.  The interpreter has to run with LD_PRELOAD=ASAN_RT
     (tools/emu_asan.py does that).  ubsan=True (or LECO_EMU_UBSAN=1): the UndefinedBehaviorSanitizer build,
@@ -44,12 +45,18 @@ def build(verbose=False, asan=None, ubsan=None):
         asan = os.environ.get("LECO_EMU_ASAN") == "1"
     if ubsan is None:
         ubsan = os.environ.get("LECO_EMU_UBSAN") == "1" and not asan
+    if tsan is None:
+        tsan = os.environ.get("LECO_EMU_TSAN") == "1" and not asan and not ubsan
     os.makedirs(OUT, exist_ok=True)
     flags = ["-std=c++17", "-O2", "-fPIC", "-pthread", "-Wno-unknown-attributes", "-Wno-unused-value",
              "-Wno-unknown-pragmas", "-Wno-pass-failed",
              "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC]
     tag, link = "", []
-    if asan:
+    if tsan:
+        link = ["-fsanitize=thread", "-shared-libsan"]
+        flags += link + ["-fno-omit-frame-pointer", "-g1"]
+        tag = ".tsan"
+    elif asan:
         link = ["-fsanitize=address", "-shared-libasan"]
         flags += link + ["-fno-omit-frame-pointer", "-g1"]
         tag = ".asan"
@@ -81,13 +88,16 @@ def build(verbose=False, asan=None, ubsan=None):
     return lib
 
 
-def build_selftest():
-    """tests/emu/selftest_sched.cpp + the fiber runtime as a stand-alone program (the work-item schedules' own test)."""
+def build_selftest(tsan=False):
+    """tests/emu/selftest_sched.cpp + the fiber runtime as a stand-alone program (the work-item schedules' own test);
+    tsan=True: under ThreadSanitizer (the cross-workgroup race probe)."""
     os.makedirs(OUT, exist_ok=True)
     srcs = [os.path.join(HERE, "selftest_sched.cpp"), os.path.join(HERE, "emu_runtime.cpp")]
-    exe = os.path.join(OUT, "selftest_sched." + hashlib.sha1("".join(_digest(x) for x in srcs).encode()).hexdigest()[:16])
+    exe = os.path.join(OUT, "selftest_sched." + hashlib.sha1("".join(_digest(x) for x in srcs).encode()).hexdigest()[:16]
+                       + (".tsan" if tsan else ""))
     if not os.path.exists(exe):
-        subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O2", "-pthread", "-Wno-unknown-attributes", "-Wno-unused-value",
+        san = ["-fsanitize=thread", "-fno-omit-frame-pointer", "-g1"] if tsan else []
+        subprocess.run([CLANG, "-x", "c++", "-std=c++17", "-O2", "-pthread", "-Wno-unknown-attributes", "-Wno-unused-value", *san,
                         "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC, *srcs, "-o", exe], check=True)
     return exe
 

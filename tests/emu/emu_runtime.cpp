@@ -24,6 +24,18 @@
 #ifndef LECO_EMU_ASAN
 #define LECO_EMU_ASAN 0
 #endif
+// ThreadSanitizer build (build(tsan=True), tools/emu_asan.py --tsan): every work-item slot is a sanitizer "fiber" (created once
+// per OS thread, reused by the workgroups that thread runs); switches synchronise, so accesses inside a workgroup are ordered
+// (they are sequential here) and what is checked is workgroup against workgroup -- the pool's OS threads.
+#if defined(__has_feature)
+#if __has_feature(thread_sanitizer)
+#include <sanitizer/tsan_interface.h>
+#define LECO_EMU_TSAN 1
+#endif
+#endif
+#ifndef LECO_EMU_TSAN
+#define LECO_EMU_TSAN 0
+#endif
 
 namespace emu {
 thread_local emu_uint3 t_idx, b_idx;
@@ -71,6 +83,7 @@ struct Fiber {
     Ctx ctx;
     bool done;
     void* fake = nullptr;           // sanitizer's fake-stack handle while the work-item is switched out
+    void* tsan = nullptr;           // ThreadSanitizer fiber of this work-item slot
 };
 
 struct Runner {
@@ -78,6 +91,7 @@ struct Runner {
     void* sched_fake = nullptr;     // sanitizer: the scheduler's fake stack / real stack bounds (learnt by the first work-item)
     const void* sched_bottom = nullptr;
     size_t sched_size = 0;
+    void* sched_tsan = nullptr;
     Fiber fibers[kMaxThreads];
     char* stacks = nullptr;
     int n = 0, cur = 0;
@@ -133,6 +147,9 @@ void trampoline() {
 #if LECO_EMU_ASAN
     __sanitizer_start_switch_fiber(nullptr, r->sched_bottom, r->sched_size);      // nullptr: this work-item's stack dies
 #endif
+#if LECO_EMU_TSAN
+    __tsan_switch_to_fiber(r->sched_tsan, 0);
+#endif
 #if defined(__x86_64__)
     leco_emu_switch(&r->fibers[r->cur].ctx, &r->sched);     // a finished work-item is never resumed
     __builtin_trap();
@@ -176,6 +193,9 @@ void yield_fiber() {
 #if LECO_EMU_ASAN
     __sanitizer_start_switch_fiber(&r->fibers[me].fake, r->sched_bottom, r->sched_size);
 #endif
+#if LECO_EMU_TSAN
+    __tsan_switch_to_fiber(r->sched_tsan, 0);
+#endif
     leco_emu_switch(&r->fibers[me].ctx, &r->sched);
 #if LECO_EMU_ASAN
     __sanitizer_finish_switch_fiber(r->fibers[me].fake, nullptr, nullptr);
@@ -194,6 +214,11 @@ void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
     r->block_arrived = 0;
     for (int w = 0; w < kMaxThreads / 64; ++w) r->wave_arrived[w] = 0;
     for (int i = 0; i < r->n; ++i) make_fiber(r, i);
+#if LECO_EMU_TSAN
+    r->sched_tsan = __tsan_get_current_fiber();
+    for (int i = 0; i < r->n; ++i)
+        if (!r->fibers[i].tsan) r->fibers[i].tsan = __tsan_create_fiber(0);
+#endif
     int live = r->n;
     long spins = 0;
     auto resume = [&](int i) {
@@ -202,6 +227,9 @@ void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
         set_tid(r, i);
 #if LECO_EMU_ASAN
         __sanitizer_start_switch_fiber(&r->sched_fake, r->stacks + (size_t)i * kStack, kStack);
+#endif
+#if LECO_EMU_TSAN
+        __tsan_switch_to_fiber(r->fibers[i].tsan, 0);
 #endif
         leco_emu_switch(&r->sched, &r->fibers[i].ctx);
 #if LECO_EMU_ASAN

@@ -51,7 +51,25 @@ __global__ void block_order_kernel(unsigned* cnt, int* order) {
     if (threadIdx.x == 0) order[atomicAdd(cnt, 1u)] = (int)blockIdx.x;
 }
 
-int main() {
+// Sixty-four workgroups add 1 to the same word 20 000 times each: with `atomic` through atomicAdd, otherwise with a plain read-modify-write -- a
+// race between workgroups, which only the ThreadSanitizer build (build_selftest(tsan=True)) can see.
+__global__ void cross_block_kernel(unsigned* word, int atomic) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < 20000; ++i) {       // long enough that the pool's threads are certainly inside it together
+        if (atomic) atomicAdd(word, 1u);
+        else *(volatile unsigned*)word = *(volatile unsigned*)word + 1;
+    }
+}
+
+int main(int argc, char** argv) {
+    if (argc > 2 && !strcmp(argv[1], "cross")) {
+        unsigned word = 0;
+        unsigned* pw = &word;
+        const int atomic = atoi(argv[2]);
+        hipLaunchKernelGGL(cross_block_kernel, dim3(64), dim3(64), 0, 0, pw, atomic);
+        printf("cross atomic=%d: %u\n", atomic, word);
+        return 0;
+    }
     unsigned cnt = 0;
     int order[12];
     for (int& v : order) v = -1;

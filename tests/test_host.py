@@ -345,6 +345,31 @@ def test_kernel_sources_are_clean_under_address_sanitizer():
     assert r.returncode != 0 and "heap-buffer-overflow" in r.stderr and "cast_f32_bf16_kernel" in r.stderr, r.stderr[-3000:]
 
 
+def test_no_two_workgroups_race_on_global_memory_under_thread_sanitizer():
+    """tools/emu_asan.py --tsan: the emulator runs the workgroups of a launch on a pool of OS threads, so ThreadSanitizer sees
+    workgroup against workgroup -- two of them touching the same global word without an atomic (work-items of ONE workgroup
+    are sequential here and ordered for the sanitizer).  First the probe (64 workgroups incrementing one word with a plain
+    read-modify-write: updates are lost and the race is reported; with atomicAdd neither), then the whole kernel test file:
+    no report may have emulator frames on both sides."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    if not os.path.exists(build_emu.TSAN_RT):
+        pytest.skip("no ThreadSanitizer runtime in this toolchain")
+    exe = build_emu.build_selftest(tsan=True)
+    env = dict(os.environ, LECO_EMU_THREADS="4")
+    ok = subprocess.run([exe, "cross", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert ok.returncode == 0 and ok.stdout.strip() == "cross atomic=1: 1280000" and "ThreadSanitizer" not in ok.stderr, ok.stderr[-2000:]
+    bad = subprocess.run([exe, "cross", "0"], env=env, capture_output=True, text=True, timeout=120)
+    assert "ThreadSanitizer: data race" in bad.stderr and "cross_block_kernel" in bad.stderr, bad.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_asan.py"), "--tsan"], cwd=ROOT, capture_output=True,
+                       text=True, timeout=2400)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    reports = [b for b in re.split(r"={18}\n", r.stdout + r.stderr) if "WARNING: ThreadSanitizer" in b]
+    ours = [b for b in reports if "libgomp" not in b and "libtorch" not in b]        # torch's own worker threads: not ours
+    assert not ours, ours[0][:3000]
+
+
 def _write_synthetic_clip(folder, hidden=64, layers=3):
     """A tiny but real transformers CLIP text stack on disk: tokenizer files + text_encoder/ (HF format)."""
     import json

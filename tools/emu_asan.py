@@ -4,6 +4,9 @@
     python tools/emu_asan.py [pytest arguments]          (default: tests/test_kernels.py -m "not gpu" -x -q)
     python tools/emu_asan.py --ubsan [pytest arguments]  (UndefinedBehaviorSanitizer: static-array bounds, shifts, signed
                                                           overflow, float-to-int range; "runtime error:" lines on stderr)
+    python tools/emu_asan.py --tsan [pytest arguments]   (ThreadSanitizer: unsynchronised accesses of two WORKGROUPS -- the emulator
+                                                          runs workgroups on a pool of OS threads -- to the same global memory;
+                                                          "WARNING: ThreadSanitizer" blocks on stderr)
 
 The host emulator (tests/emu/) compiles the unmodified leco_amd/csrc/*.hip for the CPU; with -fsanitize=address every
 global-memory access of a kernel is checked against the allocation of the tensor it belongs to (the interpreter runs
@@ -25,6 +28,14 @@ def main():
         build_emu.build(ubsan=True)
         args = argv[1:] or [os.path.join(ROOT, "tests", "test_kernels.py"), "-m", "not gpu", "-q"]
         env = dict(os.environ, LECO_EMU_UBSAN="1", UBSAN_OPTIONS=os.environ.get("UBSAN_OPTIONS", "print_stacktrace=0"))
+        os.execve(sys.executable, [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", "-s", *args], env)
+    if argv and argv[0] == "--tsan":        # ThreadSanitizer: workgroup against workgroup (the pool's OS threads)
+        build_emu.build(tsan=True)
+        args = argv[1:] or [os.path.join(ROOT, "tests", "test_kernels.py"), "-m", "not gpu", "-q"]
+        # torch's OpenMP workers synchronise through an uninstrumented libgomp: every tensor they filled would be reported
+        # against the kernel that reads it -- keep torch single-threaded under this sanitizer
+        env = dict(os.environ, LECO_EMU_TSAN="1", LD_PRELOAD=build_emu.TSAN_RT, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1",
+                   TSAN_OPTIONS=os.environ.get("TSAN_OPTIONS", "report_signal_unsafe=0:halt_on_error=0"))
         os.execve(sys.executable, [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", "-s", *args], env)
     build_emu.build(asan=True)
     args = argv or [os.path.join(ROOT, "tests", "test_kernels.py"), "-m", "not gpu", "-x", "-q"]
