@@ -85,14 +85,14 @@ __device__ __forceinline__ u32x4 gn_load(const GnSrc& s, int64_t row, int c, int
 }
 
 constexpr int GN_MAX_GROUPS = 32;
-constexpr int GN_SEG = 16;           // row segments of the in-block reduction tree
+constexpr int GN_MAX_WAVES = 16;     // 1024 threads
 
 // One block = (sample b, a run of `gpb` adjacent groups whose channel span is a multiple of 8): the block owns
 // every pixel of those channels, so the statistics need no cross-block step -- no atomics, no partial
 // buffers, no finishing kernel, bitwise reproducible.  Thread t = (pixel lane t / nv, 16-byte channel
 // vector t % nv): consecutive threads read consecutive 16-byte pieces of a pixel's channel run.
-//   pass 1: per-thread sums over its pixels -> LDS [pixel lane][channel][2] -> fixed-order tree
-//           (row segments, then segments, then the cg channels of a group) -> group statistics
+//   pass 1: per-thread sums over its pixels -> per-group sums in registers -> DPP wave reduction -> one LDS exchange
+//           of the wave totals, added by every thread in the same fixed order -> group statistics
 //   pass 2: the same pixels again (L2-resident by now) -> normalise (+SiLU) / dgrad -> store.
 // MODE 0: forward, statistics {sum x, sum x^2} (also written to stats[b][g][2] for the backward).
 // MODE 1: backward, statistics {sum dxhat, sum dxhat*xhat}, dx = rstd*(dxhat - s1/n - xhat*s2/n).
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
                                                          const float* gamma, const float* beta, int act,
                                                          float eps, int hw, int C, int G, int gpb,
                                                          bf16_t* out, int64_t ldo) {
-    float* lds = (float*)dyn_lds();
+    __shared__ f32x4 red[GN_MAX_WAVES][2];       // per wave: {sum, sumsq} of the block's <= 4 groups
     const int tid = (int)threadIdx.x, NT = (int)blockDim.x;
     const int b = (int)blockIdx.y, g0 = (int)blockIdx.x * gpb;
     const int cg = C / G, chunkC = gpb * cg, nv = chunkC / 8, cbase = g0 * cg;
@@ -114,10 +114,9 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
     const bool active = pl < PL;
     const int c = cbase + v * 8;
     const float inv_n = 1.f / ((float)hw * (float)cg);
-    float* stage = lds;                            // [PL][chunkC][2]
-    float* part = stage + PL * chunkC * 2;         // [GN_SEG][chunkC][2]
-    float* chan = part + GN_SEG * chunkC * 2;      // [chunkC][2]
-    float* gs = chan + chunkC * 2;                 // [gpb][2]
+    int gi[8];                                    // group (inside the block's run) of each of this thread's 8 channels
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gi[i] = (v * 8 + i) / cg;
 
     float ga[8], be[8], mu[8], rs[8];
 #pragma unroll
@@ -158,11 +157,6 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
                 for (int i = 0; i < 8; ++i) { s1[i] += x[i]; s2[i] += x[i] * x[i]; }
             }
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            stage[(pl * chunkC + v * 8 + i) * 2] = s1[i];
-            stage[(pl * chunkC + v * 8 + i) * 2 + 1] = s2[i];
-        }
     } else if (active) {
         for (int p0 = pl; p0 < hw; p0 += 4 * PL) {
             u32x4 xv[4], dv[4];
@@ -196,43 +190,45 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
                 }
             }
         }
+    }
+    // ---- block reduction: the thread's 8 per-channel sums fold into the <= 4 groups of the run (registers), every wave
+    // reduces them with DPP adds (wave_sum: no LDS traffic), ONE exchange through LDS, and every thread adds the wave totals
+    // in the same fixed order -- one barrier, bitwise reproducible (the round-2..5 form went through three LDS stages and
+    // four barriers with serial 13- to 20-term chains of LDS reads: 3 - 5x the latency floor of these launches).
+    f32x4 g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            stage[(pl * chunkC + v * 8 + i) * 2] = s1[i];
-            stage[(pl * chunkC + v * 8 + i) * 2 + 1] = s2[i];
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            g1[g] += gi[i] == g ? s1[i] : 0.f;
+            g2[g] += gi[i] == g ? s2[i] : 0.f;
         }
-    }
-    __syncthreads();
-    const int pairs = chunkC * 2;
-    for (int t = tid; t < pairs * GN_SEG; t += NT) {          // rows seg, seg + GN_SEG, ...
-        const int seg = t / pairs, pr = t - seg * pairs;
-        float acc = 0.f;
-        for (int r = seg; r < PL; r += GN_SEG) acc += stage[r * pairs + pr];
-        part[t] = acc;
-    }
-    __syncthreads();
-    for (int t = tid; t < pairs; t += NT) {
-        float acc = 0.f;
 #pragma unroll
-        for (int sgi = 0; sgi < GN_SEG; ++sgi) acc += part[sgi * pairs + t];
-        chan[t] = acc;
-    }
+    for (int g = 0; g < 4; ++g)
+        if (g < gpb) { g1[g] = wave_sum(g1[g]); g2[g] = wave_sum(g2[g]); }
+    const int wv = tid >> 6, nwv = NT >> 6;
+    if ((tid & 63) == 0) { red[wv][0] = g1; red[wv][1] = g2; }
     __syncthreads();
-    if (tid < gpb * 2) {
-        const int g = tid >> 1, comp = tid & 1;
-        float acc = 0.f;
-        for (int k = 0; k < cg; ++k) acc += chan[(g * cg + k) * 2 + comp];
-        gs[tid] = acc;
-        stats_out[((int64_t)b * G + g0 + g) * 2 + comp] = acc;
+    f32x4 gt1 = red[0][0], gt2 = red[0][1];
+    for (int w = 1; w < nwv; ++w) {
+        const f32x4 a = red[w][0], q = red[w][1];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { gt1[g] += a[g]; gt2[g] += q[g]; }
     }
-    __syncthreads();
+    if (tid < gpb) {
+        const float t1v = tid == 0 ? gt1[0] : (tid == 1 ? gt1[1] : (tid == 2 ? gt1[2] : gt1[3]));
+        const float t2v = tid == 0 ? gt2[0] : (tid == 1 ? gt2[1] : (tid == 2 ? gt2[2] : gt2[3]));
+        stats_out[((int64_t)b * G + g0 + tid) * 2] = t1v;
+        stats_out[((int64_t)b * G + g0 + tid) * 2 + 1] = t2v;
+    }
     if (!active) return;
     // ---- pass 2
     float t1[8], t2[8];   // MODE 0: mean, rstd.  MODE 1: s1/n, s2/n
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int g = (v * 8 + i) / cg;
-        const float q1 = gs[g * 2] * inv_n, q2 = gs[g * 2 + 1] * inv_n;
+        const int g = gi[i];
+        const float q1 = (g == 0 ? gt1[0] : (g == 1 ? gt1[1] : (g == 2 ? gt1[2] : gt1[3]))) * inv_n;
+        const float q2 = (g == 0 ? gt2[0] : (g == 1 ? gt2[1] : (g == 2 ? gt2[2] : gt2[3]))) * inv_n;
         if (MODE == 0) {
             t1[i] = q1;
             t2[i] = rsqrtf(fmaxf(q2 - q1 * q1, 0.f) + eps);
@@ -464,6 +460,27 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
     const int tid = (int)threadIdx.x, b = (int)blockIdx.y, cg = C / G;
     const int na0 = src.c0 / A, na1 = (C - src.c0) / A, ag = cg / A;        // atoms of x0 / x1, atoms per group
     __shared__ float part[GN_MAX_GROUPS * 8 * 2];
+    // Thread = (row lane, 16-byte channel vector).  The first four pixels of the first column sweep and their gamma / beta
+    // are FETCHED BEFORE the statistics are folded (they do not depend on them): the block's three dependent memory round
+    // trips (atom sums -> gamma / beta -> pixels) become one (round 6; a block normalises 16 .. 64 pixel rows, i.e. the
+    // prefetch is usually all of its input).
+    const int nvec = C / 8;
+    const int p0 = (int)blockIdx.x * rows_per_block;
+    const int p1 = min(hw, p0 + rows_per_block);
+    const int nvc_f = min(256, nvec), rows_par_f = 256 / nvc_f;
+    const int rl_f = tid / nvc_f, c_f = (tid - rl_f * nvc_f) * 8;
+    const bool pre_ok = rl_f < rows_par_f && p0 + rl_f < p1;
+    u32x4 pre[4];
+    f32x4 pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = pg0, pb0 = pg0, pb1 = pg0;
+    if (pre_ok) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + rl_f + u * rows_par_f;
+            pre[u] = gn_load<false>(src, (int64_t)b * hw + (p < p1 ? p : p0 + rl_f), c_f, 0);
+        }
+        pg0 = *(const f32x4*)(gamma + c_f); pg1 = *(const f32x4*)(gamma + c_f + 4);
+        pb0 = *(const f32x4*)(beta + c_f); pb1 = *(const f32x4*)(beta + c_f + 4);
+    }
     {   // 8 threads per group, each over every 8th channel of the group, combined in a fixed order: all blocks of a sample
         // arrive at bit-identical group statistics
         const int g = tid >> 3, pt = tid & 7;
@@ -493,19 +510,19 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
         }
     }
     __syncthreads();
-    // Thread = (row lane, 16-byte channel vector): the per-channel scale / shift a = rstd gamma, b = beta - mean a of its 8
-    // channels live in registers, so the pixel loop is load -> 8 fma (+ SiLU) -> store with no index arithmetic.
-    const int nvec = C / 8;
-    const int p0 = (int)blockIdx.x * rows_per_block;
-    const int p1 = min(hw, p0 + rows_per_block);
+    // the per-channel scale / shift a = rstd gamma, b = beta - mean a of a thread's 8 channels live in registers, so the pixel
+    // loop is load -> 8 fma (+ SiLU) -> store with no index arithmetic.
     for (int v0 = 0; v0 < nvec; v0 += 256) {
         const int nvc = min(256, nvec - v0), rows_par = 256 / nvc;
         const int rl = tid / nvc, c = (v0 + tid - rl * nvc) * 8;
         if (rl >= rows_par) continue;
         float sa[8], sb[8];
         {
-            const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
-            const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+            f32x4 g0 = pg0, g1 = pg1, b0 = pb0, b1 = pb1;
+            if (v0 != 0 || !pre_ok) {
+                g0 = *(const f32x4*)(gamma + c); g1 = *(const f32x4*)(gamma + c + 4);
+                b0 = *(const f32x4*)(beta + c); b1 = *(const f32x4*)(beta + c + 4);
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int g = (c + i) / cg;
@@ -515,10 +532,11 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
         }
         for (int pr = p0 + rl; pr < p1; pr += 4 * rows_par) {
             u32x4 xv[4];
+            const bool first = v0 == 0 && pr == p0 + rl;          // (pre_ok holds: pr < p1)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = pr + u * rows_par;
-                xv[u] = gn_load<false>(src, (int64_t)b * hw + (p < p1 ? p : pr), c, 0);
+                xv[u] = first ? pre[u] : gn_load<false>(src, (int64_t)b * hw + (p < p1 ? p : pr), c, 0);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -567,12 +585,6 @@ __global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* x, int64_t 
 
 constexpr int LN_MAXV = 4;  // vectors of 8 per lane => C <= 2048
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
-    return v;
-}
-
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, int64_t ldx, const float* gamma,
                                                       const float* beta, float eps, int M, int C,
                                                       bf16_t* y, int64_t ldy, float* mean, float* rstd) {
@@ -618,6 +630,97 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const bf16_t* x, int64_t ld
         }
     }
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// The hidden sizes of every supported UNet are C = 320 * 2^k (320 / 640 / 1280): C / 8 = 5 L vectors with L in {8, 16, 32}.
+// A row is then normalised by L lanes x 5 vectors each, a wave works on 64 / L rows at once (x R2 row groups: every load of
+// the wave is in flight before the first reduction), the row sums stay inside DPP rows (row8_sum / row16_sum; L = 32 adds
+// the two row totals through v_readlane) and gamma / beta are fetched once per lane for all of its rows -- against one
+// row per wave, 60 % idle lanes at C = 640, two 6-step ds_bpermute chains and 64 B of gamma / beta per 16 B of x above.
+template <int L, int R2>
+__global__ __launch_bounds__(256) void ln_fwd5_kernel(const bf16_t* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                                       int M, int C, bf16_t* y, int64_t ldy, float* mean, float* rstd) {
+    constexpr int RW = 64 / L;
+    const int lane = lane_id(), sub = lane / L, li = lane - sub * L;
+    const int wave = (int)blockIdx.x * ((int)blockDim.x >> 6) + ((int)threadIdx.x >> 6);
+    const int row0 = wave * (RW * R2) + sub;
+    u32x4 xv[R2][5];
+#pragma unroll
+    for (int q = 0; q < R2; ++q) {
+        const int row = row0 + RW * q;
+        const bf16_t* xr = x + (int64_t)(row < M ? row : 0) * ldx + li * 8;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) xv[q][j] = *(const u32x4*)(xr + L * 8 * j);
+    }
+    f32x4 ga[5][2], be[5][2];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int c = (li + L * j) * 8;
+        ga[j][0] = *(const f32x4*)(gamma + c); ga[j][1] = *(const f32x4*)(gamma + c + 4);
+        be[j][0] = *(const f32x4*)(beta + c); be[j][1] = *(const f32x4*)(beta + c + 4);
+    }
+    auto rsum = [&](float v) -> float {
+        if constexpr (L == 8) return row8_sum(v);
+        else if constexpr (L == 16) return row16_sum(v);
+        else {
+            v = row16_sum(v);
+            const float a = shfl(v, 0) + shfl(v, 16), b2 = shfl(v, 32) + shfl(v, 48);     // (wave-uniform lanes: v_readlane)
+            return sub == 0 ? a : b2;
+        }
+    };
+    const float inv_c = 1.f / (float)C;
+    float mu[R2], rs[R2];
+#pragma unroll
+    for (int q = 0; q < R2; ++q) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float f[8];
+            unpack8(xv[q][j], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += f[i];
+        }
+        mu[q] = rsum(s) * inv_c;
+    }
+#pragma unroll
+    for (int q = 0; q < R2; ++q) {
+        float ss = 0.f;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float f[8];
+            unpack8(xv[q][j], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float d = f[i] - mu[q]; ss += d * d; }
+        }
+        rs[q] = rsqrtf(rsum(ss) * inv_c + eps);
+    }
+#pragma unroll
+    for (int q = 0; q < R2; ++q) {
+        const int row = row0 + RW * q;
+        if (row >= M) continue;
+        bf16_t* yr = y + (int64_t)row * ldy + li * 8;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            float f[8], o[8];
+            unpack8(xv[q][j], f);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = (f[i] - mu[q]) * rs[q] * ga[j][i >> 2][i & 3] + be[j][i >> 2][i & 3];
+            *(u32x4*)(yr + L * 8 * j) = pack8(o);
+        }
+        if (li == 0) { mean[row] = mu[q]; rstd[row] = rs[q]; }
+    }
+}
+template <int L>
+void ln_fwd5_launch(hipStream_t s, const bf16_t* x, int64_t ldx, const float* gamma, const float* beta, float eps, int m, int c,
+                    bf16_t* y, int64_t ldy, float* mean, float* rstd) {
+    constexpr int RW = 64 / L;
+    // two row groups per wave once that still leaves >= 4 waves for every CU; one-wave workgroups while the launch has fewer
+    // than 1024 waves (every CU gets work)
+    const bool two = cdiv(m, RW * 2) >= 1024;
+    const int waves = cdiv(m, RW * (two ? 2 : 1));
+    const int wpb = waves >= 1024 ? 4 : 1;
+    if (two) hipLaunchKernelGGL((ln_fwd5_kernel<L, 2>), dim3(cdiv(waves, wpb)), dim3(64 * wpb), 0, s, x, ldx, gamma, beta, eps, m, c, y, ldy, mean, rstd);
+    else hipLaunchKernelGGL((ln_fwd5_kernel<L, 1>), dim3(cdiv(waves, wpb)), dim3(64 * wpb), 0, s, x, ldx, gamma, beta, eps, m, c, y, ldy, mean, rstd);
 }
 
 // dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)) (+ dres), dxhat = dy * gamma
@@ -693,9 +796,7 @@ GnGeom gn_geom(int hw, int C, int G) {
     int threads = want >= 1024 ? 1024 : (int)((want + 63) / 64 * 64);
     if (threads < 256) threads = 256;
     if (threads < nv) threads = (nv + 63) / 64 * 64;
-    const int PL = threads / nv, chunkC = gpb * cg;
-    const int lds = (PL * chunkC * 2 + GN_SEG * chunkC * 2 + chunkC * 2 + gpb * 2) * (int)sizeof(float);
-    return GnGeom{gpb, threads, lds};
+    return GnGeom{gpb, threads, 0};
 }
 // One block per (sample, group run) is the fastest shape while a block's slice stays small or there are
 // enough of them to fill the chip; large slices on few blocks (the 64x64 / 32x32 levels at batch 4) are
@@ -709,12 +810,6 @@ template <int MODE, int NVR, bool WS = false>
 void gn_launch_v(const GnGeom& ge, dim3 grid, hipStream_t s, GnSrc src, const bf16_t* dy, int64_t lddy,
                  const float* fstats, float* stats_out, const float* gamma, const float* beta, int act, float eps,
                  int hw, int C, int G, bf16_t* out, int64_t ldo) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gn_block_kernel<MODE, NVR, WS>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        attr_set = true;
-    }
     hipLaunchKernelGGL((gn_block_kernel<MODE, NVR, WS>), grid, dim3(ge.threads), ge.lds, s, src, dy, lddy, fstats, stats_out,
                        gamma, beta, act, eps, hw, C, G, ge.gpb, out, ldo);
 }
@@ -853,6 +948,14 @@ extern "C" int leco_layernorm_fwd(const void* x, int64_t ldx, const float* gamma
                                   float eps, int32_t m, int32_t c, void* y, int64_t ldy, float* mean,
                                   float* rstd, leco_stream_t stream) {
     if (c % 8 || c > 64 * 8 * LN_MAXV) return fail(-EINVAL, "layernorm: unsupported C=%d", c);
+    static const bool no5 = [] { const char* e = getenv("LECO_LN5"); return e && atoi(e) == 0; }();     // A/B switch
+    if (!no5 && (c == 320 || c == 640 || c == 1280)) {
+        hipStream_t s = (hipStream_t)stream;
+        if (c == 320) ln_fwd5_launch<8>(s, (const bf16_t*)x, ldx, gamma, beta, eps, m, c, (bf16_t*)y, ldy, mean, rstd);
+        else if (c == 640) ln_fwd5_launch<16>(s, (const bf16_t*)x, ldx, gamma, beta, eps, m, c, (bf16_t*)y, ldy, mean, rstd);
+        else ln_fwd5_launch<32>(s, (const bf16_t*)x, ldx, gamma, beta, eps, m, c, (bf16_t*)y, ldy, mean, rstd);
+        return check_launch("leco_layernorm_fwd");
+    }
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(cdiv(m, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        ldx, gamma, beta, eps, m, c, (bf16_t*)y, ldy, mean, rstd);
     return check_launch("leco_layernorm_fwd");

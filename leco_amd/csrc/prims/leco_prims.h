@@ -167,6 +167,38 @@ __device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) { return __umu
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+// Sum over lanes without LDS traffic: butterfly inside each row of 16 lanes by DPP (v_add_f32_dpp: quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror -- after each step both partners hold the same partial, so the pairing is that of an xor
+// butterfly with masks 1, 2, 4, 8), then the four row totals through v_readlane as (r0 + r1) + (r2 + r3).  Every lane
+// returns the same bits; a 6-step __shfl_xor loop is six dependent ds_bpermute round trips (~100 cycles each).
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// all 16 lanes of a DPP row (lanes 16 r .. 16 r + 15) receive the row's sum
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);      // quad_perm [1, 0, 3, 2]
+    v += dpp_f32<0x4E>(v);      // quad_perm [2, 3, 0, 1]
+    v += dpp_f32<0x141>(v);     // row_half_mirror
+    v += dpp_f32<0x140>(v);     // row_mirror
+    return v;
+}
+// sum over 8 consecutive lanes (lanes 8 q .. 8 q + 7)
+__device__ __forceinline__ float row8_sum(float v) {
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    const int bits = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 48));
+    return (r0 + r1) + (r2 + r3);
+}
 // two fp32 fused multiply-adds in one instruction (v_pk_fma_f32); true when the predicate holds in any lane of the wave
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }

@@ -194,6 +194,14 @@ static inline float shfl(float v, int src) {
     memcpy(&r, all + (size_t)(src & 63) * emu::kSlot, 4);
     return r;
 }
+// the DPP reductions of the hardware header as xor butterflies (same pairing, same bits)
+static inline float row8_sum(float v) { v += shfl_xor(v, 1); v += shfl_xor(v, 2); v += shfl_xor(v, 4); return v; }
+static inline float row16_sum(float v) { v = row8_sum(v); v += shfl_xor(v, 8); return v; }
+static inline float wave_sum(float v) {
+    v = row16_sum(v);
+    const float r0 = shfl(v, 0), r1 = shfl(v, 16), r2 = shfl(v, 32), r3 = shfl(v, 48);
+    return (r0 + r1) + (r2 + r3);
+}
 static inline float fast_exp2(float x) { return exp2f(x); }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 }  // namespace leco

@@ -457,7 +457,7 @@ def test_groupnorm_fwd_bwd(dev, act, B, HW, C0, C1, G):
     assert rel_err(stats[:B * G * 2].cpu(), s_ref) < 1e-4
 
 
-@pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64)])
+@pytest.mark.parametrize("M,C", [(37, 320), (9, 1280), (5, 64), (77, 640), (16390, 320), (4100, 640), (2050, 1280)])
 def test_layernorm_fwd_bwd(dev, M, C):
     torch.manual_seed(4)
     x = (torch.randn(M, C) * 1.5 + 0.3).to(bf).to(dev); gamma = torch.randn(C).to(dev); beta = torch.randn(C).to(dev)
