@@ -189,6 +189,34 @@ def test_gemm_two_source(dev):
     assert rel_err(o32, torch.cat([a0, a1], 1).float() @ w.float().T) < TOL32
 
 
+@pytest.mark.parametrize("split,stats", [(2, False), (5, False), (8, True), (11, False), (6, True)])
+def test_gemm_splitk_finish_sums_every_slab(dev, split, stats):
+    """split-K partial slabs + the finishing kernels (plain and GroupNorm-statistics form): the slab loop keeps four loads in
+    flight (round 6) -- every slab count around the unroll boundary gives the single-launch result."""
+    torch.manual_seed(split)
+    M, N, K = 130, 128, 64 * 12
+    a = torch.randn(M, K).to(bf).to(dev); w = (torch.randn(N, K) / K ** 0.5).to(bf).to(dev)
+    bias = torch.randn(N).to(dev); res = torch.randn(M, N).to(bf).to(dev)
+    ws = torch.zeros(16 * M * N, device=dev)
+    outs = []
+    for sp in (1, split):
+        out = torch.zeros(M, N, dtype=bf, device=dev)
+        kw = {}
+        cs = None
+        if stats:
+            cs = torch.zeros(1, N // 4, 2, device=dev)
+            kw = dict(col_stats=cs, stats_rows=M, stats_atom=4)
+        g = hip.gemm_args(a, w, out, m=M, n=N, k=K, bias=bias, residual=res, act=hip.ACT_SILU, **kw)
+        hip.gemm(g, ops.default_stream(), tile=1, split_k=sp, ws=ws)
+        _sync(dev)
+        outs.append((out.float().cpu(), None if cs is None else cs.cpu().clone()))
+    ref = F.silu(a.float().cpu() @ w.float().cpu().T + bias.cpu() + res.float().cpu())
+    assert rel_err(outs[1][0], ref) < TOLBF
+    assert rel_err(outs[1][0], outs[0][0]) < 3e-3          # same sums up to the fp32 order of the slabs
+    if stats:
+        assert rel_err(outs[1][1], _col_stats_ref(outs[1][0].to(bf), 1, M, 4)) < 1e-5
+
+
 def test_gemm_rejects_bad_shapes(dev):
     a = torch.zeros(8, 40, dtype=bf, device=dev)
     with pytest.raises(hip.LecoError):
