@@ -37,6 +37,13 @@ def step_flops(bs: int, k: int, arch: str = "sd15", res: int = 512) -> float:
     return 2 * bs * f * (k + 5 + a)
 
 
+def step_flops_dedup(bs: int, k: int, U: int, arch: str = "sd15", res: int = 512) -> float:
+    """SURVEY 8(d) W_min: the de-duplicated step executes bs F_fwd (2 k + U + 1 + (1 + a)) -- the guidance-1 passes on the
+    conditional samples only, U distinct frozen prompts, a backward of batch bs."""
+    f_fwd, a = F_FWD.get((arch, res), (F_FWD_SD15_512 * (res / 512.0) ** 2, ATTN_SHARE))
+    return bs * f_fwd * (2 * k + U + 1 + (1.0 + a))
+
+
 def cpu_baseline(k_mean: float, bs: int, ks=(1, 2), budget_s: float = 900.0):
     """The reference loop on the host CPU (BASELINE.json configs[0]: SD1.5, rank 4, 512^2, prompt batch 1, fp32,
     DDIM, AdamW), as a port: `oracle/step_ref.leco_step` restates one iteration of train_lora.py:141-281 on the
@@ -428,6 +435,8 @@ def main():
                     help="write the per-shape (launches, GFLOP, us) table of the dominant kernel to FILE (profiles/rNN_dominant_shapes.txt)")
     ap.add_argument("--no-telemetry", action="store_true", help="no clock / power sampler thread beside the timed loop")
     ap.add_argument("--telemetry-hz", type=float, default=10.0)
+    ap.add_argument("--no-dedup", action="store_true",
+                    help="skip the second timed loop (the de-duplicated pass structure, reported beside the headline as `dedup`)")
     ap.add_argument("--k", type=int, default=0, help="profiling only: fixed number of denoising passes per step "
                                                      "(0 = the seeded reference distribution; the headline number uses 0)")
     args = ap.parse_args()
@@ -571,6 +580,35 @@ def main():
     if tele:
         tele_samples = tele.stop()
         tele_after = tele.snapshot()
+    # ---- the same k sequence once more on the DE-DUPLICATED pass structure (FusedStep.dedup, what train() runs unless
+    # --strict_reference): reported beside the headline, never as the headline -- the headline executes the reference's own
+    # k + 3 + 1 CFG-doubled passes.  Two untimed steps first (plan build + graph capture).
+    dedup_out = None
+    if not args.no_dedup and not args.dominant_only and not emu:
+        fused.dedup = True
+        for i in range(min(2, args.warmup + args.steps)):
+            one(i)
+        barrier()
+        td0 = time.perf_counter()
+        dlosses = []
+        for i in range(args.warmup, args.warmup + args.steps):
+            dlosses.append(one(i).clone())
+        barrier()
+        dtd = time.perf_counter() - td0
+        fused.dedup = False
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([dtd], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtd = t.item()
+        U = fused._dedup_info(pair, args.bs)["U"]
+        dfl = sum(step_flops_dedup(args.bs, k, U, args.arch, args.res) for k in ks[args.warmup:])
+        dedup_out = {"value": world * args.steps / dtd, "unit": "steps/s", "ms_per_step": dtd / args.steps * 1e3,
+                     "distinct_frozen_prompts": U, "loss": float(dlosses[-1].item()),
+                     "achieved": dfl / dtd / 1e12, "peak": PEAK_BF16 / 1e12, "frac": dfl / dtd / PEAK_BF16,
+                     "note": "same seeded k sequence on FusedStep(dedup=True): the guidance-1 passes run on the conditional samples "
+                             "only (train_util.py:151,163-166: u + 1 (c - u) = c) and identical prompts once (train_lora.py:202-237); "
+                             "achieved = W_min(k) = bs F_fwd (2 k + U + 2 + a) over wall time (barrier to barrier), whole job"}
     e1 = step_ev[-1] if not emu else None
     dt_ev = e0.elapsed_time(e1) * 1e-3 if not emu else dt
     gpu_done = [e0.elapsed_time(ev) * 1e-3 for ev in step_ev] if not emu else list(host_done)
@@ -614,6 +652,8 @@ def main():
                    "hip_graphs": bool(unet.use_graphs), "parallelism": f"dp{world}", "loss": losses[-1], "losses": losses,
                    "collectives_per_step": collectives / args.steps, "k_identical_across_ranks": ks_same},
     }
+    if dedup_out is not None:
+        out["dedup"] = dedup_out
     if emu:
         out["data"] = "synthetic; HOST EMULATOR DRY RUN (LECO_BENCH_EMU=1): plumbing check, not a measurement"
         out["dtype"] = "bf16 (emulated)"

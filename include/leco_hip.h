@@ -235,6 +235,10 @@ int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1,
                        leco_stream_t stream);
 /* 1 if leco_groupnorm_fwd handles this shape in one launch, 0 if it takes three (statistics, finish, apply) */
 int leco_groupnorm_single_launch(int32_t batch, int32_t hw, int32_t c, int32_t groups);
+/* 1 if the producer-statistics form (col_stats / leco_colstats + leco_groupnorm_apply_stats) is the faster GroupNorm for a
+ * tensor of this shape: the three-launch shapes and the large-pixel-count shapes with too few (sample, group run) blocks to
+ * fill the chip.  The plan builder's LECO_GN_FUSED=auto asks this per producing tensor. */
+int leco_groupnorm_prefers_stats(int32_t batch, int32_t hw, int32_t c, int32_t groups);
 /* GroupNorm (+SiLU) forward whose input is the UNFINISHED output of a split-K convolution (leco_gemm_args.no_finish):
  * x[row][c] = bf16( sum_s ws[s][row][c] + bias[c] + rowbias[row / hw][c] ) -- exactly what the finishing pass would have stored --
  * is formed in the kernel's loader, so diffusers' `ResnetBlock2D`: conv1 (+ time_emb_proj bias) -> norm2 -> SiLU
@@ -334,6 +338,12 @@ int leco_cfg_sched_step(const float* pred, float* x, void* x2, const float* coef
 int leco_esd_loss(const float* tgt, const float* pos, const float* neu, const float* unc, float g_pred,
                   float g_loss, float sign, int64_t half_n, float* loss, float* dpred,
                   leco_stream_t stream);
+/* The same objective on CONDITIONAL-ONLY predictions (fp32 [half_n] each): at guidance_scale = 1 -- what the reference
+ * passes for the three frozen passes and the target pass, train_lora.py:202-256 -- predict_noise's u + 1 (c - u)
+ * (train_util.py:163-166) is c, so FusedStep's de-duplicated step never evaluates the unconditional halves.  pos_c / neu_c /
+ * unc_c may alias (identical prompts are evaluated once).  dpred_c (may be NULL): d loss / d tgt_c. */
+int leco_esd_loss_cond(const float* tgt_c, const float* pos_c, const float* neu_c, const float* unc_c, float g_loss,
+                       float sign, int64_t half_n, float* loss, float* dpred_c, leco_stream_t stream);
 /* torch.optim.AdamW step on the flat fp32 LoRA slab + refresh of its bf16 shadow
  * (train_lora.py:280).  hyper (device): {lr, 1-beta1^t, 1-beta2^t, grad_scale}. */
 int leco_adamw(float* p, const float* g, float* m, float* v, void* shadow, const float* hyper,

@@ -429,25 +429,30 @@ __global__ __launch_bounds__(256) void cfg_sched_kernel(const float* pred, float
 constexpr int ESD_BLOCKS = 64;
 __device__ float g_esd_part[ESD_BLOCKS];
 __device__ unsigned g_esd_ticket = 0;
-__global__ __launch_bounds__(256) void esd_loss_kernel(const float* tgt, const float* pos, const float* neu,
-                                                        const float* unc, float g_pred, float g_loss, float sign,
-                                                        int64_t half_n, float* loss, float* dpred) {
+// Every prediction is the guided combination u + g_pred (c - u) of the two halves of a CFG-doubled UNet output
+// (train_util.py:163-166).  A NULL unconditional half (`*_u`) means the pass ran on the conditional samples only: the
+// prediction IS c -- what the combination evaluates to at g_pred = 1, the value the reference passes for all four passes
+// (train_lora.py:202-256), up to the fp32 rounding of u + (c - u).  That is the de-duplicated step of FusedStep.
+__global__ __launch_bounds__(256) void esd_loss_kernel(const float* tgt_u, const float* tgt_c, const float* pos_u, const float* pos_c,
+                                                        const float* neu_u, const float* neu_c, const float* unc_u, const float* unc_c,
+                                                        float g_pred, float g_loss, float sign, int64_t half_n, float* loss,
+                                                        float* dpred_u, float* dpred_c) {
     __shared__ float red[4];
     __shared__ bool last;
     float part = 0.f;
     const float inv_n = 1.f / (float)half_n;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < half_n; e += (int64_t)gridDim.x * 256) {
-        const float t = tgt[e] + g_pred * (tgt[half_n + e] - tgt[e]);
-        const float p = pos[e] + g_pred * (pos[half_n + e] - pos[e]);
-        const float n = neu[e] + g_pred * (neu[half_n + e] - neu[e]);
-        const float u = unc[e] + g_pred * (unc[half_n + e] - unc[e]);
+        const float t = tgt_u ? tgt_u[e] + g_pred * (tgt_c[e] - tgt_u[e]) : tgt_c[e];
+        const float p = pos_u ? pos_u[e] + g_pred * (pos_c[e] - pos_u[e]) : pos_c[e];
+        const float n = neu_u ? neu_u[e] + g_pred * (neu_c[e] - neu_u[e]) : neu_c[e];
+        const float u = unc_u ? unc_u[e] + g_pred * (unc_c[e] - unc_u[e]) : unc_c[e];
         const float goal = n + sign * g_loss * (p - u);
         const float diff = t - goal;
         part += diff * diff;
-        if (dpred) {
+        if (dpred_c) {
             const float d = 2.f * diff * inv_n;
-            dpred[e] = (1.f - g_pred) * d;
-            dpred[half_n + e] = g_pred * d;
+            if (dpred_u) dpred_u[e] = (1.f - g_pred) * d;
+            dpred_c[e] = (tgt_u ? g_pred : 1.f) * d;
         }
     }
 #pragma unroll
@@ -817,15 +822,27 @@ extern "C" int leco_cfg_sched_step(const float* pred, float* x, void* x2, const 
                        (const int*)step, guidance, half_n, noise, hist, n_hist);
     return check_launch("leco_cfg_sched_step");
 }
-extern "C" int leco_esd_loss(const float* tgt, const float* pos, const float* neu, const float* unc, float g_pred,
-                             float g_loss, float sign, int64_t half_n, float* loss, float* dpred,
-                             leco_stream_t stream) {
+static int esd_launch(const float* tu, const float* tc, const float* pu, const float* pc, const float* nu, const float* nc,
+                      const float* uu, const float* uc, float g_pred, float g_loss, float sign, int64_t half_n, float* loss,
+                      float* du, float* dc, leco_stream_t stream, const char* what) {
     // one workgroup (bs*4*h*w = 32 k .. 64 k elements): the loss is reduced in a fixed order -- bitwise reproducible
     const int64_t want = (half_n + 4095) / 4096;       // >= 16 elements of each stream per thread
     const int blocks = (int)(want < 1 ? 1 : (want > ESD_BLOCKS ? ESD_BLOCKS : want));
-    hipLaunchKernelGGL(esd_loss_kernel, dim3(blocks), dim3(256), 0, LECO_STREAM, tgt, pos, neu, unc, g_pred, g_loss, sign,
-                       half_n, loss, dpred);
-    return check_launch("leco_esd_loss");
+    hipLaunchKernelGGL(esd_loss_kernel, dim3(blocks), dim3(256), 0, LECO_STREAM, tu, tc, pu, pc, nu, nc, uu, uc, g_pred, g_loss,
+                       sign, half_n, loss, du, dc);
+    return check_launch(what);
+}
+extern "C" int leco_esd_loss(const float* tgt, const float* pos, const float* neu, const float* unc, float g_pred,
+                             float g_loss, float sign, int64_t half_n, float* loss, float* dpred,
+                             leco_stream_t stream) {
+    return esd_launch(tgt, tgt + half_n, pos, pos + half_n, neu, neu + half_n, unc, unc + half_n, g_pred, g_loss, sign, half_n, loss,
+                      dpred, dpred ? dpred + half_n : nullptr, stream, "leco_esd_loss");
+}
+extern "C" int leco_esd_loss_cond(const float* tgt_c, const float* pos_c, const float* neu_c, const float* unc_c, float g_loss,
+                                  float sign, int64_t half_n, float* loss, float* dpred_c, leco_stream_t stream) {
+    if (!tgt_c || !pos_c || !neu_c || !unc_c || !loss || half_n <= 0) return fail(-EINVAL, "leco_esd_loss_cond: null operand");
+    return esd_launch(nullptr, tgt_c, nullptr, pos_c, nullptr, neu_c, nullptr, unc_c, 1.f, g_loss, sign, half_n, loss, nullptr,
+                      dpred_c, stream, "leco_esd_loss_cond");
 }
 extern "C" int leco_adamw(float* p, const float* g, float* m, float* v, void* shadow, const float* hyper,
                           float beta1, float beta2, float eps, float wd, int64_t n, leco_stream_t stream) {

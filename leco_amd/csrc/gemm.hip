@@ -314,36 +314,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     }
     constexpr int LDS_RING = NS * (BM + BN + 16 * TF) * BK * 2;     // bytes of the ring = what the epilogue staging may reuse
     float* lnst = (float*)(dyn_lds() + LDS_RING);                   // LNF: {mean, rstd} per tile row, behind both
-    // epilogue geometry (used below the K loop; the residual prefetch needs it here)
-    constexpr int SROW = BN + 4;                 // padded fp32 row (bank spread for the f32x4 writes)
-    constexpr int NC8 = BN / 8;
-    constexpr int LDSB = LDS_RING;
-#ifdef LECO_GEMM_EPI64      // A/B aid (tools/_ablate builds): the round-2 form, 64 rows per round
-    constexpr int RR = 64;
-#else
-    constexpr int RR = ((BM * SROW + 2 * BN) * 4 <= LDSB && (BM * NC8) % NT == 0) ? BM : 64;
-#endif
-    constexpr bool EVEN = (RR * NC8) % NT == 0;
-    constexpr int ITEMS = (RR * NC8 + NT - 1) / NT;
-    // Residual prefetch (round 6): where the whole tile is one epilogue round and a thread owns <= 4 items, the residual
-    // vectors are fetched HERE, in front of the first DMA -- older than everything the counted vmcnt waits cover (in-order
-    // completion), so the K loop's waits stay exact -- instead of behind the K loop, where their latency was the one
-    // exposed global round trip of the epilogue (a third of a short-K projection's time is its epilogue).
-    constexpr bool RPRE = RR == BM && ITEMS <= 4 && !LNF;
-    u32x4 rpre[RPRE ? ITEMS : 1];
-    if constexpr (RPRE) {
-        const bf16_t* resp = (const bf16_t*)p.residual;
-        if (resp && rt.split_k == 1 && p.act != LECO_ACT_GEGLU) {
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const int e = tid + it * NT;
-                const int rl = e / NC8, cc = e - rl * NC8;
-                const int m = m0 + rl, n = n0 + cc * 8;
-                rpre[it] = u32x4{0u, 0u, 0u, 0u};
-                if ((EVEN || e < RR * NC8) && m < M && n < N) rpre[it] = *(const u32x4*)(resp + (int64_t)m * p.ldr + n);
-            }
-        }
-    }
 #pragma unroll
     for (int s0 = 0; s0 < NS; ++s0)
         if (s0 < nstage) stage(s0, s0);
@@ -522,6 +492,16 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     // Every thread owns ITEMS (row, 8-column) items of a round; their residual loads are all issued before the first is
     // used: one exposed global latency per round instead of one per item (the short-K projections spend a third of their
     // time here).
+    constexpr int SROW = BN + 4;                 // padded fp32 row (bank spread for the f32x4 writes)
+    constexpr int NC8 = BN / 8;
+    constexpr int LDSB = LDS_RING;
+#ifdef LECO_GEMM_EPI64      // A/B aid (tools/_ablate builds): the round-2 form, 64 rows per round
+    constexpr int RR = 64;
+#else
+    constexpr int RR = ((BM * SROW + 2 * BN) * 4 <= LDSB && (BM * NC8) % NT == 0) ? BM : 64;
+#endif
+    constexpr bool EVEN = (RR * NC8) % NT == 0;
+    constexpr int ITEMS = (RR * NC8 + NT - 1) / NT;
     float* stg = (float*)dyn_lds();
     bf16_t* cp = (bf16_t*)p.c;
     const bf16_t* res = (const bf16_t*)p.residual;
@@ -588,10 +568,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
             continue;
         }
         u32x4 rres[ITEMS];
-        if constexpr (RPRE) {
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) rres[it] = rpre[it];
-        } else if (res && !wsp) {
+        if (res && !wsp) {
 #pragma unroll
             for (int it = 0; it < ITEMS; ++it) {
                 const int e = tid + it * NT;
@@ -728,20 +705,9 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const leco_gemm_args
     const bf16_t* res = (const bf16_t*)p.residual;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int m = (int)(e / nq), n = (int)(e - (int64_t)m * nq) * 4;
-        // the slabs are summed in order (bit-identical to the GroupNorm-side finish, norm.hip gn_load<true>), but FOUR loads
-        // are in flight at a time: the rolled loop was one dependent L2 / HBM round trip per slab, 2 .. 16 of them in a row
-        const float* wp = ws + (int64_t)m * N + n;
-        const int64_t slab = (int64_t)M * N;
-        f32x4 a = *(const f32x4*)wp;
-        int s = 1;
-        for (; s + 3 < splits; s += 4) {
-            const f32x4 b0 = *(const f32x4*)(wp + s * slab), b1 = *(const f32x4*)(wp + (s + 1) * slab);
-            const f32x4 b2 = *(const f32x4*)(wp + (s + 2) * slab), b3 = *(const f32x4*)(wp + (s + 3) * slab);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) a[r] = (((a[r] + b0[r]) + b1[r]) + b2[r]) + b3[r];
-        }
-        for (; s < splits; ++s) {
-            const f32x4 b = *(const f32x4*)(wp + s * slab);
+        f32x4 a = *(const f32x4*)(ws + (int64_t)m * N + n);
+        for (int s = 1; s < splits; ++s) {
+            f32x4 b = *(const f32x4*)(ws + ((int64_t)s * M + m) * N + n);
             a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
         }
         float v[4] = {a[0], a[1], a[2], a[3]};
@@ -797,18 +763,9 @@ __global__ __launch_bounds__(256) void splitk_finish_stats_kernel(const leco_gem
     };
     if (n < N) {
         for (int m = m0 + rlane; m < mhi; m += 16) {
-            const float* wp = ws + (int64_t)m * N + n;
-            const int64_t slab = (int64_t)M * N;
-            f32x4 a = *(const f32x4*)wp;
-            int sp = 1;
-            for (; sp + 3 < splits; sp += 4) {       // four slab loads in flight, summed in slab order (see splitk_finish_kernel)
-                const f32x4 b0 = *(const f32x4*)(wp + sp * slab), b1 = *(const f32x4*)(wp + (sp + 1) * slab);
-                const f32x4 b2 = *(const f32x4*)(wp + (sp + 2) * slab), b3 = *(const f32x4*)(wp + (sp + 3) * slab);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] = (((a[r] + b0[r]) + b1[r]) + b2[r]) + b3[r];
-            }
-            for (; sp < splits; ++sp) {
-                const f32x4 b = *(const f32x4*)(wp + sp * slab);
+            f32x4 a = *(const f32x4*)(ws + (int64_t)m * N + n);
+            for (int sp = 1; sp < splits; ++sp) {
+                const f32x4 b = *(const f32x4*)(ws + ((int64_t)sp * M + m) * N + n);
                 a[0] += b[0]; a[1] += b[1]; a[2] += b[2]; a[3] += b[3];
             }
             float v[4] = {a[0], a[1], a[2], a[3]};

@@ -867,6 +867,16 @@ extern "C" int leco_groupnorm_single_launch(int32_t batch, int32_t hw, int32_t c
     if (groups <= 0 || c % groups) return 1;
     return gn_use_block_kernel(gn_geom(hw, c, groups), batch, hw, c, groups) ? 1 : 0;
 }
+/* 1: for this tensor the producer-statistics form (leco_gemm_args.col_stats / leco_colstats + leco_groupnorm_apply_stats: a
+ * pixel-parallel ONE-pass apply on the whole chip) is the faster GroupNorm: every shape that would take three launches, and
+ * (round 6, profiles/r06_bench_norm.txt) the 32^2-and-larger levels whose (sample, group run) blocks cover at most half of
+ * the 256 CUs -- 14.6 vs 7.1 us at B = 4, HW = 1024, C = 640 (64 blocks), 13.6 vs 5.5 us at C = 320 (32 blocks). */
+extern "C" int leco_groupnorm_prefers_stats(int32_t batch, int32_t hw, int32_t c, int32_t groups) {
+    if (groups <= 0 || c % groups) return 0;
+    const GnGeom ge = gn_geom(hw, c, groups);
+    if (!gn_use_block_kernel(ge, batch, hw, c, groups)) return 1;
+    return (hw >= 1024 && batch * (groups / ge.gpb) <= 128) ? 1 : 0;
+}
 extern "C" int leco_groupnorm_fwd_splitk(const float* ws, int32_t splits, const float* bias, const float* rowbias,
                                          int64_t ld_rowbias, const float* gamma, const float* beta, int32_t batch, int32_t hw,
                                          int32_t c, int32_t groups, float eps, int32_t act, float* stats, void* y, int64_t ldy,

@@ -43,6 +43,7 @@ _SIGS = {
     "leco_cfg_ddim_step": [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp],
     "leco_cfg_sched_step": [_vp, _vp, _vp, _vp, _vp, _f32, _i64, _vp, _vp, _i32, _vp],
     "leco_esd_loss": [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp, _vp, _vp],
+    "leco_esd_loss_cond": [_vp, _vp, _vp, _vp, _f32, _f32, _i64, _vp, _vp, _vp],
     "leco_adamw": [_vp, _vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _i64, _vp],
     "leco_lion": [_vp, _vp, _vp, _vp, _vp, _f32, _f32, _f32, _i64, _vp],
     "leco_cast_f32_bf16": [_vp, _vp, _i64, _vp],
@@ -307,6 +308,12 @@ def cfg_ddim_step(pred, x, x2, coef, step, guidance, half_n) -> Op:
 def esd_loss(tgt, pos, neu, unc, g_pred, g_loss, sign, half_n, loss, dpred) -> Op:
     return Op("leco_esd_loss", (ptr(tgt), ptr(pos), ptr(neu), ptr(unc), g_pred, g_loss, sign, half_n, ptr(loss),
                                 ptr(dpred)))
+
+
+def esd_loss_cond(tgt_c, pos_c, neu_c, unc_c, g_loss, sign, half_n, loss, dpred_c) -> Op:
+    """The ESD objective on conditional-only predictions (the de-duplicated step: guidance_scale = 1 makes u + 1 (c - u) = c)."""
+    return Op("leco_esd_loss_cond", (ptr(tgt_c), ptr(pos_c), ptr(neu_c), ptr(unc_c), g_loss, sign, half_n, ptr(loss), ptr(dpred_c)),
+              keep=(tgt_c, pos_c, neu_c, unc_c, loss, dpred_c))
 
 
 def adamw(p, g, m, v, shadow, hyper, beta1, beta2, eps, wd, n) -> Op:

@@ -383,6 +383,16 @@ class Plan:
         self.key: Optional[tuple] = None      # its key in Engine.plans (set by Engine.plan)
         self.ctx_src = None                   # the tensor `ctx` was last filled from (FusedStep skips identical refills)
 
+    def set_ctx(self, t: torch.Tensor, src=None) -> None:
+        """The ONE writer of the prompt-context buffer.  ``src``: an identity token for the contents (FusedStep passes the
+        cached embedding tensor of the prompt pair and skips the copy while the plan still holds it); None = anonymous
+        contents, the next tokened call copies again.  Plans are shared through ``Engine.plans`` (keyed by shape), so every
+        writer has to go through here -- a direct ``plan.ctx.copy_`` would leave a stale token behind."""
+        if src is not None and self.ctx_src is src:
+            return
+        self.ctx.copy_(t)
+        self.ctx_src = src
+
 
 class Engine:
     def __init__(self, unet: "UNet2DConditionModel", device: torch.device):
@@ -565,7 +575,7 @@ class Engine:
             ops.lnfold_pack(self._lnf_dev, len(reg)).run()
 
     # ---- plan construction ---------------------------------------------------------------------
-    def plan(self, B: int, h: int, w: int, need_bwd: bool = True, ws_slot: int = 0, share: int = 1) -> Plan:
+    def plan(self, B: int, h: int, w: int, need_bwd: bool = True, ws_slot: int = 0, share: int = 1, tag: Optional[str] = None) -> Plan:
         """``need_bwd=False`` builds a forward-only plan (no gradient buffers): used for the batched
         LoRA-off passes, which never run a backward.  ``ws_slot`` > 0 gives the plan's split-K launches a workspace of
         their own (the only mutable buffer plans share), so that its lists may run CONCURRENTLY with another plan's on a
@@ -577,6 +587,8 @@ class Engine:
         if share > 1:
             assert not need_bwd and B % share == 0
             key = key + ("share", share)
+        if tag:      # a private copy of an otherwise identical plan (FusedStep's de-duplicated passes: their batch sizes collide
+            key = key + ("tag", tag)      # with the faithful plans of another resident (bs, h, w) bucket, and buckets are evicted alone)
         if key not in self.plans:
             with ops.f32_mode(self.f32):
                 # (the side workspace of forked sections is allocated by `PlanBuilder.forked()` on first use: 128 MB that
@@ -701,7 +713,11 @@ class PlanBuilder:
         B = self.B if batch is None else batch
         if not self.gn_fused or cols % self.stat_atom:
             return None
-        if self.gn_mode == "auto" and hip.lib().leco_groupnorm_single_launch(B, hw, cols, self.cfg.norm_num_groups):
+        # auto: where the one-pass apply on producer statistics is the faster GroupNorm (leco_groupnorm_prefers_stats);
+        # auto3: the round-3..5 rule (only the shapes that would otherwise take three launches), kept for A/B runs
+        if self.gn_mode == "auto" and not hip.lib().leco_groupnorm_prefers_stats(B, hw, cols, self.cfg.norm_num_groups):
+            return None
+        if self.gn_mode == "auto3" and hip.lib().leco_groupnorm_single_launch(B, hw, cols, self.cfg.norm_num_groups):
             return None
         n = 2 * B * (cols // self.stat_atom)
         assert self.stat_used + n <= self.stat_arena.numel(), "GroupNorm statistics arena too small"
@@ -1671,14 +1687,14 @@ class UNet2DConditionModel(nn.Module):
             g = plan.graphs[which] = gh
         hip.check(lib.leco_graph_launch(g, cur.cuda_stream), "graph launch")
 
-    def prepare(self, sample_shape, lora_on: bool) -> Plan:
+    def prepare(self, sample_shape, lora_on: bool, tag: Optional[str] = None) -> Plan:
         B, _, h, w = sample_shape
         eng = self.engine()
         net = eng.network
         if net is not None and lora_on and (net.needs_repack() or eng._pack_scale != net.multiplier):
             net.sync_shadow()
             eng.refresh_lora(net.multiplier)
-        return eng.plan(B, h, w)
+        return eng.plan(B, h, w, tag=tag)
 
     def lora_active(self) -> bool:
         net = self.engine().network
@@ -1714,8 +1730,7 @@ class UNet2DConditionModel(nn.Module):
         lora_on = self.lora_active()
         plan = self.prepare(sample.shape, lora_on)
         plan.x_in.copy_(sample)
-        plan.ctx.copy_(encoder_hidden_states)
-        plan.ctx_src = None
+        plan.set_ctx(encoder_hidden_states)
         t = torch.as_tensor(timestep)
         plan.t_table[:1].copy_(t.reshape(-1)[:1].to(torch.float32))
         plan.t_idx.zero_()

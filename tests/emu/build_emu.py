@@ -31,8 +31,21 @@ def _digest(path):
     return h.hexdigest()[:16]
 
 
-ASAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
-TSAN_RT = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.tsan-x86_64.so"
+def _runtime(name: str) -> str:
+    """Path of a sanitizer runtime of THIS clang (whatever its version directory is called)."""
+    try:
+        out = subprocess.run([CLANG, f"-print-file-name=libclang_rt.{name}-x86_64.so"], capture_output=True, text=True,
+                             check=True).stdout.strip()
+        if os.path.isabs(out) and os.path.exists(out):
+            return out
+        out = subprocess.run([CLANG, f"-print-file-name=libclang_rt.{name}.so"], capture_output=True, text=True, check=True).stdout.strip()
+        return out if os.path.isabs(out) and os.path.exists(out) else ""
+    except (OSError, subprocess.CalledProcessError):
+        return ""
+
+
+ASAN_RT = _runtime("asan")
+TSAN_RT = _runtime("tsan")
 
 
 def build(verbose=False, asan=None, ubsan=None, tsan=None):

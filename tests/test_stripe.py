@@ -186,7 +186,7 @@ def _stripe_unet(dev, heads=8):
 
 def _run_plan(m, plan, which, x, ctx, t=500.0):
     plan.x_in.copy_(x)
-    plan.ctx.copy_(ctx)
+    plan.set_ctx(ctx)
     plan.t_table[:1].fill_(t)
     plan.t_idx.zero_()
     m._run(plan, which)

@@ -172,6 +172,60 @@ def test_fused_step_matches_reference_golden(dev):
     assert torch.equal(net.shadow[:net.numel].cpu(), net.slab.detach()[:net.numel].to(bf).cpu())
 
 
+@pytest.mark.parametrize("same_prompts", [False, True])
+def test_dedup_step_equals_the_faithful_step(dev, same_prompts):
+    """`FusedStep(dedup=True)` (train()'s default): the guidance-1 passes run on the conditional samples only and identical
+    prompts once (train_util.py:151,163-166: u + 1 (c - u) = c; train_lora.py:202-237 evaluates equal prompts separately).
+    Same four predictions, loss, LoRA gradients and updated parameters as the reference-faithful pass structure -- compared
+    with the golden reference step at the faithful step's own tolerances, and with the faithful step directly."""
+    m = hip_unet(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
+    load_lora(net)
+    emb = _golden_emb()
+    if same_prompts:       # the usual prompt file: neutral == unconditional == "" -> U = 2 distinct frozen prompts
+        emb = dict(emb, neutral=emb["unconditional"].clone())
+    settings = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=2.0,
+                                          batch_size=BS, resolution=128, action="erase")
+    pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["target"], emb["positive"], emb["unconditional"],
+                                        emb["neutral"], settings)
+    slab0 = net.slab.detach().clone()
+    res = {}
+    for mode in (False, True):
+        with torch.no_grad():
+            net.slab.copy_(slab0)
+            net.exp_avg.zero_(); net.exp_avg_sq.zero_()
+        net.sync_shadow(); net.mark_updated()
+        fs = FusedStep(m, net, create_noise_scheduler("ddim"), N_STEPS, lr=1e-3, dedup=mode)
+        loss = fs.step(pair, K, GOLD["latents"].clone())
+        last = fs._state[(BS, 16, 16)]["last"]
+        assert last["dedup"] == mode
+        half = slice(None) if mode else slice(BS, None)          # faithful: [uncond half | cond half]
+        res[mode] = dict(loss=loss.item(), grads=net.grad[:net.numel].cpu().clone(), params=net.slab.detach()[:net.numel].cpu().clone(),
+                         target=last["plan"].pred.cpu()[half].clone(),
+                         **{n: last["preds"][n].cpu()[half].clone() for n in ("positive", "neutral", "unconditional")})
+        if mode:
+            U = 2 if same_prompts else 3
+            assert last["plan"].pred.shape[0] == BS and last["fplan"].pred.shape[0] == U * BS
+            if same_prompts:
+                assert last["preds"]["neutral"].data_ptr() == last["preds"]["unconditional"].data_ptr()
+    f, d = res[False], res[True]
+    for n in ("target", "positive", "neutral", "unconditional"):
+        e = rel_err(d[n], f[n])
+        print(f"dedup vs faithful {n}: {e:.3g}")
+        assert e < 2.5e-2                       # two launch plans of different batch: bf16 rounding apart (cf. plan vs plan, DESIGN 8.00)
+    assert abs(d["loss"] - f["loss"]) / f["loss"] < 5e-2
+    assert rel_err(d["grads"], f["grads"]) < 6e-2 and rel_err(d["params"], f["params"]) < 1e-2
+    if not same_prompts:                        # the golden step was minted with four distinct prompts
+        cal = _torch_bf16_step_errors()
+        assert rel_err(d["target"], GOLD["step.pred.target"]) <= 1.25 * cal["target"]
+        for n in ("positive", "neutral", "unconditional"):
+            assert rel_err(d[n], GOLD["step.pred." + n]) <= 1.25 * cal["target"]
+        assert abs(d["loss"] - GOLD["step.loss"].item()) / GOLD["step.loss"].item() <= max(1.25 * cal["loss"], 2e-2)
+        assert rel_err(d["grads"], GOLD["step.grads"]) <= max(1.25 * cal["grads"], 5e-2)
+        assert rel_err(d["params"], GOLD["step.params_after"]) < 1e-2
+
+
 def test_c3lier_conv_and_time_emb_lora_forward_backward(dev):
     """network.type = c3lier (BASELINE config 4): LoRA on ResnetBlock2D conv1/conv2/conv_shortcut/time_emb_proj and the
     Down/Upsample2D convs (3x3 conv lora_down, stride 2 and nearest-2x variants included) + the transformer linears."""

@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from leco_amd import hip, ops  # noqa: E402
-from tools.bench_xgemm import graph_us  # noqa: E402
+from tools.libswitch import graph_us, use_lib  # noqa: E402
 
 bf = torch.bfloat16
 dev = torch.device("cuda:0")
@@ -67,7 +67,7 @@ def main():
     for (m, n, k, res, geglu, cnt) in SHAPES + EXTRA:
         cols, ref = [], None
         for li, lib in enumerate(libs):
-            hip._use_library(lib)
+            use_lib(lib)
             torch.manual_seed(1)
             op, g, ws, c = build(m, n, k, res, geglu)
             desc = hip.gemm_describe(g, op.args[1], op.args[2], ws.data_ptr(), ws.numel() * 4)

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from leco_amd import hip, ops  # noqa: E402
-from tools.bench_xgemm import graph_us  # noqa: E402
+from tools.libswitch import graph_us, use_lib  # noqa: E402
 
 bf = torch.bfloat16
 dev = torch.device("cuda:0")
@@ -27,7 +27,7 @@ def main():
     libs = [hip.LIB_PATH] + sys.argv[1:]
     rows = {}
     for lib in libs:
-        hip._use_library(lib)
+        use_lib(lib)
         for B in (4, 12):
             for hw, c0, c1 in GN:
                 C = c0 + c1

@@ -30,6 +30,8 @@ def main():
         env = dict(os.environ, LECO_EMU_UBSAN="1", UBSAN_OPTIONS=os.environ.get("UBSAN_OPTIONS", "print_stacktrace=0"))
         os.execve(sys.executable, [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", "-s", *args], env)
     if argv and argv[0] == "--tsan":        # ThreadSanitizer: workgroup against workgroup (the pool's OS threads)
+        if not os.path.exists(build_emu.TSAN_RT):
+            sys.exit("emu_asan.py --tsan: this clang has no libclang_rt.tsan runtime to preload (build_emu.TSAN_RT is empty)")
         build_emu.build(tsan=True)
         args = argv[1:] or [os.path.join(ROOT, "tests", "test_kernels.py"), "-m", "not gpu", "-q"]
         # torch's OpenMP workers synchronise through an uninstrumented libgomp: every tensor they filled would be reported
@@ -37,6 +39,8 @@ def main():
         env = dict(os.environ, LECO_EMU_TSAN="1", LD_PRELOAD=build_emu.TSAN_RT, OMP_NUM_THREADS="1", MKL_NUM_THREADS="1",
                    TSAN_OPTIONS=os.environ.get("TSAN_OPTIONS", "report_signal_unsafe=0:halt_on_error=0"))
         os.execve(sys.executable, [sys.executable, "-m", "pytest", "-p", "no:cacheprovider", "-s", *args], env)
+    if not os.path.exists(build_emu.ASAN_RT):
+        sys.exit("emu_asan.py: this clang has no libclang_rt.asan runtime to preload (build_emu.ASAN_RT is empty)")
     build_emu.build(asan=True)
     args = argv or [os.path.join(ROOT, "tests", "test_kernels.py"), "-m", "not gpu", "-x", "-q"]
     env = dict(os.environ, LECO_EMU_ASAN="1", LD_PRELOAD=build_emu.ASAN_RT,
