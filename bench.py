@@ -164,8 +164,7 @@ def _launch_identity(op):
         parts = hip.gemm_describe(g, a[1], a[2], a[3], a[4]).split(" ; ")
         names = [p.split(" grid=")[0] for p in parts]
         ext = g.ext_k if (g.a_ext or g.t_w) else 0
-        key = (op.name, g.m, g.n, g.k, g.a_mode, ext, bool(g.t_w), bool(g.residual), g.act, g.batch, g.h_in, g.h_out, a[1], a[2],
-               bool(g.ln_s), bool(g.no_finish))
+        key = (op.name, g.m, g.n, g.k, g.a_mode, ext, bool(g.t_w), bool(g.residual), g.act, g.batch, g.h_in, g.h_out, a[1], a[2])
         kin = g.k // 9 if g.a_mode else g.k
         rows_in = g.m if g.a_mode == 0 else g.batch * g.h_in * g.w_in
         # algorithmic operand bytes: every input / weight / output element once (bf16), + the residual read
@@ -202,6 +201,11 @@ def _launch_identity(op):
         bm = 32 if A.k == 1280 else 64
         return ([f"xgemm_kernel<{bm}, {A.k}, {os.environ.get('LECO_XGEMM_VAR', '1')}>"], (op.name, A.m, A.n, A.k, ext, 1 if A.residual else 0),
                 2.0 * A.m * A.n * (A.k + ext), 2.0 * (A.m * A.k + A.n * A.k + A.m * A.n * (2 if A.residual else 1)))
+    if op.name in ("leco_groupnorm_fwd", "leco_groupnorm_apply_stats"):
+        B, hw, c = (a[7], a[8], a[9]) if op.name == "leco_groupnorm_fwd" else (a[10], a[11], a[12])
+        return [op.name], (op.name, B, hw, c), 0.0, 4.0 * B * hw * c
+    if op.name == "leco_layernorm_fwd":
+        return [op.name], (op.name, a[5], a[6]), 0.0, 4.0 * a[5] * a[6]
     if op.name == "leco_attention_bwd":
         B, H, sq, skv, d = a[26], a[27], a[28], a[29], a[30]
         return ["attention_bwd(3 kernels)"], (op.name, B, H, sq, skv, d), 10.0 * B * H * sq * skv * d, 2.0 * B * H * d * (4 * sq + 4 * skv)
@@ -211,7 +215,7 @@ def _launch_identity(op):
 def step_launches(st, k_mean):
     """[(op, launches per step)] of one reference-faithful step with k_mean denoising passes."""
     out = []
-    skip = ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step", "leco_fork", "leco_join")      # step state / stream edges; negligible time
+    skip = ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step")      # step state; negligible time
     for plan, which, w in ((st["dplan"], "ctx_on", 1.0), (st["dplan"], "denoise", float(k_mean)), (st["fplan"], "fwd_off", 1.0),
                            (st["plan"], "fwd_on", 1.0), (st["plan"], "bwd", 1.0)):
         out += [(op, w, which) for op in plan.lists[which] if op.name not in skip]
@@ -253,6 +257,54 @@ def _time_launch_us(op, reps=8):
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
+
+
+def _graph_launch_us(op, copies=16, reps=20):
+    """One plan launch replayed from a hipGraph holding `copies` of it (no eager launch floor: what the step's graphs pay;
+    the ~1.5 us node-to-node floor of a dependent chain is part of the figure)."""
+    import ctypes as C
+    from leco_amd import hip, ops
+    from leco_amd.unet import _graph_api
+    lib = _graph_api()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    hip.check(lib.leco_graph_begin_capture(side.cuda_stream), "begin")
+    try:
+        ops.run_plan([op] * copies, side.cuda_stream)
+    finally:
+        g = C.c_void_p()
+        hip.check(lib.leco_graph_end_capture(side.cuda_stream, C.byref(g)), "end")
+    cur = torch.cuda.current_stream().cuda_stream
+    for _ in range(3):
+        lib.leco_graph_launch(g, cur)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.leco_graph_launch(g, cur)
+    e1.record()
+    e1.synchronize()
+    lib.leco_graph_destroy(g)
+    return e0.elapsed_time(e1) / reps / copies * 1e3
+
+
+HBM_PEAK = 8.0e12            # HBM3E, MI355X_MICROARCH.md
+
+
+def hbm_bound_launches(groups, top_n=6):
+    """The GroupNorm / LayerNorm launches of a step (the HBM-bound kernels of the path, SURVEY 8d: read + write 2 B per
+    element each): the `top_n` shapes by time per step, each timed from a hipGraph, GB/s against the 8 TB/s roof."""
+    cand = [(key, op, w, by) for key, (op, names, fl, w, by) in groups.items()
+            if key[0] in ("leco_groupnorm_fwd", "leco_groupnorm_apply_stats", "leco_layernorm_fwd") and by > 0]
+    rows = []
+    for key, op, w, by in cand:
+        us = _graph_launch_us(op)
+        rows.append({"op": key[0][5:], "shape": list(key[1:]), "launches_per_step": w, "us_per_launch": us,
+                     "algorithmic_bytes": by, "achieved_GBps": by / us / 1e3, "frac": by / us / 1e3 / (HBM_PEAK / 1e9)})
+    rows.sort(key=lambda r: -r["launches_per_step"] * r["us_per_launch"])
+    tot = sum(r["launches_per_step"] * r["us_per_launch"] for r in rows)
+    return {"peak_GBps": HBM_PEAK / 1e9, "us_per_step_all_norm_launches": tot, "top": rows[:top_n],
+            "note": "us from a hipGraph of 16 copies of the launch (includes the ~1.5 us node-to-node floor); bytes = one bf16 read + "
+                    "one bf16 write of the tensor; these launches are latency-, not bandwidth-bound at UNet batch 4 (DESIGN 8.000)"}
 
 
 def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
@@ -334,6 +386,10 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
     out["isolated_us"] = {"per_denoise_pass": list_us.get("denoise", 0.0),
                           "fixed": sum(v for k_, v in list_us.items() if k_ != "denoise"), "by_list": list_us,
                           "launches": {which: sum(d.values()) for which, d in per_list.items()}}
+    try:
+        out["hbm_bound"] = hbm_bound_launches(groups)
+    except Exception as e:       # never hide the MFMA figures behind the secondary list
+        out["hbm_bound"] = {"error": repr(e)}
     if dump_shapes:
         # every shape the dominant kernel runs in a step: the numerator of the fraction can be recomputed from this table
         n, us, fl, shapes, by = per_name[name]
@@ -604,7 +660,7 @@ def main():
         U = fused._dedup_info(pair, args.bs)["U"]
         dfl = sum(step_flops_dedup(args.bs, k, U, args.arch, args.res) for k in ks[args.warmup:])
         dedup_out = {"value": world * args.steps / dtd, "unit": "steps/s", "ms_per_step": dtd / args.steps * 1e3,
-                     "distinct_frozen_prompts": U, "loss": float(dlosses[-1].item()),
+                     "distinct_frozen_prompts": U, "loss": float(dlosses[-1].item()), "losses": [float(l.item()) for l in dlosses],
                      "achieved": dfl / dtd / 1e12, "peak": PEAK_BF16 / 1e12, "frac": dfl / dtd / PEAK_BF16,
                      "note": "same seeded k sequence on FusedStep(dedup=True): the guidance-1 passes run on the conditional samples "
                              "only (train_util.py:151,163-166: u + 1 (c - u) = c) and identical prompts once (train_lora.py:202-237); "
@@ -709,7 +765,8 @@ def main():
         # the roofline object is the DOMINANT KERNEL's (algorithmic FLOPs per launch / its average launch duration);
         # the whole-step figure rides along
         out["roofline"] = {"bound": "mfma", "achieved": dom["achieved"], "peak": dom["peak"], "unit": "TFLOP/s",
-                           "frac": dom["frac"], "traffic": dom.get("traffic"), "kernel": dom, "whole_step": whole}
+                           "frac": dom["frac"], "traffic": dom.get("traffic"), "kernel": dom, "whole_step": whole,
+                           "hbm_bound": dom.pop("hbm_bound", None)}
     except Exception as e:  # never hide the step number
         out["roofline"] = {"bound": "mfma", "achieved": whole["achieved"], "peak": whole["peak"], "unit": "TFLOP/s",
                            "frac": whole["frac"], "traffic": None, "whole_step": whole, "kernel": {"error": repr(e)}}

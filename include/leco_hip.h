@@ -98,24 +98,6 @@ typedef struct leco_gemm_args {
     float* col_stats;
     int32_t stats_rows;
     int32_t stats_atom;
-    /* split-K launches only (leco_gemm_ex with split_k > 1): 1 = leave the fp32 partial slabs ws[split][m][n] in the workspace
-     * and do NOT run the finishing pass (sum + bias + rowbias + residual + activation -> c): the consumer does it --
-     * leco_groupnorm_fwd_splitk, for ResnetBlock2D.conv1 -> norm2, whose pre-norm tensor has no other reader in a forward-only
-     * pass.  Ignored when the launch does not split. */
-    int32_t no_finish;
-    /* LayerNorm folded into this Linear (diffusers' BasicTransformerBlock: norm1 -> attn1.to_q|k|v, norm2 -> attn2.to_q,
-     * norm3 -> ff.net.0.proj; forward-only passes).  When ln_s != NULL: a0 holds the RAW rows x (k = the normalised width),
-     * w = bf16(gamma (.) W), t_w = the 16-row stacked bf16(gamma (.) lora_down) image whose row 15 is all ones,
-     *   ln_s[n] = sum_k w[n][k],  ln_c[n] = sum_k beta[k] W[n][k] + bias[n]        (fp32 [n]; GEGLU: in the interleaved order)
-     *   ln_sd[j], ln_cd[j] the same sums for the stacked down rows (fp32 [16], entry 15 = 0)
-     * and the kernel returns rstd (x w^T - mean ln_s) + ln_c (+ the LoRA term, + GEGLU) with mean / rstd of x's rows over k
-     * (eps = ln_eps) taken from its own operands.  Needs t_w with t_rows == 16, one plain A operand, bias == NULL, no split-K
-     * (leco_lnfold_pack builds the t_w image and ln_sd / ln_cd from the packed lora_down once per optimizer step). */
-    const float* ln_s;
-    const float* ln_c;
-    const float* ln_sd;
-    const float* ln_cd;
-    float ln_eps;
 } leco_gemm_args;
 
 int leco_gemm(const leco_gemm_args* args, leco_stream_t stream);
@@ -147,21 +129,6 @@ typedef struct leco_lora_site {
 
 int leco_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_stream_t stream);
 
-/* The per-optimizer-step half of the LayerNorm fold (leco_gemm_args.ln_s), after leco_lora_pack: for every Linear whose
- * LayerNorm is folded in (diffusers' BasicTransformerBlock.norm{1,2,3} -> attn1 q|k|v / attn2.to_q / ff.net.0.proj; LoRA branch
- * lora.py:102-106) the 16-row stacked lora_down image is re-scaled by the LayerNorm weight -- dn_ln[j][k] =
- * bf16(gamma[k] dn_s[j][k]), row 15 := ones (the LoRA stack must leave it free: groups * r <= 15) -- and
- * sd[j] = sum_k dn_ln[j][k], cd[j] = sum_k beta[k] dn_s[j][k] (fp32 [16]).  `sites`: DEVICE array. */
-typedef struct leco_lnfold_site {
-    const void* dn_s;     /* bf16 [>= 16][k]: leco_lora_site.dn_s */
-    const float* gamma;   /* fp32 [k] LayerNorm weight */
-    const float* beta;    /* fp32 [k] LayerNorm bias */
-    void* dn_ln;          /* bf16 [16][k] out */
-    float* sd;            /* fp32 [16] out */
-    float* cd;            /* fp32 [16] out */
-    int32_t k;
-} leco_lnfold_site;
-int leco_lnfold_pack(const leco_lnfold_site* sites, int32_t nsites, leco_stream_t stream);
 
 /* G[j*g_sj + c*g_sc] += scale * sum_m P[m][p_off+j] * Q[m][q_off+c], j<r, c<cols (LoRA weight
  * gradients into the flat gradient slab).  P, Q bf16.  Replaces autograd's wgrad of lora_down / lora_up
@@ -235,18 +202,6 @@ int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, int64_t ld1,
                        leco_stream_t stream);
 /* 1 if leco_groupnorm_fwd handles this shape in one launch, 0 if it takes three (statistics, finish, apply) */
 int leco_groupnorm_single_launch(int32_t batch, int32_t hw, int32_t c, int32_t groups);
-/* 1 if the producer-statistics form (col_stats / leco_colstats + leco_groupnorm_apply_stats) is the faster GroupNorm for a
- * tensor of this shape: the three-launch shapes and the large-pixel-count shapes with too few (sample, group run) blocks to
- * fill the chip.  The plan builder's LECO_GN_FUSED=auto asks this per producing tensor. */
-int leco_groupnorm_prefers_stats(int32_t batch, int32_t hw, int32_t c, int32_t groups);
-/* GroupNorm (+SiLU) forward whose input is the UNFINISHED output of a split-K convolution (leco_gemm_args.no_finish):
- * x[row][c] = bf16( sum_s ws[s][row][c] + bias[c] + rowbias[row / hw][c] ) -- exactly what the finishing pass would have stored --
- * is formed in the kernel's loader, so diffusers' `ResnetBlock2D`: conv1 (+ time_emb_proj bias) -> norm2 -> SiLU
- * (train_util.py:156-160) costs one launch and one trip through memory less.  One-launch shapes only
- * (leco_groupnorm_single_launch); ws: fp32 [splits][batch * hw][c]; bias / rowbias may be NULL. */
-int leco_groupnorm_fwd_splitk(const float* ws, int32_t splits, const float* bias, const float* rowbias, int64_t ld_rowbias,
-                              const float* gamma, const float* beta, int32_t batch, int32_t hw, int32_t c, int32_t groups,
-                              float eps, int32_t act, float* stats, void* y, int64_t ldy, leco_stream_t stream);
 /* GroupNorm forward from per-(sample, channel) {sum, sumsq} statistics that the producers of x0 / x1 left behind
  * (leco_gemm_args.col_stats, or leco_colstats for tensors whose producer has no such epilogue): ONE pass over x, no
  * reduction over pixels.  cstats0: fp32 [batch][(c0 or c) / atom][2] for x0's channels, cstats1: [batch][(c - c0) / atom][2]
@@ -481,19 +436,6 @@ int leco_graph_begin_capture(leco_stream_t stream);
 int leco_graph_end_capture(leco_stream_t stream, leco_graph_t* out);
 int leco_graph_launch(leco_graph_t graph, leco_stream_t stream);
 int leco_graph_destroy(leco_graph_t graph);
-
-/* ------------------------------------------------------------------------
- * Two-stream sections of a launch list (round 4).  The reference runs every op of a UNet pass serially on one stream
- * (train_util.py:156-160); a few of them are independent of their neighbours -- ResnetBlock2D.conv_shortcut reads the
- * block's INPUT and is only needed by conv2's residual add, so it can run beside norm1 -> conv1 -> norm2, whose
- * GroupNorm launches leave most of the chip idle.  leco_fork makes the library's side stream (one per device, created on
- * first use) wait for everything enqueued on `stream` so far; launches handed leco_side_stream() then run concurrently
- * with `stream`; leco_join makes `stream` wait for them.  Inside a stream capture the fork / join become graph edges.
- * A forked launch must not share mutable scratch (split-K workspace) with the launches it runs beside.
- * ---------------------------------------------------------------------- */
-int leco_fork(leco_stream_t stream);
-int leco_join(leco_stream_t stream);
-leco_stream_t leco_side_stream(void);
 
 /* ---- fp32 compute mode (`train.precision: float32`, config_util.py:75-83; csrc/f32.hip) --------------------------------
  * One twin per entry point above that touches activations: SAME argument list and meaning, but every tensor the bf16

@@ -918,48 +918,26 @@ extern "C" int leco_step_mid(const void* src, void* dst_a, void* dst_b, int64_t 
                        (u32x4*)dst_b, bytes / 16, reps_b, t_cur, t_slot_a, t_slot_b, (int*)t_idx_a, (int*)t_idx_b, slot);
     return check_launch("leco_step_mid");
 }
+// byte fill as a KERNEL node.  (hipMemsetAsync captured into a hipGraph becomes a memset node; round 6 met a replayed graph
+// -- the de-duplicated frozen pass, a second plan of the denoising plan's exact shape -- whose memset node zeroed the
+// GroupNorm statistics arena on the first replay only: profiles/r06_graph_memset_node.txt.)
+__global__ __launch_bounds__(256) void fill_kernel(unsigned* p, unsigned v, int64_t n4, unsigned char* tail, int ntail, unsigned char b) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) p[e] = v;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = b;
+}
 extern "C" int leco_memset(void* p, int32_t value, int64_t bytes, leco_stream_t stream) {
-    hipError_t e = hipMemsetAsync(p, value, (size_t)bytes, LECO_STREAM);
-    if (e != hipSuccess) return fail(-EIO, "leco_memset: %s", hipGetErrorString(e));
-    return 0;
+    if (!p || bytes < 0 || ((uintptr_t)p & 3)) return fail(-EINVAL, "leco_memset: pointer must be 4-byte aligned");
+    if (bytes == 0) return 0;
+    const unsigned b = (unsigned)value & 0xffu, v = b * 0x01010101u;
+    const int64_t n4 = bytes / 4;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n4 > 0 ? n4 : 1)), dim3(256), 0, LECO_STREAM, (unsigned*)p, v, n4,
+                       (unsigned char*)p + n4 * 4, (int)(bytes - n4 * 4), (unsigned char)b);
+    return check_launch("leco_memset");
 }
 extern "C" int leco_lora_pack(const leco_lora_site* sites, int32_t nsites, leco_stream_t stream) {
     if (nsites <= 0) return 0;
     hipLaunchKernelGGL(lora_pack_kernel, dim3(64, (unsigned)nsites), dim3(256), 0, LECO_STREAM, sites);
     return check_launch("leco_lora_pack");
-}
-// ---- LayerNorm fold (leco_gemm_args.ln_s): the per-optimizer-step half.  One block per (stacked lora_down row j < 16, site):
-//   dn_ln[j][k] = bf16(gamma[k] * dn_s[j][k]),  sd[j] = sum_k dn_ln[j][k] (the ROUNDED values: what the MFMA multiplies),
-//   cd[j] = sum_k beta[k] * dn_s[j][k];   row 15: all ones (its T column is sum_k x[k]), sd = cd = 0.
-__global__ __launch_bounds__(256) void lnfold_pack_kernel(const leco_lnfold_site* sites) {
-    __shared__ float red[2][256];
-    const leco_lnfold_site s = sites[blockIdx.y];
-    const int j = (int)blockIdx.x, tid = (int)threadIdx.x;
-    const bf16_t* src = (const bf16_t*)s.dn_s + (int64_t)j * s.k;
-    bf16_t* dst = (bf16_t*)s.dn_ln + (int64_t)j * s.k;
-    float a = 0.f, b = 0.f;
-    for (int k = tid; k < s.k; k += 256) {
-        if (j == 15) { dst[k] = f2bf(1.0f); continue; }
-        const float d = bf2f(src[k]);
-        const bf16_t q = f2bf(s.gamma[k] * d);
-        dst[k] = q;
-        a += bf2f(q);
-        b += s.beta[k] * d;
-    }
-    red[0][tid] = a;
-    red[1][tid] = b;
-    __syncthreads();
-    for (int st = 128; st > 0; st >>= 1) {       // fixed-order tree: bitwise reproducible
-        if (tid < st) { red[0][tid] += red[0][tid + st]; red[1][tid] += red[1][tid + st]; }
-        __syncthreads();
-    }
-    if (tid == 0) { s.sd[j] = j == 15 ? 0.f : red[0][0]; s.cd[j] = j == 15 ? 0.f : red[1][0]; }
-}
-extern "C" int leco_lnfold_pack(const leco_lnfold_site* sites, int32_t nsites, leco_stream_t stream) {
-    if (nsites <= 0) return 0;
-    if (!sites) return fail(-EINVAL, "leco_lnfold_pack: null site table");
-    hipLaunchKernelGGL(lnfold_pack_kernel, dim3(16, (unsigned)nsites), dim3(256), 0, LECO_STREAM, sites);
-    return check_launch("leco_lnfold_pack");
 }
 static int wgrad_launch(const void* p, int64_t ldp, const void* q, int64_t ldq, float* g, int64_t g_sj, int64_t g_sc,
                         int32_t m, int32_t r, int32_t cols, float scale, WgradConv cv, float* part, int64_t part_bytes,

@@ -83,15 +83,8 @@ struct GemmRt {      // launch-time extras (not part of the C ABI struct)
 // site) disappears.  TF = 1: every wave computes the 16 T columns for half of its row fragments;
 // TF = 2: wave column wave_n computes T columns [16 wave_n, 16 wave_n + 16).
 //
-// LNF (TF = 1 only): the LayerNorm in front of this Linear is folded in (leco_gemm_args.ln_s).  A holds the RAW rows x, W is
-// bf16(gamma (.) W), and y = rstd (x W'^T - mean s) + c needs only the row statistics -- taken from operands that are
-// already in registers: sum x is column 15 of T (a row of ones in the stacked lora_down image), sum x^2 the diagonal of
-// one Gram MFMA mfma(a, a) per row fragment, on the same duty split as the fused down-projection.  T is corrected to
-// T / rstd = (T_raw - mean sd) + cd / rstd before the K-extension, so the low-rank term stays inside the one accumulator
-// that the epilogue then normalises.  Round 2 took the statistics from the PRODUCER's epilogue (atomics: slower).
-template <int BM, int BN, bool CONV, int NS, int NWM, int TF = 0, bool LNF = false>
+template <int BM, int BN, bool CONV, int NS, int NWM, int TF = 0>
 __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p, const GemmRt rt) {
-    static_assert(!LNF || TF == 1, "the LayerNorm fold rides on the 16-row fused down-projection");
     constexpr int NW = NWM * 2, NT = NW * 64;
     constexpr int WM = BM / NWM, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int BNT = BN + 16 * TF;                     // W tile rows including the fused lora_down rows
@@ -282,15 +275,12 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
 
     f32x4 acc[FM][FN];
     f32x4 acct[TFM ? TFM : 1];
-    f32x4 gram[(LNF && TFM) ? TFM : 1];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < (TFM ? TFM : 1); ++i) acct[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < ((LNF && TFM) ? TFM : 1); ++i) gram[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int t_i0 = TF == 1 ? wave_n * (FM / 2) : 0;          // first row fragment this wave projects
     const int t_row = BN + (TF == 2 ? wave_n * 16 : 0);        // W-tile row of its lora_down fragment
 
@@ -305,15 +295,7 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
     // The steady-state body (tile it+NS is a main tile) is one straight-line basic block -- no branches,
     // waitcnt immediates fixed per instantiation -- so the address arithmetic and the DMA issue interleave
     // with the MFMAs instead of forming a separate phase after the barrier.
-    // LNF: the correction vectors of this lane's four T columns (issued BEFORE the first DMA: older than everything the
-    // counted waits below cover)
-    f32x4 ln_sd4 = {0.f, 0.f, 0.f, 0.f}, ln_cd4 = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (LNF) {
-        ln_sd4 = *(const f32x4*)(p.ln_sd + 4 * (lane >> 4));
-        ln_cd4 = *(const f32x4*)(p.ln_cd + 4 * (lane >> 4));
-    }
     constexpr int LDS_RING = NS * (BM + BN + 16 * TF) * BK * 2;     // bytes of the ring = what the epilogue staging may reuse
-    float* lnst = (float*)(dyn_lds() + LDS_RING);                   // LNF: {mean, rstd} per tile row, behind both
 #pragma unroll
     for (int s0 = 0; s0 < NS; ++s0)
         if (s0 < nstage) stage(s0, s0);
@@ -352,7 +334,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
                 // dynamically indexed register array)
                 const bf16x8 a = (TF == 1 && wave_n) ? af[(TF == 1 ? FM / 2 : 0) + i] : af[i];
                 acct[i] = mfma16(wf[FN], a, acct[i]);
-                if constexpr (LNF) gram[i] = mfma16(a, a, gram[i]);     // D[r][r'] = sum_k x_r x_r': the diagonal is sum x^2
             }
         }
     };
@@ -433,28 +414,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
         bf16_t* sB = sA + BM * BK;
         bf16_t* tout = (bf16_t*)p.t_out;
         const int tcol = (TF == 2 ? wave_n * 16 : 0) + 4 * fg;
-        if constexpr (LNF) {
-            // row statistics of this wave's T-duty fragments: sum x = T column 15 (lanes fg = 3, element 3), sum x^2 = the Gram
-            // diagonal (row fr of the fragment: lane group fr >> 2, element fr & 3); T -> T / rstd; {mean, rstd} to LDS for the
-            // epilogue (every row of the tile is on exactly one wave's duty list)
-            const float invk = 1.f / (float)p.k;
-            const int rsel = fr & 3;
-#pragma unroll
-            for (int i = 0; i < TFM; ++i) {
-                const float sx = shfl(acct[i][3], 48 + fr);
-                const float dsel = rsel == 0 ? gram[i][0] : (rsel == 1 ? gram[i][1] : (rsel == 2 ? gram[i][2] : gram[i][3]));
-                const float ssq = shfl(dsel, ((fr >> 2) << 4) + fr);
-                const float mu = sx * invk;
-                const float sdev = sqrtf(fmaxf(ssq * invk - mu * mu, 0.f) + p.ln_eps);
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) acct[i][c4] = acct[i][c4] - mu * ln_sd4[c4] + ln_cd4[c4] * sdev;
-                if (fg == 0) {
-                    const int row = wave_m * WM + (t_i0 + i) * 16 + fr;
-                    lnst[2 * row] = mu;
-                    lnst[2 * row + 1] = 1.f / sdev;
-                }
-            }
-        }
 #pragma unroll
         for (int i = 0; i < TFM; ++i) {
             const int row = wave_m * WM + (t_i0 + i) * 16 + fr;
@@ -540,20 +499,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
                 const f32x4 g0 = *(const f32x4*)(sr + 64), g1 = *(const f32x4*)(sr + 68);
                 float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 float gt[8] = {g0[0], g0[1], g0[2], g0[3], g1[0], g1[1], g1[2], g1[3]};
-                if constexpr (LNF) {      // y = rstd (acc - mean s) + c, value and gate columns alike
-                    const float mu = lnst[2 * (h * RR + rl)], rs = lnst[2 * (h * RR + rl) + 1];
-                    const f32x4 s0 = *(const f32x4*)(p.ln_s + n), s1 = *(const f32x4*)(p.ln_s + n + 4);
-                    const f32x4 s2 = *(const f32x4*)(p.ln_s + n + 64), s3 = *(const f32x4*)(p.ln_s + n + 68);
-                    const f32x4 c0 = *(const f32x4*)(p.ln_c + n), c1 = *(const f32x4*)(p.ln_c + n + 4);
-                    const f32x4 c2 = *(const f32x4*)(p.ln_c + n + 64), c3 = *(const f32x4*)(p.ln_c + n + 68);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = rs * (v[r] - mu * s0[r]) + c0[r];
-                        v[4 + r] = rs * (v[4 + r] - mu * s1[r]) + c1[r];
-                        gt[r] = rs * (gt[r] - mu * s2[r]) + c2[r];
-                        gt[4 + r] = rs * (gt[4 + r] - mu * s3[r]) + c3[r];
-                    }
-                }
                 if (p.bias) {
                     const f32x4 a0 = *(const f32x4*)(p.bias + n), a1 = *(const f32x4*)(p.bias + n + 4);
                     const f32x4 b0 = *(const f32x4*)(p.bias + n + 64), b1 = *(const f32x4*)(p.bias + n + 68);
@@ -592,16 +537,6 @@ __global__ __launch_bounds__(NWM * 128) void gemm_kernel(const leco_gemm_args p,
                 *(f32x4*)(wsp + (int64_t)m * N + n) = v0;
                 *(f32x4*)(wsp + (int64_t)m * N + n + 4) = v1;
                 continue;
-            }
-            if constexpr (LNF) {      // y = rstd (acc - mean s) + c
-                const float mu = lnst[2 * (h * RR + rl)], rs = lnst[2 * (h * RR + rl) + 1];
-                const f32x4 s0 = *(const f32x4*)(p.ln_s + n), s1 = *(const f32x4*)(p.ln_s + n + 4);
-                const f32x4 c0 = *(const f32x4*)(p.ln_c + n), c1 = *(const f32x4*)(p.ln_c + n + 4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = rs * (v[r] - mu * s0[r]) + c0[r];
-                    v[4 + r] = rs * (v[4 + r] - mu * s1[r]) + c1[r];
-                }
             }
             if (p.bias) {
                 const f32x4 b0 = *(const f32x4*)(p.bias + n), b1 = *(const f32x4*)(p.bias + n + 4);
@@ -832,14 +767,14 @@ __global__ __launch_bounds__(256) void splitk_finish_stats_kernel(const leco_gem
 thread_local char* tl_describe = nullptr;
 thread_local int tl_describe_len = 0;
 
-template <int BM, int BN, bool CONV, int NS, int NWM, int TF, bool LNF = false>
+template <int BM, int BN, bool CONV, int NS, int NWM, int TF>
 void launch_k(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
-    constexpr int lds_bytes = NS * (BM + BN + 16 * TF) * BK * (int)sizeof(bf16_t) + (LNF ? BM * 8 : 0);
+    constexpr int lds_bytes = NS * (BM + BN + 16 * TF) * BK * (int)sizeof(bf16_t);
     static_assert(lds_bytes <= 160 * 1024, "LDS ring does not fit");
     if (tl_describe) {
         const int used = (int)strlen(tl_describe);
-        snprintf(tl_describe + used, tl_describe_len - used, "%sgemm_kernel<%d, %d, %s, %d, %d, %d, %s> grid=%u split=%d",
-                 used ? " ; " : "", BM, BN, CONV ? "true" : "false", NS, NWM, TF, LNF ? "true" : "false", grid.x, rt.split_k);
+        snprintf(tl_describe + used, tl_describe_len - used, "%sgemm_kernel<%d, %d, %s, %d, %d, %d> grid=%u split=%d",
+                 used ? " ; " : "", BM, BN, CONV ? "true" : "false", NS, NWM, TF, grid.x, rt.split_k);
         return;
     }
     // > 64 KB of dynamic LDS needs the opt-in attribute: once per instantiation AND device (the attribute lives on
@@ -848,11 +783,11 @@ void launch_k(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t 
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, NS, NWM, TF, LNF>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, CONV, NS, NWM, TF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, NS, NWM, TF, LNF>), grid, dim3(NWM * 128), lds_bytes, s, a, rt);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, CONV, NS, NWM, TF>), grid, dim3(NWM * 128), lds_bytes, s, a, rt);
 }
 // fused LoRA down-projection variants exist for plain operands only; the ring loses one slot where the
 // extra lora_down rows would not fit in 160 KB
@@ -860,7 +795,6 @@ template <int BM, int BN, bool CONV, int NS, int NWM>
 void launch_ns(const leco_gemm_args& a, const GemmRt& rt, dim3 grid, hipStream_t s) {
     if constexpr (!CONV) {
         constexpr int NS2 = (NS * (BM + BN + 32) * BK * 2 <= 156 * 1024) ? NS : NS - 1;
-        if (a.t_w && a.t_rows == 16 && a.ln_s) return launch_k<BM, BN, CONV, NS, NWM, 1, true>(a, rt, grid, s);
         if (a.t_w && a.t_rows == 16) return launch_k<BM, BN, CONV, NS, NWM, 1>(a, rt, grid, s);
         if (a.t_w) return launch_k<BM, BN, CONV, NS2, NWM, 2>(a, rt, grid, s);
     }
@@ -904,7 +838,7 @@ int launch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, int s
         if (a.a_mode == LECO_A_PLAIN) launch_one<BM, BN, false>(a, rt, grid, s, shape);
         else launch_one<BM, BN, true>(a, rt, grid, s, shape);
     }
-    if (split_k > 1 && !tl_describe && !a.no_finish) splitk_finish_launch(a, ws, split_k, s);
+    if (split_k > 1 && !tl_describe) splitk_finish_launch(a, ws, split_k, s);
     if (tl_describe) return 0;
     return check_launch("leco_gemm");
 }
@@ -926,9 +860,6 @@ int validate(const leco_gemm_args& a) {
             (a.t_out && a.ld_tout % 8))
             return fail(-EINVAL, "leco_gemm: t_w needs w_ext, ext_k == 32, t_rows in {16, 32}, 16-byte aligned strides");
     }
-    if (a.ln_s && (!a.ln_c || !a.ln_sd || !a.ln_cd || !a.t_w || a.t_rows != 16 || a.a_mode != LECO_A_PLAIN || a.a1 || a.bias || a.t_out))
-        return fail(-EINVAL, "leco_gemm: the LayerNorm fold needs ln_c / ln_sd / ln_cd, the 16-row fused down-projection (t_w), one plain "
-                             "A operand, no separate bias (folded into ln_c) and no t_out");
     if (a.rowbias && a.rows_per_group <= 0) return fail(-EINVAL, "leco_gemm: rowbias needs rows_per_group");
     if (a.col_stats && (!a.c || a.stats_rows <= 0 || a.stats_atom <= 0 || a.n % a.stats_atom || a.m % a.stats_rows ||
                         a.act == LECO_ACT_GEGLU))
@@ -988,7 +919,6 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         if (tile == 0) tile = 1;
         split_k = 1;
     }
-    if (args->ln_s) split_k = 1;         // the row statistics need the whole K range in one workgroup
     static const bool no_patch = getenv("LECO_NO_CONV_PATCH") != nullptr;      // A/B switch for measurements
     if (tile == 0 && (args->a_mode == LECO_A_CONV3_S1 || args->a_mode == LECO_A_CONV3_UP2) && !no_patch) {
         // 3x3 / stride-1 convolutions (plain or on the 2x upsampled input): the patch-staged kernel (conv_patch.hip) with the
@@ -1064,7 +994,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         // did not split at all and has written its finished output)
         const int nchunks = args->k / 9 / BK;
         const int eff = split_k < nchunks ? split_k : nchunks;
-        if (eff > 1 && !args->no_finish) splitk_finish_launch(*args, (const float*)workspace, eff, s);
+        if (eff > 1) splitk_finish_launch(*args, (const float*)workspace, eff, s);
         return check_launch("leco_gemm");
     }
     switch (tile) {

@@ -46,42 +46,9 @@ struct GnSrc {
     const bf16_t* x1;
     int64_t ld0, ld1;
     int c0;  // channels served by x0
-    // WS form (leco_groupnorm_fwd_splitk): the input is the UNFINISHED output of a split-K convolution -- `splits` fp32
-    // partial slabs ws[split][rows][C] + bias[C] + rowbias[sample][C] (the time-embedding bias of ResnetBlock2D.conv1)
-    const float* ws;
-    int splits;
-    int64_t slab;            // rows * C
-    const float* bias;
-    const float* rowbias;
-    int64_t ld_rowbias;
 };
-template <bool WS>
-__device__ __forceinline__ u32x4 gn_load(const GnSrc& s, int64_t row, int c, int b) {
-    if constexpr (WS) {
-        // exactly splitk_finish_kernel's arithmetic (gemm.hip): slabs in order, + bias, + row bias, bf16 rounding -- the
-        // tensor the unfused pair (finish launch, GroupNorm launch) would have passed through memory
-        const float* p = s.ws + row * (int64_t)s.c0 + c;
-        f32x4 a0 = *(const f32x4*)p, a1 = *(const f32x4*)(p + 4);
-        for (int sp = 1; sp < s.splits; ++sp) {
-            const f32x4 b0 = *(const f32x4*)(p + sp * s.slab), b1 = *(const f32x4*)(p + sp * s.slab + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a0[i] += b0[i]; a1[i] += b1[i]; }
-        }
-        if (s.bias) {
-            const f32x4 b0 = *(const f32x4*)(s.bias + c), b1 = *(const f32x4*)(s.bias + c + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a0[i] += b0[i]; a1[i] += b1[i]; }
-        }
-        if (s.rowbias) {
-            const float* rb = s.rowbias + (int64_t)b * s.ld_rowbias + c;
-            const f32x4 b0 = *(const f32x4*)rb, b1 = *(const f32x4*)(rb + 4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a0[i] += b0[i]; a1[i] += b1[i]; }
-        }
-        return u32x4{pack_bf2(a0[0], a0[1]), pack_bf2(a0[2], a0[3]), pack_bf2(a1[0], a1[1]), pack_bf2(a1[2], a1[3])};
-    } else {
-        return c < s.c0 ? *(const u32x4*)(s.x0 + row * s.ld0 + c) : *(const u32x4*)(s.x1 + row * s.ld1 + (c - s.c0));
-    }
+__device__ __forceinline__ u32x4 gn_load(const GnSrc& s, int64_t row, int c) {
+    return c < s.c0 ? *(const u32x4*)(s.x0 + row * s.ld0 + c) : *(const u32x4*)(s.x1 + row * s.ld1 + (c - s.c0));
 }
 
 constexpr int GN_MAX_GROUPS = 32;
@@ -99,7 +66,7 @@ constexpr int GN_MAX_WAVES = 16;     // 1024 threads
 // NVR > 0 (forward only): every thread owns at most NVR pixels of its channel vector and KEEPS them in registers between
 // the two passes -- one trip to memory instead of two (the launches are latency-, not bandwidth-bound: 8 - 16 us each, 45
 // of them per UNet pass).
-template <int MODE, int NVR = 0, bool WS = false>
+template <int MODE, int NVR = 0>
 __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t* dy, int64_t lddy,
                                                          const float* fstats, float* stats_out,
                                                          const float* gamma, const float* beta, int act,
@@ -146,7 +113,7 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
 #pragma unroll
         for (int j = 0; j < NVR; ++j) {
             const int p = pl + j * PL;
-            keep[j] = gn_load<WS>(src, (int64_t)b * hw + (p < hw ? p : 0), c, b);      // (pl itself may lie beyond a small sample)
+            keep[j] = gn_load(src, (int64_t)b * hw + (p < hw ? p : 0), c);      // (pl itself may lie beyond a small sample)
         }
 #pragma unroll
         for (int j = 0; j < NVR; ++j) {
@@ -164,7 +131,7 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
             for (int u = 0; u < 4; ++u) {
                 const int p = p0 + u * PL;
                 const int64_t row = (int64_t)b * hw + (p < hw ? p : p0);
-                xv[u] = gn_load<WS>(src, row, c, b);
+                xv[u] = gn_load(src, row, c);
                 if (MODE == 1) dv[u] = *(const u32x4*)(dy + row * lddy + c);
             }
 #pragma unroll
@@ -260,7 +227,7 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
         for (int u = 0; u < 4; ++u) {
             const int p = p0 + u * PL;
             const int64_t row = (int64_t)b * hw + (p < hw ? p : p0);
-            xv[u] = gn_load<WS>(src, row, c, b);
+            xv[u] = gn_load(src, row, c);
             if (MODE == 1) dv[u] = *(const u32x4*)(dy + row * lddy + c);
         }
 #pragma unroll
@@ -335,7 +302,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(GnSrc src, const bf16_t* 
             for (int p = p0 + r; p < p1; p += rows_par) {
                 const int64_t row = (int64_t)b * hw + p;
                 float x[8];
-                unpack8(gn_load<false>(src, row, c, 0), x);
+                unpack8(gn_load(src, row, c), x);
                 if (MODE == 0) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { s1[i] += x[i]; s2[i] += x[i] * x[i]; }
@@ -403,7 +370,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc src, const bf16_t* 
         const int c = (e - row * nvec) * 8;
         const int b = row / hw;
         float x[8], o[8], d[8], ga[8], be[8];
-        unpack8(gn_load<false>(src, row, c, 0), x);
+        unpack8(gn_load(src, row, c), x);
         if (MODE == 1) unpack8(*(const u32x4*)(dy + (int64_t)row * lddy + c), d);
         {
             f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
@@ -476,7 +443,7 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int p = p0 + rl_f + u * rows_par_f;
-            pre[u] = gn_load<false>(src, (int64_t)b * hw + (p < p1 ? p : p0 + rl_f), c_f, 0);
+            pre[u] = gn_load(src, (int64_t)b * hw + (p < p1 ? p : p0 + rl_f), c_f);
         }
         pg0 = *(const f32x4*)(gamma + c_f); pg1 = *(const f32x4*)(gamma + c_f + 4);
         pb0 = *(const f32x4*)(beta + c_f); pb1 = *(const f32x4*)(beta + c_f + 4);
@@ -536,7 +503,7 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = pr + u * rows_par;
-                xv[u] = first ? pre[u] : gn_load<false>(src, (int64_t)b * hw + (p < p1 ? p : pr), c, 0);
+                xv[u] = first ? pre[u] : gn_load(src, (int64_t)b * hw + (p < p1 ? p : pr), c);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -806,25 +773,25 @@ bool gn_use_block_kernel(const GnGeom& ge, int batch, int hw, int C, int G) {
     const int blocks = batch * (G / ge.gpb);
     return !(slice_bytes > 200 * 1024 && blocks < 96);
 }
-template <int MODE, int NVR, bool WS = false>
+template <int MODE, int NVR>
 void gn_launch_v(const GnGeom& ge, dim3 grid, hipStream_t s, GnSrc src, const bf16_t* dy, int64_t lddy,
                  const float* fstats, float* stats_out, const float* gamma, const float* beta, int act, float eps,
                  int hw, int C, int G, bf16_t* out, int64_t ldo) {
-    hipLaunchKernelGGL((gn_block_kernel<MODE, NVR, WS>), grid, dim3(ge.threads), ge.lds, s, src, dy, lddy, fstats, stats_out,
+    hipLaunchKernelGGL((gn_block_kernel<MODE, NVR>), grid, dim3(ge.threads), ge.lds, s, src, dy, lddy, fstats, stats_out,
                        gamma, beta, act, eps, hw, C, G, ge.gpb, out, ldo);
 }
-template <int MODE, bool WS = false>
+template <int MODE>
 void gn_launch(const GnGeom& ge, dim3 grid, hipStream_t s, GnSrc src, const bf16_t* dy, int64_t lddy,
                const float* fstats, float* stats_out, const float* gamma, const float* beta, int act, float eps,
                int hw, int C, int G, bf16_t* out, int64_t ldo) {
     if (MODE == 0) {      // forward: pixels per thread -> the register-resident instantiation that holds them (else two passes)
         const int nv = ge.gpb * (C / G) / 8, PL = ge.threads / nv, per = (hw + PL - 1) / PL;
         static const bool off = [] { const char* e = getenv("LECO_GN_REGS"); return e && atoi(e) == 0; }();
-        if (!off && per <= 2) return gn_launch_v<0, 2, WS>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
-        if (!off && per <= 6) return gn_launch_v<0, 6, WS>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
-        if (!off && per <= 16) return gn_launch_v<0, 16, WS>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+        if (!off && per <= 2) return gn_launch_v<0, 2>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+        if (!off && per <= 6) return gn_launch_v<0, 6>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+        if (!off && per <= 16) return gn_launch_v<0, 16>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
     }
-    return gn_launch_v<MODE, 0, WS>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+    return gn_launch_v<MODE, 0>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
 }
 }  // namespace
 }  // namespace leco
@@ -866,33 +833,6 @@ extern "C" int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, i
 extern "C" int leco_groupnorm_single_launch(int32_t batch, int32_t hw, int32_t c, int32_t groups) {
     if (groups <= 0 || c % groups) return 1;
     return gn_use_block_kernel(gn_geom(hw, c, groups), batch, hw, c, groups) ? 1 : 0;
-}
-/* 1: for this tensor the producer-statistics form (leco_gemm_args.col_stats / leco_colstats + leco_groupnorm_apply_stats: a
- * pixel-parallel ONE-pass apply on the whole chip) is the faster GroupNorm: every shape that would take three launches, and
- * (round 6, profiles/r06_bench_norm.txt) the 32^2-and-larger levels whose (sample, group run) blocks cover at most half of
- * the 256 CUs -- 14.6 vs 7.1 us at B = 4, HW = 1024, C = 640 (64 blocks), 13.6 vs 5.5 us at C = 320 (32 blocks). */
-extern "C" int leco_groupnorm_prefers_stats(int32_t batch, int32_t hw, int32_t c, int32_t groups) {
-    if (groups <= 0 || c % groups) return 0;
-    const GnGeom ge = gn_geom(hw, c, groups);
-    if (!gn_use_block_kernel(ge, batch, hw, c, groups)) return 1;
-    return (hw >= 1024 && batch * (groups / ge.gpb) <= 128) ? 1 : 0;
-}
-extern "C" int leco_groupnorm_fwd_splitk(const float* ws, int32_t splits, const float* bias, const float* rowbias,
-                                         int64_t ld_rowbias, const float* gamma, const float* beta, int32_t batch, int32_t hw,
-                                         int32_t c, int32_t groups, float eps, int32_t act, float* stats, void* y, int64_t ldy,
-                                         leco_stream_t stream) {
-    int rc = gn_check(c, groups, 0, nullptr);
-    if (rc) return rc;
-    if (!ws || splits < 1 || !y || !stats || (rowbias && ld_rowbias % 4))
-        return fail(-EINVAL, "leco_groupnorm_fwd_splitk: ws / splits=%d / y / stats (rowbias stride %% 4 == 0)", splits);
-    const GnGeom ge = gn_geom(hw, c, groups);
-    if (!gn_use_block_kernel(ge, batch, hw, c, groups))
-        return fail(-EINVAL, "leco_groupnorm_fwd_splitk: B=%d hw=%d C=%d is not a one-launch GroupNorm shape "
-                    "(leco_groupnorm_single_launch)", batch, hw, c);
-    GnSrc src{nullptr, nullptr, 0, 0, c, ws, splits, (int64_t)batch * hw * c, bias, rowbias, ld_rowbias};
-    gn_launch<0, true>(ge, dim3(groups / ge.gpb, batch), (hipStream_t)stream, src, (const bf16_t*)nullptr, (int64_t)0,
-                       (const float*)nullptr, stats, gamma, beta, act, eps, hw, c, groups, (bf16_t*)y, ldy);
-    return check_launch("leco_groupnorm_fwd_splitk");
 }
 extern "C" int leco_groupnorm_apply_stats(const void* x0, int64_t ld0, const void* x1, int64_t ld1, int32_t c0,
                                           const float* cstats0, const float* cstats1, int32_t atom, const float* gamma,

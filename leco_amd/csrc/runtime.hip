@@ -41,54 +41,3 @@ extern "C" int leco_graph_destroy(leco_graph_t graph) {
     if (graph) (void)hipGraphExecDestroy((hipGraphExec_t)graph);
     return 0;
 }
-
-// ---- two-stream sections (leco_hip.h): one side stream per device + a ring of timing-less events
-namespace {
-constexpr int MAX_DEV = 64, NEV = 256;
-hipStream_t g_side[MAX_DEV] = {};
-hipEvent_t g_ev[MAX_DEV][NEV] = {};
-int g_ev_next[MAX_DEV] = {};
-int cur_dev() {
-    int d = 0;
-    (void)hipGetDevice(&d);
-    return d < 0 || d >= MAX_DEV ? 0 : d;
-}
-// stream + event ring are created together on first use (leco_side_stream() before a capture begins: resource creation
-// is not a capturable operation)
-hipStream_t side_of(int d) {
-    if (!g_side[d]) {
-        if (hipStreamCreateWithFlags(&g_side[d], hipStreamNonBlocking) != hipSuccess) { g_side[d] = nullptr; return nullptr; }
-        for (int i = 0; i < NEV; ++i)
-            if (hipEventCreateWithFlags(&g_ev[d][i], hipEventDisableTiming) != hipSuccess) g_ev[d][i] = nullptr;
-    }
-    return g_side[d];
-}
-// an event of the ring: a record / wait pair is enqueued back to back, so re-use after NEV pairs is safe
-hipEvent_t next_event(int d) {
-    const int i = g_ev_next[d];
-    g_ev_next[d] = (i + 1) % NEV;
-    return g_ev[d][i];
-}
-int edge(hipStream_t from, hipStream_t to, const char* what) {
-    const int d = cur_dev();
-    (void)side_of(d);
-    hipEvent_t ev = next_event(d);
-    if (!ev) return fail(-EIO, "%s: hipEventCreate failed", what);
-    hipError_t e = hipEventRecord(ev, from);
-    if (e == hipSuccess) e = hipStreamWaitEvent(to, ev, 0);
-    if (e != hipSuccess) return fail(-EIO, "%s: %s", what, hipGetErrorString(e));
-    return 0;
-}
-}  // namespace
-
-extern "C" leco_stream_t leco_side_stream(void) { return (leco_stream_t)side_of(cur_dev()); }
-extern "C" int leco_fork(leco_stream_t stream) {
-    hipStream_t side = side_of(cur_dev());
-    if (!side) return fail(-EIO, "leco_fork: cannot create the side stream");
-    return edge((hipStream_t)stream, side, "leco_fork");
-}
-extern "C" int leco_join(leco_stream_t stream) {
-    hipStream_t side = side_of(cur_dev());
-    if (!side) return fail(-EIO, "leco_join: no side stream");
-    return edge(side, (hipStream_t)stream, "leco_join");
-}

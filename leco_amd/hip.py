@@ -35,8 +35,7 @@ class GemmArgs(C.Structure):
         ("act", C.c_int32),
         ("c", C.c_void_p), ("ldc", C.c_int64), ("c_f32", C.c_void_p), ("ldc32", C.c_int64),
         ("t_w", C.c_void_p), ("ld_tw", C.c_int64), ("t_rows", C.c_int32), ("t_out", C.c_void_p), ("ld_tout", C.c_int64),
-        ("col_stats", C.c_void_p), ("stats_rows", C.c_int32), ("stats_atom", C.c_int32), ("no_finish", C.c_int32),
-        ("ln_s", C.c_void_p), ("ln_c", C.c_void_p), ("ln_sd", C.c_void_p), ("ln_cd", C.c_void_p), ("ln_eps", C.c_float),
+        ("col_stats", C.c_void_p), ("stats_rows", C.c_int32), ("stats_atom", C.c_int32),
     ]
 
 
@@ -48,11 +47,6 @@ class LoraSite(C.Structure):
         ("dn_s", C.c_void_p), ("up_p", C.c_void_p), ("up_t", C.c_void_p), ("dn_p", C.c_void_p),
         ("up_pg", C.c_void_p), ("rp", C.c_int32),
     ]
-
-
-class LnFoldSite(C.Structure):       # mirrors `leco_lnfold_site`
-    _fields_ = [("dn_s", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("dn_ln", C.c_void_p), ("sd", C.c_void_p),
-                ("cd", C.c_void_p), ("k", C.c_int32)]
 
 
 class WgradProblem(C.Structure):     # mirrors `leco_wgrad_problem` in include/leco_hip.h

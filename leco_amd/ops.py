@@ -22,7 +22,6 @@ _SIGS = {
     "leco_groupnorm_fwd": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
     "leco_groupnorm_bwd": [_vp, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
     "leco_groupnorm_apply_stats": [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
-    "leco_groupnorm_fwd_splitk": [_vp, _i32, _vp, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _i64, _vp],
     "leco_colstats": [_vp, _i64, _vp, _i32, _i32, _i32, _i32, _vp],
     "leco_layernorm_fwd": [_vp, _i64, _vp, _vp, _f32, _i32, _i32, _vp, _i64, _vp, _vp, _vp],
     "leco_layernorm_bwd": [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp],
@@ -51,9 +50,7 @@ _SIGS = {
     "leco_repeat": [_vp, _vp, _i64, _i32, _vp],
     "leco_step_begin": [_vp, _vp, _i32, _f32, _i64, _vp, _vp],
     "leco_step_mid": [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _i32, _vp],
-    "leco_fork": [_vp], "leco_join": [_vp],
     "leco_lora_pack": [_vp, _i32, _vp],
-    "leco_lnfold_pack": [_vp, _i32, _vp],
     "leco_lora_wgrad_conv": [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _i32, _i32, _i32, _i32, _i32,
                              _i32, _i32, _vp, _i64, _vp],
     "leco_rowgroup_sum": [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _vp],
@@ -113,25 +110,12 @@ def _fn(name: str):
     return f
 
 
-_STREAM_OPS = ("leco_fork", "leco_join")     # two-stream sections of a launch list (leco_hip.h); no-ops on the host emulator
-
-
-def _noop(*_a):
-    return 0
-
-
 class Op:
-    """One enqueue-only C-ABI call: ``fn(*args, stream)``.  ``side``: the launch belongs to a forked section (between a
-    ``leco_fork`` and a ``leco_join`` op of the list) and is handed the library's side stream instead of ``stream``."""
-    __slots__ = ("name", "fn", "args", "keep", "tag", "side")
+    """One enqueue-only C-ABI call: ``fn(*args, stream)``."""
+    __slots__ = ("name", "fn", "args", "keep", "tag")
 
     def __init__(self, name: str, args: tuple, keep=None):
         self.tag = None   # plan builders label ops (e.g. "ctx": depends only on the prompt embeddings)
-        self.side = False
-        if name in _STREAM_OPS:
-            self.name, self.args, self.keep = name, args, keep
-            self.fn = _noop if hip.is_emulated() else _fn(name)
-            return
         if _f32_active:
             if name in _F32_TWINS:
                 name = "leco_f32_" + name[len("leco_"):]
@@ -170,24 +154,12 @@ def _describe_op(op) -> str:
         return ""
 
 
-def side_stream():
-    """Handle of the library's side stream (None on the host emulator: forked launches then run in list order)."""
-    if hip.is_emulated() or not torch.cuda.is_available():
-        return None
-    f = hip.lib().leco_side_stream
-    f.restype = C.c_void_p
-    f.argtypes = []
-    return f()
-
-
 def run_plan(plan: Sequence[Op], stream=None) -> None:
     if stream is None:
         stream = default_stream()
     if _TRACE_OPS:       # LECO_TRACE_OPS=1: name every launch on stderr before it goes out and wait for it (a GPU memory
         import sys        # fault kills the process without a Python error: the last name printed is the faulting launch)
         for op in plan:
-            if op.name in _STREAM_OPS:
-                continue
             print(f"[leco op] {op.name} {_describe_op(op)}", file=sys.stderr, flush=True)
             rc = op.fn(*op.args, stream)
             if rc != 0:
@@ -195,16 +167,8 @@ def run_plan(plan: Sequence[Op], stream=None) -> None:
             if torch.cuda.is_available() and not hip.is_emulated():
                 torch.cuda.synchronize()
         return
-    side = None
     for op in plan:
-        s = stream
-        if op.side and stream is not None:
-            if side is None:
-                side = side_stream()
-            s = side
-        elif stream is None and op.name in _STREAM_OPS:
-            continue
-        rc = op.fn(*op.args, s)
+        rc = op.fn(*op.args, stream)
         if rc != 0:
             hip.check(rc, op.name)
 
@@ -352,10 +316,6 @@ def step_mid(src: torch.Tensor, dst_a: Optional[torch.Tensor], dst_b: Optional[t
     return Op("leco_step_mid", (ptr(src), ptr(dst_a), ptr(dst_b), nbytes, reps_b, float(t_cur), ta, tb,
                                 None if plan_a is None else ptr(plan_a.t_idx), None if plan_b is None else ptr(plan_b.t_idx), slot),
               keep=(src, dst_a, dst_b))
-
-
-def lnfold_pack(sites_dev: torch.Tensor, nsites: int) -> Op:
-    return Op("leco_lnfold_pack", (ptr(sites_dev), nsites), keep=(sites_dev,))
 
 
 def lora_pack(sites_dev: torch.Tensor, nsites: int) -> Op:

@@ -166,12 +166,6 @@ class FusedStep:
         # ancestral schedulers (ddpm / euler_a): `noise_fn(i, numel)` supplies the noise of denoising pass i (a replayable
         # stream for parity tests); None = fresh device-RNG noise, like diffusers' randn_tensor on the UNet's device
         self.noise_fn = None
-        # LECO_OVERLAP_FROZEN=1: the batched LoRA-off pass (train_lora.py:202-237) and the LoRA-on target pass (:244-256)
-        # both depend only on the denoised latents; run them on two streams (the frozen plan then owns a split-K
-        # workspace, the only mutable buffer plans share).  Default off: see DESIGN.md section 8.1.
-        self.overlap = (os.environ.get("LECO_OVERLAP_FROZEN", "0") not in ("", "0") and dev.type == "cuda"
-                        and torch.cuda.is_available())
-        self._side = torch.cuda.Stream(device=dev) if self.overlap else None
         self._pin = {}          # (numel, dtype) -> ring of pinned host staging buffers (`_h2d`)
         # De-duplicated step (SURVEY 7.1 step 5 / 8(d) `W_min`): the reference evaluates the three frozen predictions and the
         # target prediction through predict_noise at guidance_scale = 1 (train_lora.py:202-256), i.e. it runs the
@@ -182,6 +176,7 @@ class FusedStep:
         # unless `--strict_reference` (or LECO_DEDUP=0); this class, bench.py's headline and the parity tests default to the
         # reference-faithful pass structure.  May be flipped between steps: both plan sets are built on demand.
         self.dedup = bool(dedup)
+        self.target_from_forward_only = False      # test hook, see `step`
         self._token = next(FusedStep._tokens)      # names this object's private launch lists on plans the engine shares by shape
 
     # ---- host -> device copies that do not stall the host -------------------------------------------------------
@@ -292,7 +287,7 @@ class FusedStep:
         if "plan" not in st:
             bs, h, w = st["bs"], st["h"], st["w"]
             plan = self.unet.prepare((2 * bs, 4, h, w), lora_on=True)
-            fplan = self.unet.engine().plan(6 * bs, h, w, need_bwd=False, ws_slot=1 if self.overlap else 0, share=6)
+            fplan = self.unet.engine().plan(6 * bs, h, w, need_bwd=False, share=6)
             st.update(plan=plan, fplan=fplan,
                       preds={n: fplan.pred[2 * bs * i:2 * bs * (i + 1)] for i, n in enumerate(("positive", "neutral", "unconditional"))})
             st["owned"] += [plan.key, fplan.key]
@@ -306,7 +301,7 @@ class FusedStep:
             st["plan_d"] = self.unet.prepare((bs, 4, h, w), lora_on=True, tag="dedup")
             st["owned"].append(st["plan_d"].key)
         if U not in st["fplan_d"]:
-            fp = self.unet.engine().plan(U * bs, h, w, need_bwd=False, ws_slot=1 if self.overlap else 0, share=U, tag="dedup")
+            fp = self.unet.engine().plan(U * bs, h, w, need_bwd=False, share=U, tag="dedup")
             st["fplan_d"][U] = fp
             st["owned"].append(fp.key)
         return st["plan_d"], st["fplan_d"][U]
@@ -460,23 +455,20 @@ class FusedStep:
             fplan.time_ids.copy_(ids.repeat(nrep * pb, 1).reshape(-1))
             fplan.text_embeds.copy_(torch.cat([self._pooled(pair, w_, bs) for w_ in ("positive", "neutral", "unconditional")])
                                     if dd is None else dd["pooled"])
-        if self.overlap:      # inputs of both passes are in place: fork
-            self._set_ctx(plan, ctx_t)
-            cur = torch.cuda.current_stream()
-            self._side.wait_stream(cur)
-            with torch.cuda.stream(self._side):
-                self._run(fplan, "fwd_off")
-        else:
-            self._run(fplan, "fwd_off")
+        self._run(fplan, "fwd_off")
         trace.pop()
         # 3. target prediction with LoRA on; activations stay resident for the backward
         trace.push("target forward")
         net.multiplier = 1.0
-        if not self.overlap:
-            self._set_ctx(plan, ctx_t)
+        self._set_ctx(plan, ctx_t)
         self._run(plan, "fwd_on")
-        if self.overlap:
-            torch.cuda.current_stream().wait_stream(self._side)      # join before the loss reads the frozen predictions
+        if self.target_from_forward_only and dd is None:
+            # parity experiment (tests/test_fullsize.py): the VALUE of the target prediction comes from the forward-only plan --
+            # the arithmetic of the frozen predictions it is subtracted from (stripe kernels, fused GEGLU, shared prefix) --
+            # while the backward still runs on the training plan's activations
+            ops.step_mid(plan.x_in, dplan.x_in, None, 0, float(t_cur), dplan, None, self.single_slot).run()
+            self._run(dplan, "fwd_on")
+            plan.pred.copy_(dplan.pred)
         trace.pop()
         # 4. ESD objective + gradient w.r.t. the raw target prediction
         trace.push("loss + backward")

@@ -241,7 +241,7 @@ class UNetOutput:
 class TRef:
     """A row-major [rows][cols] activation view (row stride ``ld``; bf16, or fp32 in the fp32 compute mode) inside a
     device buffer."""
-    __slots__ = ("t", "ptr", "ld", "rows", "cols", "rg", "gparts", "name", "cstats", "pend")
+    __slots__ = ("t", "ptr", "ld", "rows", "cols", "rg", "gparts", "name", "cstats")
 
     def __init__(self, t: torch.Tensor, rows: int, cols: int, ld: Optional[int] = None, offset: int = 0,
                  rg: bool = False, name: str = ""):
@@ -253,7 +253,6 @@ class TRef:
         self.gparts: List["TRef"] = []
         self.name = name
         self.cstats: Optional[int] = None   # device address of fp32 [B][cols][2] {sum, sumsq} left by the producer, or None
-        self.pend: Optional[dict] = None    # the tensor only exists as UNFINISHED split-K slabs (gemm_fwd(defer_finish=True))
 
     def cols_view(self, c0: int, c1: int) -> "TRef":
         v = TRef(self.t, self.rows, c1 - c0, self.ld, 0, self.rg, self.name)
@@ -352,26 +351,6 @@ class GemmSite:
 # =============================================================================================
 # the engine
 # =============================================================================================
-class LnFoldState:
-    """Pack-time operands of `leco_gemm_args.ln_s` for one (Linear, preceding LayerNorm) pair: W' = bf16(gamma (.) W),
-    s[n] = sum_k W'[n][k] (of the ROUNDED weights: what the MFMA multiplies), c[n] = sum_k beta[k] W[n][k] + bias[n]; the
-    stacked lora_down image dn_ln / sd / cd is (re)built on the device by `leco_lnfold_pack`."""
-
-    def __init__(self, eng: "Engine", site: "GemmSite", norm_name: str, geglu: bool):
-        gamma, beta = eng.norm_p[norm_name]
-        w, b = site.w_geglu if geglu else (site.w, site.bias)
-        self.lora, self.k = site.lora, site.k
-        self.gamma, self.beta = gamma, beta
-        self.w = (w.float() * gamma[None, :]).to(bf16).contiguous()
-        self.s = self.w.float().sum(1).contiguous()
-        c = w.float() @ beta
-        self.c = (c + b.float() if b is not None else c).contiguous()
-        dev = w.device
-        self.dn_ln = torch.zeros(16, site.k, dtype=bf16, device=dev)
-        self.sd = torch.zeros(16, dtype=torch.float32, device=dev)
-        self.cd = torch.zeros(16, dtype=torch.float32, device=dev)
-
-
 class Plan:
     def __init__(self):
         # named launch lists; callers may add their own (e.g. the fused denoising pass)
@@ -549,30 +528,7 @@ class Engine:
             self._pack_scale = multiplier
         with ops.f32_mode(self.f32):
             ops.lora_pack(self._pack_dev, len(self.lora_sites)).run()
-        self.lnfold_repack()
         net._packed_version = net.version
-
-    # ---- LayerNorm folded into its consuming Linear (leco_gemm_args.ln_s; forward-only LoRA-on passes) ---------------
-    def lnfold_state(self, site: "GemmSite", norm_name: str, geglu: bool) -> "LnFoldState":
-        """Operands of the fold for (Linear site, the LayerNorm in front of it): built once, the LoRA half re-packed with
-        every `refresh_lora`."""
-        reg = self.__dict__.setdefault("_lnf", {})
-        key = (site.name, norm_name, geglu)
-        if key not in reg:
-            reg[key] = LnFoldState(self, site, norm_name, geglu)
-            tab = (hip.LnFoldSite * len(reg))()
-            for i, st in enumerate(reg.values()):
-                tab[i].dn_s, tab[i].gamma, tab[i].beta = st.lora.dn_s.data_ptr(), st.gamma.data_ptr(), st.beta.data_ptr()
-                tab[i].dn_ln, tab[i].sd, tab[i].cd, tab[i].k = st.dn_ln.data_ptr(), st.sd.data_ptr(), st.cd.data_ptr(), st.k
-            self._lnf_host = tab
-            self._lnf_dev = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
-            self.lnfold_repack()         # the new entry is valid at once (plans may be built between two re-packs)
-        return reg[key]
-
-    def lnfold_repack(self) -> None:
-        reg = self.__dict__.get("_lnf")
-        if reg:
-            ops.lnfold_pack(self._lnf_dev, len(reg)).run()
 
     # ---- plan construction ---------------------------------------------------------------------
     def plan(self, B: int, h: int, w: int, need_bwd: bool = True, ws_slot: int = 0, share: int = 1, tag: Optional[str] = None) -> Plan:
@@ -591,10 +547,8 @@ class Engine:
             key = key + ("tag", tag)      # with the faithful plans of another resident (bs, h, w) bucket, and buckets are evicted alone)
         if key not in self.plans:
             with ops.f32_mode(self.f32):
-                # (the side workspace of forked sections is allocated by `PlanBuilder.forked()` on first use: 128 MB that
-                # training plans and LECO_FORK=0 -- the default -- never touch)
                 self.plans[key] = PlanBuilder(self, B, h, w, need_bwd, ws=self.workspace_slot(ws_slot), share=share,
-                                              ws_side_slot=ws_slot + 2).build()
+                                              ).build()
                 self.plans[key].key = key
         return self.plans[key]
 
@@ -631,10 +585,9 @@ class Engine:
 
 class PlanBuilder:
     def __init__(self, eng: Engine, B: int, h: int, w: int, need_bwd: bool = True, ws: Optional[torch.Tensor] = None,
-                 share: int = 1, ws_side_slot: int = 2):
+                 share: int = 1):
         self.eng, self.cfg, self.dev = eng, eng.cfg, eng.device
         self.share = share
-        self._ws_side_slot = ws_side_slot                      # split-K slabs of the launches of forked sections (lazily allocated)
         self.Bfull = B          # (self.B is lowered to B / share while the batch-shared prefix is built)
         self.ws = eng.workspace if ws is None else ws      # split-K slabs of this plan's launches
         self.B, self.h, self.w = B, h, w
@@ -683,41 +636,13 @@ class PlanBuilder:
         self.f_on.append(op)
         self.f_off.append(op)
 
-    # ---- two-stream sections (leco_hip.h: leco_fork / leco_join): launches built inside `with self.forked():` go to the
-    # library's side stream and use their own split-K workspace; the caller emits the join before the first consumer
-    def fork_ok(self) -> bool:
-        import os
-        # default OFF: measured step-neutral on MI355X / ROCm 7.2 (227.8 vs 228.2 ms per step, profiles/r04_fork_join.txt) --
-        # a replayed hipGraph does not overlap the two branches enough to pay for the extra edges
-        return not self.need_bwd and not self.eng.f32 and os.environ.get("LECO_FORK", "0") not in ("", "0")
-
-    @contextlib.contextmanager
-    def forked(self):
-        n_on, n_off = len(self.f_on), len(self.f_off)
-        self.both(ops.Op("leco_fork", ()))
-        ws_main, self.ws = self.ws, self.eng.workspace_slot(self._ws_side_slot)
-        try:
-            yield
-        finally:
-            self.ws = ws_main
-            for lst, n0 in ((self.f_on, n_on + 1), (self.f_off, n_off + 1)):
-                for op in lst[n0:]:
-                    op.side = True
-
-    def join(self):
-        self.both(ops.Op("leco_join", ()))
-
     def stat_slice(self, cols: int, hw: int, batch: Optional[int] = None) -> Optional[int]:
         """Device address of a fresh [B][cols / atom][2] slice of the statistics arena (None when the fusion is off or does
         not pay for a tensor of this shape)."""
         B = self.B if batch is None else batch
         if not self.gn_fused or cols % self.stat_atom:
             return None
-        # auto: where the one-pass apply on producer statistics is the faster GroupNorm (leco_groupnorm_prefers_stats);
-        # auto3: the round-3..5 rule (only the shapes that would otherwise take three launches), kept for A/B runs
-        if self.gn_mode == "auto" and not hip.lib().leco_groupnorm_prefers_stats(B, hw, cols, self.cfg.norm_num_groups):
-            return None
-        if self.gn_mode == "auto3" and hip.lib().leco_groupnorm_single_launch(B, hw, cols, self.cfg.norm_num_groups):
+        if self.gn_mode == "auto" and hip.lib().leco_groupnorm_single_launch(B, hw, cols, self.cfg.norm_num_groups):
             return None
         n = 2 * B * (cols // self.stat_atom)
         assert self.stat_used + n <= self.stat_arena.numel(), "GroupNorm statistics arena too small"
@@ -748,11 +673,7 @@ class PlanBuilder:
     def gemm_fwd(self, site: GemmSite, x: Union[TRef, Tuple[TRef, TRef]], name: str, *, conv=None, amode=A_PLAIN,
                  rows: int, residual: Optional[TRef] = None, rowbias=None, rows_per_group=0, ld_rowbias=0,
                  act=ACT_NONE, out: Optional[TRef] = None, out_f32: Optional[torch.Tensor] = None,
-                 bias="site", ldc32_override: int = 0, geglu: bool = False, stats_hw: int = 0,
-                 defer_finish: bool = False) -> TRef:
-        """``defer_finish`` (forward-only plans, no LoRA on the site): if the launch shape splits K, leave the fp32 partial
-        slabs in the workspace and hand their description to the consumer in ``y.pend`` instead of running the finishing
-        pass -- the caller guarantees that the ONLY reader of y is a `groupnorm(..., pend=y.pend)` emitted right behind."""
+                 bias="site", ldc32_override: int = 0, geglu: bool = False, stats_hw: int = 0) -> TRef:
         if geglu:
             return self._gemm_fwd_geglu(site, x, name, rows)
         xs = x if isinstance(x, tuple) else (x,)
@@ -779,12 +700,6 @@ class PlanBuilder:
         yptr = y.ptr if y is not None else None
         ldc = y.ld if y is not None else site.n
         g_off = gemm_args(a0, site.w, yptr, lda=lda0, ldc=ldc, **common)
-        if defer_finish and lora is None and y is not None and y.cstats is None and residual is None and act == ACT_NONE:
-            y.pend = self._deferred_splitk(g_off, (site, xs, y), bias_t, rowbias, ld_rowbias)
-            if y.pend is not None:
-                self._last_T = None
-                y.rg = rg_in
-                return y
         self.f_off.append(ops.gemm(g_off, keep=(site, xs, residual, y), ws=self.ws))
         T = None
         self._last_T = None
@@ -828,27 +743,6 @@ class PlanBuilder:
             if y.rg:
                 self.tape.append(lambda: self.gemm_bwd(site, xs, y, T, conv, amode, rows, residual))
         return y
-
-    def _deferred_splitk(self, g: "hip.GemmArgs", keep, bias_t, rowbias, ld_rowbias) -> Optional[dict]:
-        """Emits the launch of `g` WITHOUT its split-K finishing pass (`leco_gemm_args.no_finish`) when the launch shape the
-        tuner / the C cost model picks splits K; returns what `leco_groupnorm_fwd_splitk` needs, or None (nothing emitted)."""
-        import re
-        from . import tune
-        if self.ws is None:
-            return None
-        tile, split = tune.choose(g, self.ws)
-        ws_ptr, ws_bytes = self.ws.data_ptr(), self.ws.numel() * self.ws.element_size()
-        first = hip.gemm_describe(g, tile, split, ws_ptr, ws_bytes).split(" ; ")[0]
-        m = re.search(r"split=(\d+)", first)
-        eff = int(m.group(1)) if m else 1
-        if first.startswith("conv_patch_kernel"):
-            eff = min(eff, g.k // 9 // 64)          # splits beyond the channel-chunk count write nothing (conv_patch.hip)
-        if eff <= 1:
-            return None
-        g.no_finish = 1
-        for lst in (self.f_off, self.f_on):
-            lst.append(ops.Op("leco_gemm_ex", (C.byref(g), tile, split, ws_ptr, ws_bytes), keep=(g, keep, self.ws)))
-        return dict(splits=eff, ws=self.ws, bias=bias_t, rowbias=rowbias, ld_rowbias=ld_rowbias)
 
     # ---- A-stationary GEMM (csrc/xgemm.hip) for the short-K / small-M Linears of the forward-only plans ------------------
     def xgemm_ok(self, site: GemmSite, xs, amode, rows: int, rowbias, act) -> bool:
@@ -1033,15 +927,6 @@ class PlanBuilder:
         y = self.act(name, rows, Cc, rg=any(t.rg for t in xs))
         stats = self.buf(name + ".stats", (self.B * G * 2 * 257,), torch.float32)
         x1 = xs[1] if len(xs) == 2 else None
-        if len(xs) == 1 and xs[0].pend is not None:
-            # the producer left unfinished split-K slabs: sum + bias + time-embedding bias + bf16 rounding happen in this
-            # kernel's loader (leco_groupnorm_fwd_splitk) -- no finishing launch, no pre-norm tensor in memory
-            pd = xs[0].pend
-            assert not self.need_bwd
-            self.both(ops.Op("leco_groupnorm_fwd_splitk", (
-                hip.ptr(pd["ws"]), pd["splits"], hip.ptr(pd["bias"]), pd["rowbias"], pd["ld_rowbias"], gamma.data_ptr(), beta.data_ptr(),
-                self.B, hw, Cc, G, eps, act, stats.data_ptr(), y.ptr, y.ld), keep=(xs, y, stats, pd)))
-            return y
         if all(t.cstats is not None for t in xs) and (Cc // G) % self.stat_atom == 0 and xs[0].cols % self.stat_atom == 0:
             # the producers left per-(sample, channel) statistics: one apply pass, no reduction over the tensor
             self.both(ops.Op("leco_groupnorm_apply_stats", (
@@ -1145,18 +1030,9 @@ class PlanBuilder:
         eng, m = self.eng, self.eng.named[rname]
         hw, rows = hs * ws, self.B * hs * ws
         conv = (self.B, hs, ws, hs, ws)
-        # conv_shortcut reads the block's input and is only needed by conv2's residual: it runs on the side stream beside
-        # norm1 -> conv1 -> norm2 (whose GroupNorm launches leave most of the chip idle)
-        sc_early = None
-        if m.conv_shortcut is not None and self.fork_ok():
-            with self.forked():
-                sc_early = self.gemm_fwd(eng.sites[rname + ".conv_shortcut"], x, rname + ".sc", rows=rows)
         n1 = self.groupnorm(rname + ".norm1", x, hw, ACT_SILU, self.cfg.norm_eps, rname + ".n1")
         off = eng.temb_off[rname]
         temb = self.temb_all  # fp32 [B][temb_total]
-        if getattr(self, "_pending_join", False):     # the time-embedding chain of build() ran on the side stream
-            self.join()
-            self._pending_join = False
         tsite = eng.temb_lora_sites.get(rname)
         temb_T = None
         if tsite is not None:
@@ -1167,15 +1043,10 @@ class PlanBuilder:
             self.gemm_fwd(tsite, self.emb_silu, rname + ".temb", rows=self.B,
                           out_f32=temb[:, off:off + cout], ldc32_override=eng.temb_total)
             temb_T = self._last_T
-        # forward-only plans: conv1's output is read by norm2 alone -- when the launch splits K, norm2 finishes it
-        import os
         site1 = eng.sites[rname + ".conv1"]
-        fin_in_gn = (not self.need_bwd and not eng.f32 and tsite is None and site1.lora is None
-                     and os.environ.get("LECO_GN_FINISH", "0") not in ("", "0")      # measured neutral on MI355X: off
-                     and bool(hip.lib().leco_groupnorm_single_launch(self.B, hw, m.out_channels, self.cfg.norm_num_groups)))
         h1 = self.gemm_fwd(site1, n1, rname + ".h1", conv=conv, amode=A_CONV3_S1, rows=rows,
                            rowbias=temb.data_ptr() + 4 * off, rows_per_group=hw, ld_rowbias=eng.temb_total, bias=None,
-                           stats_hw=hw, defer_finish=fin_in_gn)
+                           stats_hw=hw)
         if tsite is not None and h1.rg:
             def temb_bwd():
                 out = self.plan.bwd
@@ -1190,10 +1061,7 @@ class PlanBuilder:
                 self.lora_bwd(tsite, (self.emb_silu,), dtb, temb_T, None, A_PLAIN, self.B, rname + ".temb")
             self.tape.append(temb_bwd)
         n2 = self.groupnorm(rname + ".norm2", h1, hw, ACT_SILU, self.cfg.norm_eps, rname + ".n2")
-        if sc_early is not None:
-            sc = sc_early
-            self.join()
-        elif m.conv_shortcut is not None:
+        if m.conv_shortcut is not None:
             sc = self.gemm_fwd(eng.sites[rname + ".conv_shortcut"], x, rname + ".sc", rows=rows)
         else:
             assert not isinstance(x, tuple)
@@ -1293,48 +1161,11 @@ class PlanBuilder:
             lst.append(ops.xblock_tail(A, keep=keep))
         return out
 
-    def lnfold_ok(self, site: GemmSite, kind: str) -> bool:
-        """LayerNorm -> Linear as one launch (leco_gemm_args.ln_s) in the LoRA-on list of a forward-only bf16 plan: needs the
-        16-row fused down-projection with a free row for the ones-row (groups * rank <= 15).  LECO_LNFOLD=0 switches it
-        off, a comma list of {qkv, q, ff} restricts it to those consumers (A/B measurements)."""
-        import os
-        # DEFAULT OFF.  Measured on MI355X (profiles/r05_plan_denoise_{base,ln}.txt, r05_bench_fuse_*.json, r05_bench_lnfold_*.json):
-        # launch by launch the q|k|v / to_q consumers grow by 0.8 - 5 us where the LayerNorm launch they absorb costs 8 (the GEGLU
-        # projection, with four times the columns and no registers to spare in its two-workgroups-per-CU form, grows by 8 - 15 us),
-        # 31 launches and 0.09 ms less per pass in isolation -- but the whole step moved by +0.2 % on one lease (all three
-        # folds) and by -1.5 % on another (q|k|v + to_q only, two interleaved A/B pairs).  Not a win that survives a step.
-        sel = os.environ.get("LECO_LNFOLD", "0")
-        if self.need_bwd or self.eng.f32 or sel in ("", "0") or (sel not in ("1", "all") and kind not in sel.split(",")):
-            return False
-        lo = site.lora
-        return lo is not None and lo.Rp == 32 and lo.R16 == 16 and lo.R <= 15
-
-    def ln_linear(self, norm_name: str, site: GemmSite, x: TRef, ln_name: str, name: str, rows: int, kind: str,
-                  geglu: bool = False) -> TRef:
-        """y = Linear(LayerNorm(x)) [GEGLU].  Both lists get the two-launch chain; where the fold applies, the LoRA-ON list's
-        pair (what the k denoising passes replay) is replaced by ONE launch on the raw rows."""
-        n_on = len(self.f_on)
-        l = self.layernorm(norm_name, x, ln_name)
-        y = self.gemm_fwd(site, l, name, rows=rows, geglu=geglu)
-        std = self.f_on[n_on:]
-        if not self.lnfold_ok(site, kind) or len(std) != 2 or std[0].name != "leco_layernorm_fwd" or std[1].name != "leco_gemm_ex":
-            return y
-        gstd, tile, split = std[1].keep[0], std[1].args[1], std[1].args[2]
-        if split > 1 or not gstd.t_w or gstd.t_rows != 16 or gstd.a1 or gstd.rowbias or gstd.residual or gstd.col_stats:
-            return y
-        st = self.eng.lnfold_state(site, norm_name, geglu)
-        g = hip.GemmArgs.from_buffer_copy(gstd)
-        g.a0, g.lda0 = x.ptr, x.ld
-        g.w, g.t_w = st.w.data_ptr(), st.dn_ln.data_ptr()
-        g.bias, g.t_out = None, None
-        g.ln_s, g.ln_c, g.ln_sd, g.ln_cd, g.ln_eps = st.s.data_ptr(), st.c.data_ptr(), st.sd.data_ptr(), st.cd.data_ptr(), 1e-5
-        # the 4-wave / two-workgroups-per-CU form of the 128 x 128 tile has no registers to spare for the statistics
-        # (268 > 256: it would run one workgroup per CU): those launches take the 8-wave form
-        if "gemm_kernel<128, 128, false, 2, 2," in hip.gemm_describe(g, tile, 1):
-            tile = 6
-        del self.f_on[n_on:]
-        self.f_on.append(ops.Op("leco_gemm_ex", (C.byref(g), tile, 1, None, 0), keep=(g, st, site, x, y, std[1].keep)))
-        return y
+    def ln_linear(self, norm_name: str, site: GemmSite, x: TRef, ln_name: str, name: str, rows: int, geglu: bool = False) -> TRef:
+        """y = Linear(LayerNorm(x)) [GEGLU]: two launches.  (A one-launch form -- LayerNorm folded into the Linear through
+        the row statistics of its own operands, rounds 2 and 5 -- measured step-neutral to slightly negative on SD1.5 and
+        neutral on SDXL, profiles/r05_bench_lnfold_*.json / r06_switch_ab_sdxl.txt, and was removed in round 6.)"""
+        return self.gemm_fwd(site, self.layernorm(norm_name, x, ln_name), name, rows=rows, geglu=geglu)
 
     def basic_block(self, bname: str, hcur: TRef, ctx: TRef, heads: int, hw: int, tname: str = "", last: bool = False,
                     x_res: Optional[TRef] = None, qkv: Optional[TRef] = None) -> Tuple[TRef, bool]:
@@ -1345,7 +1176,7 @@ class PlanBuilder:
         S = eng.sites
         fused = bool(tname) and self.stripe_ok(bname, tname, Cc, heads, hw, ctx.rows // self.Bfull)
         if qkv is None:
-            qkv = self.ln_linear(bname + ".norm1", S[bname + ".attn1.qkv"], hcur, bname + ".l1", bname + ".qkv", rows, "qkv")
+            qkv = self.ln_linear(bname + ".norm1", S[bname + ".attn1.qkv"], hcur, bname + ".l1", bname + ".qkv", rows)
         a1 = self.attention(qkv, qkv, heads, hw, hw, bname + ".a1")
         if fused:
             n_on, n_off = len(self.f_on), len(self.f_off)
@@ -1354,7 +1185,7 @@ class PlanBuilder:
                 op.tag = "ctx"
             return self.block_tail_fused(bname, tname, a1, hcur, kv, heads, hw, last, x_res), last
         h1 = self.gemm_fwd(S[bname + ".attn1.to_out.0"], a1, bname + ".h1", rows=rows, residual=hcur)
-        q2 = self.ln_linear(bname + ".norm2", S[bname + ".attn2.to_q"], h1, bname + ".l2", bname + ".q2", rows, "q")
+        q2 = self.ln_linear(bname + ".norm2", S[bname + ".attn2.to_q"], h1, bname + ".l2", bname + ".q2", rows)
         # K/V of cross-attention depend only on the prompt embeddings (and the LoRA weights): tag their ops
         # so that callers replaying the same prompt (the k denoising passes of a step) can run them once
         n_on, n_off = len(self.f_on), len(self.f_off)
@@ -1365,7 +1196,7 @@ class PlanBuilder:
         h2 = self.gemm_fwd(S[bname + ".attn2.to_out.0"], a2, bname + ".h2", rows=rows, residual=h1)
         ff1 = S[bname + ".ff.net.0.proj"]
         if not self.need_bwd and not eng.f32 and ff1.geglu_ok and (ff1.lora is None or (ff1.lora.Rp == 32 and ff1.lora.up_pg is not None)):
-            gg = self.ln_linear(bname + ".norm3", ff1, h2, bname + ".l3", bname + ".geglu", rows, "ff", geglu=True)
+            gg = self.ln_linear(bname + ".norm3", ff1, h2, bname + ".l3", bname + ".geglu", rows, geglu=True)
             return self.gemm_fwd(S[bname + ".ff.net.2"], gg, bname + ".h3", rows=rows, residual=h2), False
         l3 = self.layernorm(bname + ".norm3", h2, bname + ".l3")
         u = self.gemm_fwd(ff1, l3, bname + ".u", rows=rows)
@@ -1448,13 +1279,7 @@ class PlanBuilder:
         P.pred = self.buf("pred", (B, cfg.out_channels, h, w), torch.float32)
         P.dpred = self.buf("dpred", (B, cfg.out_channels, h, w), torch.float32, zero=True)
         ctx = TRef(P.ctx, B * 77, cfg.cross_attention_dim, name="ctx")
-        # -- time embedding.  Forward-only plans: the whole chain (sinusoid, the two Linears, SDXL's add-embedding, the fused
-        # time_emb_proj GEMM) runs on the side stream beside conv_in and the first GroupNorm; the first consumer -- conv1 of
-        # the first ResnetBlock2D -- joins (resnet())
-        temb_fork = contextlib.ExitStack()
-        if self.fork_ok():
-            temb_fork.enter_context(self.forked())
-            self._pending_join = True
+        # -- time embedding
         tsin = self.act("t_sin", B, ch[0])
         self.both(ops.timestep_embedding(P.t_table, P.t_idx, 0, B, ch[0], tsin.t))
         e1 = self.gemm_fwd(S["time_embedding.linear_1"], tsin, "t_e1", rows=B, act=ACT_SILU)
@@ -1472,7 +1297,6 @@ class PlanBuilder:
         self.emb_silu = emb_silu
         self.temb_all = self.buf("temb_all", (B, eng.temb_total), torch.float32)
         self.gemm_fwd(S["time_emb_proj_all"], emb_silu, "temb_all_g", rows=B, out_f32=self.temb_all)
-        temb_fork.close()
         # -- conv_in.  BATCH-SHARED PREFIX (share > 1: the B latents are `share` copies of B / share samples at one timestep):
         # conv_in, the first ResnetBlock2D and the first Transformer2DModel up to and including its self-attention do not see
         # the prompt, so they run ONCE per distinct sample (batch Bp); the stripe tail kernel of that transformer reads them
@@ -1659,25 +1483,21 @@ class UNet2DConditionModel(nn.Module):
         if not (self.use_graphs and self.device.type == "cuda" and not hip.is_emulated()) or ops._TRACE_OPS:
             ops.run_plan(oplist)
             return
+        import os
+        eager = os.environ.get("LECO_EAGER_LISTS")      # debugging aid: comma list of "<list name>[:B]" launched eagerly
+        if eager and any(e == which.split("@")[0] or e == f"{which.split('@')[0]}:{plan.key[0]}" for e in eager.split(",")):
+            ops.run_plan(oplist)
+            return
         lib = _graph_api()
         g = plan.graphs.get(which)
         cur = torch.cuda.current_stream()
         if g is None:
             import os
-            if os.environ.get("LECO_CAPTURE_STREAM") == "lib":
-                # experiment switch (ROCm 7.2 capture crash): capture on the library's own stream
-                # instead of one from torch's pool
-                sp = ops.side_stream()
-                lib.leco_fork.argtypes, lib.leco_fork.restype = [C.c_void_p], C.c_int
-                hip.check(lib.leco_fork(cur.cuda_stream), "capture edge")
-            else:
-                side = getattr(self, "_capture_stream", None)
-                if side is None:
-                    side = self._capture_stream = torch.cuda.Stream()
-                side.wait_stream(cur)
-                sp = side.cuda_stream
-            if any(op.side for op in oplist):
-                ops.side_stream()       # forked sections: the library's side stream exists before the capture begins
+            side = getattr(self, "_capture_stream", None)
+            if side is None:
+                side = self._capture_stream = torch.cuda.Stream()
+            side.wait_stream(cur)
+            sp = side.cuda_stream
             hip.check(lib.leco_graph_begin_capture(sp), "graph begin")
             try:
                 ops.run_plan(oplist, sp)

@@ -691,125 +691,6 @@ def test_xgemm_a_stationary_linear(dev, m, n, k, rank, res):
     assert (c2[m:].float() == 7.0).all() and torch.isfinite(c2.float()).all()
 
 
-@pytest.mark.parametrize("conv,B,hw,C,K,split", [(False, 2, 64, 64, 512, 2), (False, 3, 16, 320, 1024, 4), (True, 2, 64, 64, 64 * 9, 1),
-                                                 (True, 2, 64, 128, 128 * 9, 2), (True, 4, 256, 128, 256 * 9, 4)])
-def test_groupnorm_finishes_a_split_k_convolution(dev, conv, B, hw, C, K, split):
-    """`leco_gemm_args.no_finish` + `leco_groupnorm_fwd_splitk`: the GroupNorm(+SiLU) that is the ONLY reader of a split-K
-    launch's output (ResnetBlock2D.conv1 -> norm2 in the forward-only plans) sums the fp32 slabs + bias + time-embedding row
-    bias in its loader.  Bit-identical to the unfused pair (finishing pass, then leco_groupnorm_fwd); the plain GEMM kernels
-    and the patch-staged convolution as producers."""
-    torch.manual_seed(B * hw + C)
-    m = B * hw
-    side = int(math.isqrt(hw))
-    cin = K // 9 if conv else K
-    a = (torch.randn(m, cin) * 0.5).to(bf).to(dev)
-    w = (torch.randn(C, K) / math.sqrt(K)).to(bf).to(dev)
-    bias = (torch.randn(C) * 0.1).to(dev)
-    rowbias = (torch.randn(B, C) * 0.3).to(dev)
-    gamma, beta = (1 + 0.1 * torch.randn(C)).to(dev), (0.1 * torch.randn(C)).to(dev)
-    ws = torch.zeros(8 << 20, dtype=torch.float32, device=dev)
-    stats = torch.zeros(B * 32 * 2 * 257, dtype=torch.float32, device=dev)
-    kw = dict(m=m, n=C, k=K, bias=bias, rowbias=rowbias, rows_per_group=hw, ld_rowbias=C)
-    if conv:
-        kw.update(a_mode=hip.A_CONV3_S1, conv=(B, side, side, side, side), lda=cin)
-    tile = 9 if conv else 3              # the 128 x 128 patch kernel / the 64 x 64 ring GEMM
-    sp = max(split, 2)
-    ws_b = ws.numel() * 4
-
-    def run(no_finish):
-        y = torch.zeros(m, C, dtype=bf, device=dev)
-        g = hip.gemm_args(a, w, y, **kw)
-        g.no_finish = 1 if no_finish else 0
-        ops.Op("leco_gemm_ex", (C_.byref(g), tile, sp, ws.data_ptr(), ws_b), keep=(g, a, w, y)).run()
-        return y
-    import ctypes as C_
-    y = run(False)
-    out_ref = torch.zeros(m, C, dtype=bf, device=dev)
-    ops.Op("leco_groupnorm_fwd", (y.data_ptr(), C, None, 0, 0, gamma.data_ptr(), beta.data_ptr(), B, hw, C, 32, 1e-5, 1,
-                                  stats.data_ptr(), out_ref.data_ptr(), C)).run()
-    _sync(dev)
-    ws.zero_()
-    y2 = run(True)
-    import re
-    first = hip.gemm_describe(hip.gemm_args(a, w, y2, **kw), tile, sp, ws.data_ptr(), ws_b).split(" ; ")[0]
-    eff = int(re.search(r"split=(\d+)", first).group(1))          # what the planner reads (unet.py::_deferred_splitk)
-    if eff <= 1:         # the launch shape does not split (one channel chunk): nothing to defer, the planner never sets the flag
-        return
-    _sync(dev)
-    assert float(y2.float().abs().sum()) == 0.0                  # nothing was finished into c
-    out = torch.zeros(m, C, dtype=bf, device=dev)
-    ops.Op("leco_groupnorm_fwd_splitk", (ws.data_ptr(), eff, bias.data_ptr(), rowbias.data_ptr(), C, gamma.data_ptr(),
-                                         beta.data_ptr(), B, hw, C, 32, 1e-5, 1, stats.data_ptr(), out.data_ptr(), C)).run()
-    _sync(dev)
-    assert torch.isfinite(out.float()).all() and float(out.float().abs().mean()) > 0.05
-    assert torch.equal(out.cpu(), out_ref.cpu())
-
-
-def _lnfold_operands(dev, x, w, bias, gamma, beta, dn_rows, up, geglu_perm=None):
-    """Pack-time half of the LayerNorm fold: W' = bf16(gamma (.) W), s, c; the stacked lora_down image through leco_lnfold_pack."""
-    import ctypes as C_
-    K = w.shape[1]
-    wp = (w.float() * gamma[None, :]).to(bf)
-    s_ = wp.float().sum(1)
-    c_ = w.float() @ beta + bias
-    dn_s = torch.zeros(32, K, dtype=bf)
-    dn_s[:dn_rows.shape[0]] = dn_rows
-    dn_s = dn_s.to(dev)
-    dn_ln = torch.zeros(16, K, dtype=bf, device=dev)
-    sd, cd = torch.zeros(16, device=dev), torch.zeros(16, device=dev)
-    gd, bd = gamma.to(dev), beta.to(dev)
-    site = (hip.LnFoldSite * 1)()
-    site[0].dn_s, site[0].gamma, site[0].beta = dn_s.data_ptr(), gd.data_ptr(), bd.data_ptr()
-    site[0].dn_ln, site[0].sd, site[0].cd, site[0].k = dn_ln.data_ptr(), sd.data_ptr(), cd.data_ptr(), K
-    sites_dev = torch.frombuffer(bytearray(bytes(site)), dtype=torch.uint8).to(dev)
-    ops.lnfold_pack(sites_dev, 1).run()
-    _sync(dev)
-    return dict(w=wp.to(dev), s=s_.to(dev), c=c_.to(dev), dn_ln=dn_ln, sd=sd, cd=cd, keep=(dn_s, gd, bd, sites_dev))
-
-
-@pytest.mark.parametrize("tile,M,N,K", [(3, 200, 256, 320), (1, 300, 384, 640), (5, 256, 256, 1280), (2, 130, 320, 640)])
-def test_gemm_with_the_layernorm_folded_in(dev, tile, M, N, K):
-    """leco_gemm_args.ln_s: LayerNorm -> Linear (+ LoRA) as ONE launch on the raw rows -- gamma folded into the weights at
-    pack time (leco_lnfold_pack for the LoRA stack), row statistics from the kernel's own operands (sum x: ones-row of the T
-    fragment, sum x^2: the diagonal of a Gram MFMA), y = rstd (acc - mean s) + c in the epilogue.  Against the two-launch
-    chain it replaces (fp32 LayerNorm rounded to bf16, then the same Linear + LoRA in fp32), over the GEMM's tile forms."""
-    torch.manual_seed(tile * 1000 + K)
-    x = (torch.randn(M, K) * 1.5 + 0.7 * torch.randn(M, 1) + 0.3).to(bf)          # rows with different means / scales
-    gamma, beta = 1 + 0.2 * torch.randn(K), 0.1 * torch.randn(K)
-    w = (torch.randn(N, K) / math.sqrt(K)).to(bf)
-    bias = 0.1 * torch.randn(N)
-    R = 12
-    dn = (torch.randn(R, K) / math.sqrt(K)).to(bf)
-    up = torch.zeros(N, 32)
-    up[:, :R] = torch.randn(N, R) * 0.2
-    up = up.to(bf)
-    # ---- the chain it replaces
-    xf = x.float()
-    mu, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
-    xn = (((xf - mu) * torch.rsqrt(var + 1e-5)) * gamma + beta).to(bf).float()
-    T = (xn @ dn.float().t()).to(bf).float()
-    ref = xn @ w.float().t() + bias + T @ up.float()[:, :R].t()
-    # ---- the fold
-    P = _lnfold_operands(dev, x, w, bias, gamma, beta, dn, up)
-    sdn = P["sd"].cpu()
-    assert sdn[15].item() == 0.0 and rel_err(sdn[:R], (dn.float() * gamma).to(bf).float().sum(1)) < 1e-6
-    assert (P["dn_ln"][15].float() == 1.0).all() and rel_err(P["cd"].cpu()[:R], dn.float() @ beta) < 1e-5
-    xd, upd = x.to(dev), up.to(dev)
-    y = torch.zeros(M, N, dtype=bf, device=dev)
-    g = hip.gemm_args(xd, P["w"], y, m=M, n=N, k=K, w_ext=upd, ext_k=32, ld_wext=32, t_w=P["dn_ln"], t_rows=16)
-    g.ln_s, g.ln_c, g.ln_sd, g.ln_cd, g.ln_eps = P["s"].data_ptr(), P["c"].data_ptr(), P["sd"].data_ptr(), P["cd"].data_ptr(), 1e-5
-    assert hip.gemm_describe(g, tile, 1).split(" grid=")[0].endswith(", 1, true>")
-    ops.gemm(g, keep=(xd, P, upd, y), tile=tile, split_k=1).run()
-    _sync(dev)
-    err = rel_err(y.float().cpu(), ref)
-    print(f"LayerNorm-folded GEMM tile {tile} M={M} N={N} K={K}: rel {err:.3e}")
-    assert err < 6e-3
-    # a bias pointer beside the fold is refused (it lives in ln_c)
-    g.bias = P["c"].data_ptr()
-    with pytest.raises(hip.LecoError):
-        ops.gemm(g, keep=(xd, P, upd, y), tile=tile, split_k=1).run()
-
-
 @pytest.mark.parametrize("adt", [bf, torch.float32])
 def test_step_glue_launches(dev, adt):
     """leco_step_begin / leco_step_mid (the tensor moves between the launch plans of a step, train_lora.py:175-199) against

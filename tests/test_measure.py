@@ -29,18 +29,18 @@ def test_describe_names_the_instantiation_the_dispatcher_would_launch():
     d = hip.gemm_describe(_args(1024, 1280, 11520, a_mode=hip.A_CONV3_S1, conv=(4, 16, 16, 16, 16)), 0, 0, wsp, wsb)
     assert d.startswith("conv_patch_kernel<128, 128, 4, false> grid=80 split=3"), d
     # tile = -1 pins the implicit-GEMM family (what other gathers, and LoRA-carrying convs, run)
-    assert hip.gemm_describe(g0, -1, 0, wsp, wsb).startswith("gemm_kernel<128, 160, true, 4, 4, 0, false> grid=256 split=1")
+    assert hip.gemm_describe(g0, -1, 0, wsp, wsb).startswith("gemm_kernel<128, 160, true, 4, 4, 0> grid=256 split=1")
     d = hip.gemm_describe(_args(1024, 1280, 11520, a_mode=hip.A_CONV3_S1, conv=(4, 16, 16, 16, 16)), -1, 0, wsp, wsb)
-    assert d.startswith("gemm_kernel<256, 128, true, 3, 4, 0, false>") and "split=6" in d
+    assert d.startswith("gemm_kernel<256, 128, true, 3, 4, 0>") and "split=6" in d
     # large plain 128x128 grids run as 4-wave workgroups (two per CU); explicit tile ids pin either form
     g = _args(16384, 2560, 320)
-    assert "gemm_kernel<128, 128, false, 2, 2, 0, false>" in hip.gemm_describe(g, 0, 0, wsp, wsb)
-    assert "gemm_kernel<128, 128, false, 4, 4, 0, false>" in hip.gemm_describe(g, 6, 1)
-    assert "gemm_kernel<128, 128, false, 2, 2, 0, false>" in hip.gemm_describe(g, 5, 1)
+    assert "gemm_kernel<128, 128, false, 2, 2, 0>" in hip.gemm_describe(g, 0, 0, wsp, wsb)
+    assert "gemm_kernel<128, 128, false, 4, 4, 0>" in hip.gemm_describe(g, 6, 1)
+    assert "gemm_kernel<128, 128, false, 2, 2, 0>" in hip.gemm_describe(g, 5, 1)
     # fused LoRA down-projection on a deep-K small-M shape: the unsplit 64x64 grid keeps it fused (one kernel)
     x = torch.zeros(8, 8, dtype=bf)
     g = _args(1024, 1280, 5120, w_ext=x, ext_k=32, t_w=x, t_rows=16, t_out=x)
-    assert hip.gemm_describe(g, 0, 0, wsp, wsb) == "gemm_kernel<64, 64, false, 4, 2, 1, false> grid=320 split=1"
+    assert hip.gemm_describe(g, 0, 0, wsp, wsb) == "gemm_kernel<64, 64, false, 4, 2, 1> grid=320 split=1"
 
 
 def test_tuner_keys_candidates_and_table():

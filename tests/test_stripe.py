@@ -237,53 +237,6 @@ def test_forward_only_plans_run_the_stripe_kernels_and_match_the_per_op_plan(dev
         assert rel_err(p_on, p_off) > 1e-3 and rel_err(y_on, y_off) > 1e-3     # the LoRA term is really there
 
 
-def test_forked_shortcut_convolutions_give_the_same_prediction(dev, monkeypatch):
-    """Forward-only plans run ResnetBlock2D.conv_shortcut on the library's side stream beside norm1 -> conv1 -> norm2
-    (leco_fork / leco_join, include/leco_hip.h) and the time-embedding chain beside conv_in: every fork is closed by a join before the consumer, forked GEMMs own a
-    split-K workspace, and the prediction of repeated eager runs equals the single-stream plan's."""
-    torch.manual_seed(11)
-    monkeypatch.setenv("LECO_FORK", "1")         # (off by default: measured step-neutral under graph replay)
-    m = _stripe_unet(dev)
-    B, h, w = 2, 8, 8
-    x = torch.randn(B, 4, h, w).to(dev, bf); ctx = torch.randn(B, 77, 64).to(dev, bf)
-    eng = m.engine()
-    plan = eng.plan(B, h, w, need_bwd=False)
-    lst = plan.lists["fwd_off"]
-    names = [op.name for op in lst]
-    n_sc = sum(1 for nm, mod in m.named_modules() if nm.endswith("conv_shortcut"))
-    # one section per conv_shortcut + the time-embedding chain beside conv_in
-    assert n_sc >= 2 and names.count("leco_fork") == n_sc + 1 == names.count("leco_join")
-    depth = 0
-    for op in lst:                                # sections do not nest, side launches only inside one, all closed at the end
-        if op.name == "leco_fork":
-            assert depth == 0
-            depth = 1
-        elif op.name == "leco_join":
-            assert depth == 1
-            depth = 0
-        elif op.side:
-            assert depth == 1 and op.name.startswith(("leco_gemm", "leco_timestep_embedding"))
-            if op.name.startswith("leco_gemm") and op.args[3]:
-                assert op.args[3] == eng.workspace_slot(2).data_ptr() != eng.workspace.data_ptr()
-    assert depth == 0 and any(op.side for op in lst)
-    assert not any(op.side for op in eng.plan(B, h, w, need_bwd=True).lists["fwd_off"])      # training plans stay single-stream
-    # eager launches on two real streams (the graph-captured form was measured on the GPU, profiles/r04_fork_join.txt; it is
-    # not exercised in this shared test process: a multi-stream capture here was followed by a segfault inside
-    # hipStreamBeginCapture of a LATER test's full-size model on ROCm 7.2, the capture fragility of DESIGN.md section 6)
-    outs = []
-    m.use_graphs = False
-    for _ in range(3):
-        outs.append(_run_plan(m, plan, "fwd_off", x, ctx))
-    monkeypatch.setenv("LECO_FORK", "0")
-    eng.plans.clear()
-    plain = eng.plan(B, h, w, need_bwd=False)
-    assert "leco_fork" not in [op.name for op in plain.lists["fwd_off"]]
-    ref = _run_plan(m, plain, "fwd_off", x, ctx)
-    _sync(dev)
-    for o in outs:
-        assert rel_err(o, ref) < 2e-3 and torch.isfinite(o).all()
-
-
 @pytest.mark.parametrize("rank,gn,B,hw", [(4, True, 2, 64), (0, False, 1, 128), (8, True, 1, 64)])
 def test_xblock_head_matches_the_per_op_chain(dev, rank, gn, B, hw):
     """GroupNorm (from producer statistics) -> proj_in -> LayerNorm -> q|k|v: h_out and qkv_out vs the fp32 chain."""
@@ -405,89 +358,3 @@ def test_forward_only_plans_run_the_a_stationary_gemm_and_match_the_ring_gemm(de
         assert rel_err(p_on, p_off) > 1e-3 and rel_err(y_on, y_off) > 1e-3     # the LoRA term is really there
 
 
-def test_forward_only_plans_finish_split_k_convolutions_inside_groupnorm(dev, monkeypatch):
-    """ResnetBlock2D.conv1 -> norm2 in the forward-only plans: where conv1's launch shape splits K, norm2's kernel sums the fp32
-    slabs itself (`leco_gemm_args.no_finish` + `leco_groupnorm_fwd_splitk`): one launch and one trip through memory less per
-    ResnetBlock2D.  Same bits as the finishing pass + GroupNorm pair (LECO_GN_FINISH=0); never in a plan with a backward."""
-    from leco_amd import tune
-    torch.manual_seed(21)
-    # every patch-staged convolution of this small model takes the 128 x 128 tile with two K slices (the real table's
-    # entries for the 16^2 / 8^2 levels look like this)
-    real_choose = tune.choose
-    monkeypatch.setenv("LECO_GN_FINISH", "1")        # (default off: measured step-neutral on MI355X)
-    monkeypatch.setattr(tune, "choose", lambda g, ws: (9, 2) if (g.a_mode == 1 and ws is not None and g.k // 9 // 64 >= 2) else real_choose(g, ws))
-    m = _stripe_unet(dev)
-    B, h, w = 2, 8, 8
-    x = torch.randn(B, 4, h, w).to(dev, bf); ctx = torch.randn(B, 77, 64).to(dev, bf)
-    eng = m.engine()
-    fused = eng.plan(B, h, w, need_bwd=False)
-    names = [op.name for op in fused.lists["fwd_off"]]
-    n_res = sum(1 for nm, mod in m.named_modules() if nm.endswith(".conv1"))
-    assert names.count("leco_groupnorm_fwd_splitk") == n_res >= 4, (names.count("leco_groupnorm_fwd_splitk"), n_res)
-    assert "leco_groupnorm_fwd_splitk" not in [op.name for op in eng.plan(B, h, w).lists["fwd_off"]]
-    y = _run_plan(m, fused, "fwd_off", x, ctx)
-    monkeypatch.setenv("LECO_GN_FINISH", "0")
-    eng.plans.clear()
-    plain = eng.plan(B, h, w, need_bwd=False)
-    assert "leco_groupnorm_fwd_splitk" not in [op.name for op in plain.lists["fwd_off"]]
-    assert len(plain.lists["fwd_off"]) == len(names)            # (the finishing launch is not a list entry: same length)
-    p_ = _run_plan(m, plain, "fwd_off", x, ctx)
-    _sync(dev)
-    assert torch.isfinite(y).all() and torch.equal(y, p_)
-
-
-def test_forward_only_lora_on_plans_fold_layernorm_into_the_linears(dev, monkeypatch):
-    """norm1 -> q|k|v, norm2 -> to_q, norm3 -> GEGLU projection of a BasicTransformerBlock in the LoRA-ON list of a forward-only
-    plan (what the k denoising passes replay): ONE launch each on the raw residual stream (leco_gemm_args.ln_s) instead of
-    LayerNorm + Linear.  Same prediction as the two-launch chain to bf16 rounding; follows the LoRA weights through a
-    re-pack (leco_lnfold_pack); the LoRA-off list and plans with a backward keep the LayerNorm launches."""
-    import contextlib
-    import io
-    from leco_amd import model_util
-    from leco_amd.lora import LoRANetwork
-    from leco_amd.unet import UNet2DConditionModel
-    torch.manual_seed(13)
-    monkeypatch.setenv("LECO_STRIPE", "0")
-    monkeypatch.setenv("LECO_LNFOLD", "1")          # all three consumers (the default leaves the GEGLU projection out)
-    m = model_util.init_synthetic_(UNet2DConditionModel(model_util.tiny_config()), seed=5).to(dev, bf)
-    with torch.no_grad():           # LayerNorm affine parameters that are not the identity
-        for n_, p_ in m.named_parameters():
-            if ".norm1." in n_ or ".norm2." in n_ or ".norm3." in n_:
-                p_.copy_((p_.float() + 0.2 * torch.randn(p_.shape).to(p_.device)).to(p_.dtype))
-    m.requires_grad_(False)
-    with contextlib.redirect_stdout(io.StringIO()):
-        net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
-    with torch.no_grad():
-        for l in net.unet_loras:
-            l.lora_up.weight.normal_(0, 0.05)
-    net.mark_updated()
-    B, h, w = 2, 16, 16
-    x = torch.randn(B, 4, h, w).to(dev, bf); ctx = torch.randn(B, 77, 64).to(dev, bf)
-    eng = m.engine()
-    net.multiplier = 1.0
-    m.prepare((B, 4, h, w), lora_on=True)
-    fold = eng.plan(B, h, w, need_bwd=False)
-    on, off = [op.name for op in fold.lists["fwd_on"]], [op.name for op in fold.lists["fwd_off"]]
-    n_blocks = sum(1 for n_, _ in m.named_modules() if n_.endswith(".norm3"))
-    assert off.count("leco_layernorm_fwd") == 3 * n_blocks and on.count("leco_layernorm_fwd") == 0, (on.count("leco_layernorm_fwd"), n_blocks)
-    assert "leco_layernorm_fwd" in [op.name for op in eng.plan(B, h, w).lists["fwd_on"]]       # the training plan keeps them
-    y1 = _run_plan(m, fold, "fwd_on", x, ctx)
-    with torch.no_grad():           # an "optimizer step": the fold's LoRA half must follow the re-pack
-        for l in net.unet_loras:
-            l.lora_down.weight.mul_(1.5)
-            l.lora_up.weight.mul_(-0.7)
-    net.mark_updated()
-    m.prepare((B, 4, h, w), lora_on=True)
-    y2 = _run_plan(m, fold, "fwd_on", x, ctx)
-    monkeypatch.setenv("LECO_LNFOLD", "0")
-    eng.plans.clear()
-    plain = eng.plan(B, h, w, need_bwd=False)
-    assert [op.name for op in plain.lists["fwd_on"]].count("leco_layernorm_fwd") == 3 * n_blocks
-    p2 = _run_plan(m, plain, "fwd_on", x, ctx)
-    _sync(dev)
-    e2 = rel_err(y2, p2)
-    print(f"LayerNorm fold vs LayerNorm + Linear plan: {e2:.3g}; LoRA change moved the prediction by {rel_err(y2, y1):.3g}")
-    # (two bf16 plans with differently placed roundings: the fold and the chain are EACH 2.5e-3 from fp32 on a single Linear --
-    # tests/test_kernels.py -- and 3.4e-3 from each other; through a whole UNet that is ~1e-2, the level at which the
-    # stripe / per-op plans and two replays of the fused-statistics GroupNorm differ as well)
-    assert torch.isfinite(y2).all() and e2 < 2e-2 and rel_err(y2, y1) > 2 * e2

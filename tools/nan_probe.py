@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--rank", type=int, default=4)
     ap.add_argument("--k", type=int, default=2)
     ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--dedup", action="store_true", help="walk the de-duplicated pass structure (FusedStep.dedup)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     tokenizer, text_encoder, unet, sched = model_util.load_models(f"synthetic:{args.arch}", "ddim")
@@ -98,7 +99,7 @@ def main():
                                           action="erase", guidance_scale=1.0, resolution=args.res, batch_size=args.bs)
     emb = {p: text_encoder([p])[0] for p in ("van gogh", "")}
     pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["van gogh"], emb["van gogh"], emb[""], emb[""], settings)
-    fused = FusedStep(unet, net, sched, 50, lr=1e-4, world_size=1)
+    fused = FusedStep(unet, net, sched, 50, lr=1e-4, world_size=1, dedup=args.dedup)
     noise_gen = torch.Generator().manual_seed(1000)
     probe = Probe()
 
@@ -114,7 +115,8 @@ def main():
         print(f"step {s}: loss={loss.item():.6e} grad finite={torch.isfinite(net.grad).all().item()} "
               f"|grad|={net.grad.norm().item():.4e} slab finite={torch.isfinite(net.slab).all().item()} "
               f"x finite={torch.isfinite(st['x']).all().item()} |x|max={st['x'].abs().max().item():.3f} "
-              f"pred max={st['plan'].pred.abs().max().item():.4f}", flush=True)
+              f"pred max={st['last']['plan'].pred.abs().max().item():.4f} "
+              f"frozen finite={ {n: bool(torch.isfinite(t).all().item()) for n, t in st['last']['preds'].items()} }", flush=True)
     print("probe events:", probe.events)
 
 

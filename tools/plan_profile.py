@@ -30,8 +30,7 @@ def describe(op):
         g = op.keep[0]
         ext = g.ext_k if (g.a_ext or g.t_w) else 0
         key = (f"gemm {AMODE[g.a_mode]} M={g.m} N={g.n} K={g.k}" + (f" +lora{ext}{'(fusedT)' if g.t_w else ''}" if ext else "")
-               + (" geglu" if g.act == 2 else "") + (" +res" if g.residual else "") + (" +lnfold" if g.ln_s else "")
-               + (" nofinish" if g.no_finish else ""))
+               + (" geglu" if g.act == 2 else "") + (" +res" if g.residual else ""))
         kin = g.k // 9 if g.a_mode else g.k
         rows_in = g.m if g.a_mode == 0 else g.batch * g.h_in * g.w_in
         return key, 2.0 * g.m * g.n * (g.k + ext), 2.0 * (rows_in * kin + g.n * g.k + g.m * g.n * (0.5 if g.act == 2 else 1))
@@ -44,9 +43,6 @@ def describe(op):
     if op.name == "leco_groupnorm_fwd":
         B, hw, c = a[7], a[8], a[9]
         return f"groupnorm_fwd B={B} HW={hw} C={c} act={a[12]}", 0.0, 4.0 * B * hw * c
-    if op.name == "leco_groupnorm_fwd_splitk":
-        sp, B, hw, c = a[1], a[7], a[8], a[9]
-        return f"groupnorm_fwd_splitk B={B} HW={hw} C={c} splits={sp} act={a[12]}", 0.0, (4.0 * sp + 2.0) * B * hw * c
     if op.name == "leco_groupnorm_bwd":
         B, hw, c = a[10], a[11], a[12]
         return f"groupnorm_bwd B={B} HW={hw} C={c}", 0.0, 8.0 * B * hw * c
@@ -111,7 +107,7 @@ def main():
     plan, which = {"denoise": (st["dplan"], "denoise"), "frozen": (st["fplan"], "fwd_off"), "fwd_on": (st["plan"], "fwd_on"),
                    "fwd_off": (st["plan"], "fwd_off"), "bwd": (st["plan"], "bwd")}[args.list]
     # the CFG / DDIM update and the timestep advance mutate the step state: leave them out of the repeats
-    ops_ = [op for op in plan.lists[which] if op.name not in ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step", "leco_fork", "leco_join")]
+    ops_ = [op for op in plan.lists[which] if op.name not in ("leco_advance", "leco_cfg_ddim_step", "leco_cfg_sched_step")]
     x = torch.randn(4096, 4096, device=dev)
     for _ in range(20):
         (x @ x).sum().item()      # clock ramp

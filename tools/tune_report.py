@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--rank", type=int, default=4)
     ap.add_argument("--c3lier", action="store_true")
     ap.add_argument("--out", default="gpurun_out/gemm_tune_gfx950.json")
+    ap.add_argument("--dedup", action="store_true",
+                    help="also build (= tune) the plans of the de-duplicated pass structure: training plan at UNet batch bs, frozen "
+                         "plans at U bs for U = 2 and 3 distinct prompts")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     x = torch.randn(4096, 4096, device=dev)
@@ -45,13 +48,18 @@ def main():
         net = LoRANetwork(unet, rank=args.rank, multiplier=1.0, alpha=1.0, target_replace_modules=targets).to(dev)
     fused = FusedStep(unet, net, sched, 50, lr=1e-4)
     st = fused._bucket(args.bs, args.res // 8, args.res // 8)       # builds the three plans -> tunes every shape
+    extra = []
+    if args.dedup:
+        for U in (2, 3):
+            pd, fd = fused._deduped(st, U)
+            extra += [(fd, "fwd_off")] + ([(pd, "fwd_on"), (pd, "bwd")] if U == 2 else [])
     torch.cuda.synchronize()
     per_pass = Counter()
     for op in st["dplan"].lists["denoise"]:
         if op.name == "leco_gemm_ex":
             per_pass[tune.shape_key(op.keep[0])] += 1
     fixed = Counter()
-    for plan, which in ((st["fplan"], "fwd_off"), (st["plan"], "fwd_on"), (st["plan"], "bwd"), (st["dplan"], "ctx_on")):
+    for plan, which in [(st["fplan"], "fwd_off"), (st["plan"], "fwd_on"), (st["plan"], "bwd"), (st["dplan"], "ctx_on")] + extra:
         for op in plan.lists[which]:
             if op.name == "leco_gemm_ex":
                 fixed[tune.shape_key(op.keep[0])] += 1
