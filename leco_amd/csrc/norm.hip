@@ -35,7 +35,9 @@ __device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
     for (int i = 0; i < 4; ++i) v[i] = pack_bf2(f[2 * i], f[2 * i + 1]);
     return v;
 }
-__device__ __forceinline__ float silu(float z) { return z / (1.f + __expf(-z)); }
+// z sigmoid(z) with the hardware reciprocal (v_rcp_f32, 1 ulp) and exp2: the IEEE fp32 division of `z / (1 + expf(-z))` is a
+// ten-instruction sequence per element, and the GroupNorm launches of the 32^2 / 64^2 levels are VALU-bound on it (round 6)
+__device__ __forceinline__ float silu(float z) { return z * fast_rcp(1.f + fast_exp2(-1.4426950408889634f * z)); }
 __device__ __forceinline__ float dsilu(float z) {
     float s = 1.f / (1.f + __expf(-z));
     return s * (1.f + z * (1.f - s));
@@ -54,10 +56,10 @@ __device__ __forceinline__ u32x4 gn_load(const GnSrc& s, int64_t row, int c) {
 constexpr int GN_MAX_GROUPS = 32;
 constexpr int GN_MAX_WAVES = 16;     // 1024 threads
 
-// One block = (sample b, a run of `gpb` adjacent groups whose channel span is a multiple of 8): the block owns
+// One block = (sample b, a run of `gpb` adjacent groups whose channel span is a multiple of VEC): the block owns
 // every pixel of those channels, so the statistics need no cross-block step -- no atomics, no partial
-// buffers, no finishing kernel, bitwise reproducible.  Thread t = (pixel lane t / nv, 16-byte channel
-// vector t % nv): consecutive threads read consecutive 16-byte pieces of a pixel's channel run.
+// buffers, no finishing kernel, bitwise reproducible.  Thread t = (pixel lane t / nv, channel vector t % nv):
+// consecutive threads read consecutive 2 VEC-byte pieces of a pixel's channel run.
 //   pass 1: per-thread sums over its pixels -> per-group sums in registers -> DPP wave reduction -> one LDS exchange
 //           of the wave totals, added by every thread in the same fixed order -> group statistics
 //   pass 2: the same pixels again (L2-resident by now) -> normalise (+SiLU) / dgrad -> store.
@@ -66,7 +68,62 @@ constexpr int GN_MAX_WAVES = 16;     // 1024 threads
 // NVR > 0 (forward only): every thread owns at most NVR pixels of its channel vector and KEEPS them in registers between
 // the two passes -- one trip to memory instead of two (the launches are latency-, not bandwidth-bound: 8 - 16 us each, 45
 // of them per UNet pass).
-template <int MODE, int NVR = 0>
+// VEC in {8, 4, 2} channels per thread vector (round 6).  With 16-byte vectors a block needs a channel run that is a
+// multiple of 8: 40 channels = 2 groups at C = 640, 4 groups at C = 320 -- 64 resp. 32 blocks at UNet batch 4, a quarter /
+// an eighth of the chip doing the whole tensor's SiLU arithmetic (14.6 / 13.6 us at HW = 1024,
+// profiles/r06_bench_norm.txt).  8- and 4-byte vectors let a block own ONE group (20 resp. 10 channels): 128 blocks, each
+// with half / a quarter of the work; the narrower loads cost nothing at these sizes (the tensors are L2-resident).
+template <int VEC>
+struct GnVec { unsigned w[VEC / 2]; };
+template <int VEC>
+__device__ __forceinline__ GnVec<VEC> gn_loadv(const GnSrc& s, int64_t row, int c) {
+    const bf16_t* p = c < s.c0 ? s.x0 + row * s.ld0 + c : s.x1 + row * s.ld1 + (c - s.c0);
+    GnVec<VEC> v;
+    if constexpr (VEC == 8) {
+        const u32x4 t = *(const u32x4*)p;
+        v.w[0] = t[0]; v.w[1] = t[1]; v.w[2] = t[2]; v.w[3] = t[3];
+    } else if constexpr (VEC == 4) {
+        const u32x2 t = *(const u32x2*)p;
+        v.w[0] = t[0]; v.w[1] = t[1];
+    } else {
+        v.w[0] = *(const unsigned*)p;
+    }
+    return v;
+}
+template <int VEC>
+__device__ __forceinline__ GnVec<VEC> gn_loadp(const bf16_t* p) {
+    GnVec<VEC> v;
+    if constexpr (VEC == 8) {
+        const u32x4 t = *(const u32x4*)p;
+        v.w[0] = t[0]; v.w[1] = t[1]; v.w[2] = t[2]; v.w[3] = t[3];
+    } else if constexpr (VEC == 4) {
+        const u32x2 t = *(const u32x2*)p;
+        v.w[0] = t[0]; v.w[1] = t[1];
+    } else {
+        v.w[0] = *(const unsigned*)p;
+    }
+    return v;
+}
+template <int VEC>
+__device__ __forceinline__ void gn_storev(bf16_t* p, const float (&o)[VEC]) {
+    if constexpr (VEC == 8) {
+        *(u32x4*)p = u32x4{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
+    } else if constexpr (VEC == 4) {
+        *(u32x2*)p = u32x2{pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3])};
+    } else {
+        *(unsigned*)p = pack_bf2(o[0], o[1]);
+    }
+}
+template <int VEC>
+__device__ __forceinline__ void gn_unpack(const GnVec<VEC>& v, float (&f)[VEC]) {
+#pragma unroll
+    for (int i = 0; i < VEC / 2; ++i) {
+        f[2 * i] = bf2f((bf16_t)(v.w[i] & 0xffffu));
+        f[2 * i + 1] = bf2f((bf16_t)(v.w[i] >> 16));
+    }
+}
+
+template <int MODE, int NVR = 0, int VEC = 8>
 __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t* dy, int64_t lddy,
                                                          const float* fstats, float* stats_out,
                                                          const float* gamma, const float* beta, int act,
@@ -75,27 +132,28 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
     __shared__ f32x4 red[GN_MAX_WAVES][2];       // per wave: {sum, sumsq} of the block's <= 4 groups
     const int tid = (int)threadIdx.x, NT = (int)blockDim.x;
     const int b = (int)blockIdx.y, g0 = (int)blockIdx.x * gpb;
-    const int cg = C / G, chunkC = gpb * cg, nv = chunkC / 8, cbase = g0 * cg;
+    const int cg = C / G, chunkC = gpb * cg, nv = chunkC / VEC, cbase = g0 * cg;
     const int PL = NT / nv;                       // pixel lanes
     const int pl = tid / nv, v = tid - pl * nv;
     const bool active = pl < PL;
-    const int c = cbase + v * 8;
+    const int c = cbase + v * VEC;
     const float inv_n = 1.f / ((float)hw * (float)cg);
-    int gi[8];                                    // group (inside the block's run) of each of this thread's 8 channels
+    int gi[VEC];                                  // group (inside the block's run) of each of this thread's channels
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gi[i] = (v * 8 + i) / cg;
+    for (int i = 0; i < VEC; ++i) gi[i] = (v * VEC + i) / cg;
 
-    float ga[8], be[8], mu[8], rs[8];
+    float ga[VEC], be[VEC], mu[VEC], rs[VEC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { ga[i] = 1.f; be[i] = 0.f; mu[i] = 0.f; rs[i] = 1.f; }
+    for (int i = 0; i < VEC; ++i) { ga[i] = 1.f; be[i] = 0.f; mu[i] = 0.f; rs[i] = 1.f; }
     if (active) {
-        const f32x4 a0 = *(const f32x4*)(gamma + c), a1 = *(const f32x4*)(gamma + c + 4);
-        const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { ga[i] = a0[i]; ga[4 + i] = a1[i]; be[i] = b0[i]; be[4 + i] = b1[i]; }
+        for (int i = 0; i < VEC; i += 2) {
+            const f32x2 a = *(const f32x2*)(gamma + c + i), bb = *(const f32x2*)(beta + c + i);
+            ga[i] = a[0]; ga[i + 1] = a[1]; be[i] = bb[0]; be[i + 1] = bb[1];
+        }
         if (MODE == 1) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < VEC; ++i) {
                 const int g = (c + i) / cg;
                 const float m = fstats[(b * G + g) * 2] * inv_n;
                 const float var = fstats[(b * G + g) * 2 + 1] * inv_n - m * m;
@@ -105,48 +163,48 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
         }
     }
     // ---- pass 1
-    float s1[8], s2[8];
+    float s1[VEC], s2[VEC];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-    u32x4 keep[NVR > 0 ? NVR : 1];
+    for (int i = 0; i < VEC; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
+    GnVec<VEC> keep[NVR > 0 ? NVR : 1];
     if (active && NVR > 0) {
 #pragma unroll
         for (int j = 0; j < NVR; ++j) {
             const int p = pl + j * PL;
-            keep[j] = gn_load(src, (int64_t)b * hw + (p < hw ? p : 0), c);      // (pl itself may lie beyond a small sample)
+            keep[j] = gn_loadv<VEC>(src, (int64_t)b * hw + (p < hw ? p : 0), c);      // (pl itself may lie beyond a small sample)
         }
 #pragma unroll
         for (int j = 0; j < NVR; ++j) {
             if (pl + j * PL < hw) {
-                float x[8];
-                unpack8(keep[j], x);
+                float x[VEC];
+                gn_unpack<VEC>(keep[j], x);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) { s1[i] += x[i]; s2[i] += x[i] * x[i]; }
+                for (int i = 0; i < VEC; ++i) { s1[i] += x[i]; s2[i] += x[i] * x[i]; }
             }
         }
     } else if (active) {
         for (int p0 = pl; p0 < hw; p0 += 4 * PL) {
-            u32x4 xv[4], dv[4];
+            GnVec<VEC> xv[4], dv[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = p0 + u * PL;
                 const int64_t row = (int64_t)b * hw + (p < hw ? p : p0);
-                xv[u] = gn_load(src, row, c);
-                if (MODE == 1) dv[u] = *(const u32x4*)(dy + row * lddy + c);
+                xv[u] = gn_loadv<VEC>(src, row, c);
+                if (MODE == 1) dv[u] = gn_loadp<VEC>(dy + row * lddy + c);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 if (p0 + u * PL >= hw) break;
-                float x[8];
-                unpack8(xv[u], x);
+                float x[VEC];
+                gn_unpack<VEC>(xv[u], x);
                 if (MODE == 0) {
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) { s1[i] += x[i]; s2[i] += x[i] * x[i]; }
+                    for (int i = 0; i < VEC; ++i) { s1[i] += x[i]; s2[i] += x[i] * x[i]; }
                 } else {
-                    float d[8];
-                    unpack8(dv[u], d);
+                    float d[VEC];
+                    gn_unpack<VEC>(dv[u], d);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
+                    for (int i = 0; i < VEC; ++i) {
                         const float xh = (x[i] - mu[i]) * rs[i];
                         float dz = d[i];
                         if (act) dz *= dsilu(xh * ga[i] + be[i]);
@@ -158,13 +216,13 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
             }
         }
     }
-    // ---- block reduction: the thread's 8 per-channel sums fold into the <= 4 groups of the run (registers), every wave
+    // ---- block reduction: the thread's per-channel sums fold into the <= 4 groups of the run (registers), every wave
     // reduces them with DPP adds (wave_sum: no LDS traffic), ONE exchange through LDS, and every thread adds the wave totals
     // in the same fixed order -- one barrier, bitwise reproducible (the round-2..5 form went through three LDS stages and
     // four barriers with serial 13- to 20-term chains of LDS reads: 3 - 5x the latency floor of these launches).
     f32x4 g1 = {0.f, 0.f, 0.f, 0.f}, g2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < VEC; ++i)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             g1[g] += gi[i] == g ? s1[i] : 0.f;
@@ -177,10 +235,13 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
     if ((tid & 63) == 0) { red[wv][0] = g1; red[wv][1] = g2; }
     __syncthreads();
     f32x4 gt1 = red[0][0], gt2 = red[0][1];
-    for (int w = 1; w < nwv; ++w) {
-        const f32x4 a = red[w][0], q = red[w][1];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { gt1[g] += a[g]; gt2[g] += q[g]; }
+    for (int w = 1; w < GN_MAX_WAVES; ++w) {          // (unrolled: all LDS reads in flight at once; same order for every thread)
+        if (w < nwv) {
+            const f32x4 a = red[w][0], q = red[w][1];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { gt1[g] += a[g]; gt2[g] += q[g]; }
+        }
     }
     if (tid < gpb) {
         const float t1v = tid == 0 ? gt1[0] : (tid == 1 ? gt1[1] : (tid == 2 ? gt1[2] : gt1[3]));
@@ -190,9 +251,9 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
     }
     if (!active) return;
     // ---- pass 2
-    float t1[8], t2[8];   // MODE 0: mean, rstd.  MODE 1: s1/n, s2/n
+    float t1[VEC], t2[VEC];   // MODE 0: mean, rstd.  MODE 1: s1/n, s2/n
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < VEC; ++i) {
         const int g = gi[i];
         const float q1 = (g == 0 ? gt1[0] : (g == 1 ? gt1[1] : (g == 2 ? gt1[2] : gt1[3]))) * inv_n;
         const float q2 = (g == 0 ? gt2[0] : (g == 1 ? gt2[1] : (g == 2 ? gt2[2] : gt2[3]))) * inv_n;
@@ -209,44 +270,44 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
         for (int j = 0; j < NVR; ++j) {
             const int p = pl + j * PL;
             if (p < hw) {
-                float x[8], o[8];
-                unpack8(keep[j], x);
+                float x[VEC], o[VEC];
+                gn_unpack<VEC>(keep[j], x);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < VEC; ++i) {
                     const float z = (x[i] - t1[i]) * t2[i] * ga[i] + be[i];
                     o[i] = act ? silu(z) : z;
                 }
-                *(u32x4*)(out + ((int64_t)b * hw + p) * ldo + c) = pack8(o);
+                gn_storev<VEC>(out + ((int64_t)b * hw + p) * ldo + c, o);
             }
         }
         return;
     }
     for (int p0 = pl; p0 < hw; p0 += 4 * PL) {
-        u32x4 xv[4], dv[4];
+        GnVec<VEC> xv[4], dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int p = p0 + u * PL;
             const int64_t row = (int64_t)b * hw + (p < hw ? p : p0);
-            xv[u] = gn_load(src, row, c);
-            if (MODE == 1) dv[u] = *(const u32x4*)(dy + row * lddy + c);
+            xv[u] = gn_loadv<VEC>(src, row, c);
+            if (MODE == 1) dv[u] = gn_loadp<VEC>(dy + row * lddy + c);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int p = p0 + u * PL;
             if (p >= hw) break;
-            float x[8], o[8];
-            unpack8(xv[u], x);
+            float x[VEC], o[VEC];
+            gn_unpack<VEC>(xv[u], x);
             if (MODE == 0) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < VEC; ++i) {
                     const float z = (x[i] - t1[i]) * t2[i] * ga[i] + be[i];
                     o[i] = act ? silu(z) : z;
                 }
             } else {
-                float d[8];
-                unpack8(dv[u], d);
+                float d[VEC];
+                gn_unpack<VEC>(dv[u], d);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < VEC; ++i) {
                     const float xh = (x[i] - mu[i]) * rs[i];
                     float dz = d[i];
                     if (act) dz *= dsilu(xh * ga[i] + be[i]);
@@ -254,7 +315,7 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
                     o[i] = rs[i] * (dxh - t1[i] - xh * t2[i]);
                 }
             }
-            *(u32x4*)(out + ((int64_t)b * hw + p) * ldo + c) = pack8(o);
+            gn_storev<VEC>(out + ((int64_t)b * hw + p) * ldo + c, o);
         }
     }
 }
@@ -427,27 +488,6 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
     const int tid = (int)threadIdx.x, b = (int)blockIdx.y, cg = C / G;
     const int na0 = src.c0 / A, na1 = (C - src.c0) / A, ag = cg / A;        // atoms of x0 / x1, atoms per group
     __shared__ float part[GN_MAX_GROUPS * 8 * 2];
-    // Thread = (row lane, 16-byte channel vector).  The first four pixels of the first column sweep and their gamma / beta
-    // are FETCHED BEFORE the statistics are folded (they do not depend on them): the block's three dependent memory round
-    // trips (atom sums -> gamma / beta -> pixels) become one (round 6; a block normalises 16 .. 64 pixel rows, i.e. the
-    // prefetch is usually all of its input).
-    const int nvec = C / 8;
-    const int p0 = (int)blockIdx.x * rows_per_block;
-    const int p1 = min(hw, p0 + rows_per_block);
-    const int nvc_f = min(256, nvec), rows_par_f = 256 / nvc_f;
-    const int rl_f = tid / nvc_f, c_f = (tid - rl_f * nvc_f) * 8;
-    const bool pre_ok = rl_f < rows_par_f && p0 + rl_f < p1;
-    u32x4 pre[4];
-    f32x4 pg0 = {0.f, 0.f, 0.f, 0.f}, pg1 = pg0, pb0 = pg0, pb1 = pg0;
-    if (pre_ok) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int p = p0 + rl_f + u * rows_par_f;
-            pre[u] = gn_load(src, (int64_t)b * hw + (p < p1 ? p : p0 + rl_f), c_f);
-        }
-        pg0 = *(const f32x4*)(gamma + c_f); pg1 = *(const f32x4*)(gamma + c_f + 4);
-        pb0 = *(const f32x4*)(beta + c_f); pb1 = *(const f32x4*)(beta + c_f + 4);
-    }
     {   // 8 threads per group, each over every 8th channel of the group, combined in a fixed order: all blocks of a sample
         // arrive at bit-identical group statistics
         const int g = tid >> 3, pt = tid & 7;
@@ -477,19 +517,19 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
         }
     }
     __syncthreads();
-    // the per-channel scale / shift a = rstd gamma, b = beta - mean a of a thread's 8 channels live in registers, so the pixel
-    // loop is load -> 8 fma (+ SiLU) -> store with no index arithmetic.
+    // Thread = (row lane, 16-byte channel vector): the per-channel scale / shift a = rstd gamma, b = beta - mean a of its 8
+    // channels live in registers, so the pixel loop is load -> 8 fma (+ SiLU) -> store with no index arithmetic.
+    const int nvec = C / 8;
+    const int p0 = (int)blockIdx.x * rows_per_block;
+    const int p1 = min(hw, p0 + rows_per_block);
     for (int v0 = 0; v0 < nvec; v0 += 256) {
         const int nvc = min(256, nvec - v0), rows_par = 256 / nvc;
         const int rl = tid / nvc, c = (v0 + tid - rl * nvc) * 8;
         if (rl >= rows_par) continue;
         float sa[8], sb[8];
         {
-            f32x4 g0 = pg0, g1 = pg1, b0 = pb0, b1 = pb1;
-            if (v0 != 0 || !pre_ok) {
-                g0 = *(const f32x4*)(gamma + c); g1 = *(const f32x4*)(gamma + c + 4);
-                b0 = *(const f32x4*)(beta + c); b1 = *(const f32x4*)(beta + c + 4);
-            }
+            const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+            const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int g = (c + i) / cg;
@@ -499,11 +539,10 @@ __global__ __launch_bounds__(256) void gn_apply_stats_kernel(GnSrc src, const fl
         }
         for (int pr = p0 + rl; pr < p1; pr += 4 * rows_par) {
             u32x4 xv[4];
-            const bool first = v0 == 0 && pr == p0 + rl;          // (pre_ok holds: pr < p1)
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int p = pr + u * rows_par;
-                xv[u] = first ? pre[u] : gn_load(src, (int64_t)b * hw + (p < p1 ? p : pr), c);
+                xv[u] = gn_load(src, (int64_t)b * hw + (p < p1 ? p : pr), c);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -753,18 +792,20 @@ int pix_per_block(int batch, int hw, int c) {
     return ppb < 12 ? 12 : ppb;
 }
 // launch geometry of gn_block_kernel: groups per block (channel span % 8 == 0), threads, LDS bytes
-struct GnGeom { int gpb, threads, lds; };
-GnGeom gn_geom(int hw, int C, int G) {
+struct GnGeom { int gpb, threads, lds, vec; };
+GnGeom gn_geom_vec(int hw, int C, int G, int vec) {
     const int cg = C / G;
     int gpb = 1;
-    while ((gpb * cg) % 8) gpb *= 2;                 // cg even (C % 8 == 0, G = 2^k): gpb in {1, 2, 4}
-    const int nv = gpb * cg / 8;
+    while ((gpb * cg) % vec) gpb *= 2;               // cg even (C % 8 == 0, G = 2^k): gpb in {1, 2, 4}
+    const int nv = gpb * cg / vec;
     int64_t want = (int64_t)hw * nv;                 // one thread per (pixel, vector) if the block allows it
     int threads = want >= 1024 ? 1024 : (int)((want + 63) / 64 * 64);
     if (threads < 256) threads = 256;
     if (threads < nv) threads = (nv + 63) / 64 * 64;
-    return GnGeom{gpb, threads, 0};
+    return GnGeom{gpb, threads, 0, vec};
 }
+// the 16-byte-vector geometry: what decides between the one-launch and the three-launch / producer-statistics forms
+GnGeom gn_geom(int hw, int C, int G) { return gn_geom_vec(hw, C, G, 8); }
 // One block per (sample, group run) is the fastest shape while a block's slice stays small or there are
 // enough of them to fill the chip; large slices on few blocks (the 64x64 / 32x32 levels at batch 4) are
 // bandwidth-starved (measured 41 vs 22 us for 4 x 4096 x 320) and take the pixel-parallel three-launch path.
@@ -773,25 +814,43 @@ bool gn_use_block_kernel(const GnGeom& ge, int batch, int hw, int C, int G) {
     const int blocks = batch * (G / ge.gpb);
     return !(slice_bytes > 200 * 1024 && blocks < 96);
 }
-template <int MODE, int NVR>
+// The geometry a one-launch shape RUNS on: with 16-byte vectors a block is 40 channels wide at C = 320 / 640 / 960 (4 / 2 / 4
+// groups) -- 32 or 64 blocks at UNet batch 4; where fewer than 128 blocks would carry a tensor of >= 256 pixels per sample,
+// narrower vectors give one group per block (LECO_GN_VEC=8 keeps the 16-byte form: A/B measurements).
+GnGeom gn_geom_run(int batch, int hw, int C, int G) {
+    GnGeom ge = gn_geom_vec(hw, C, G, 8);
+    static const int forced = [] { const char* e = getenv("LECO_GN_VEC"); return e ? atoi(e) : 0; }();
+    if (forced == 8 || hw < 256) return ge;
+    for (int vec = 4; vec >= 2 && batch * (G / ge.gpb) < 128 && ge.gpb > 1; vec >>= 1) ge = gn_geom_vec(hw, C, G, vec);
+    return ge;
+}
+template <int MODE, int NVR, int VEC>
 void gn_launch_v(const GnGeom& ge, dim3 grid, hipStream_t s, GnSrc src, const bf16_t* dy, int64_t lddy,
                  const float* fstats, float* stats_out, const float* gamma, const float* beta, int act, float eps,
                  int hw, int C, int G, bf16_t* out, int64_t ldo) {
-    hipLaunchKernelGGL((gn_block_kernel<MODE, NVR>), grid, dim3(ge.threads), ge.lds, s, src, dy, lddy, fstats, stats_out,
+    hipLaunchKernelGGL((gn_block_kernel<MODE, NVR, VEC>), grid, dim3(ge.threads), ge.lds, s, src, dy, lddy, fstats, stats_out,
                        gamma, beta, act, eps, hw, C, G, ge.gpb, out, ldo);
+}
+template <int MODE, int VEC>
+void gn_launch_vec(const GnGeom& ge, dim3 grid, hipStream_t s, GnSrc src, const bf16_t* dy, int64_t lddy,
+                   const float* fstats, float* stats_out, const float* gamma, const float* beta, int act, float eps,
+                   int hw, int C, int G, bf16_t* out, int64_t ldo) {
+    if (MODE == 0) {      // forward: pixels per thread -> the register-resident instantiation that holds them (else two passes)
+        const int nv = ge.gpb * (C / G) / VEC, PL = ge.threads / nv, per = (hw + PL - 1) / PL;
+        static const bool off = [] { const char* e = getenv("LECO_GN_REGS"); return e && atoi(e) == 0; }();
+        if (!off && per <= 2) return gn_launch_v<0, 2, VEC>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+        if (!off && per <= 6) return gn_launch_v<0, 6, VEC>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+        if (!off && per <= 16) return gn_launch_v<0, 16, VEC>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+    }
+    return gn_launch_v<MODE, 0, VEC>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
 }
 template <int MODE>
 void gn_launch(const GnGeom& ge, dim3 grid, hipStream_t s, GnSrc src, const bf16_t* dy, int64_t lddy,
                const float* fstats, float* stats_out, const float* gamma, const float* beta, int act, float eps,
                int hw, int C, int G, bf16_t* out, int64_t ldo) {
-    if (MODE == 0) {      // forward: pixels per thread -> the register-resident instantiation that holds them (else two passes)
-        const int nv = ge.gpb * (C / G) / 8, PL = ge.threads / nv, per = (hw + PL - 1) / PL;
-        static const bool off = [] { const char* e = getenv("LECO_GN_REGS"); return e && atoi(e) == 0; }();
-        if (!off && per <= 2) return gn_launch_v<0, 2>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
-        if (!off && per <= 6) return gn_launch_v<0, 6>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
-        if (!off && per <= 16) return gn_launch_v<0, 16>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
-    }
-    return gn_launch_v<MODE, 0>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+    if (ge.vec == 4) return gn_launch_vec<MODE, 4>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+    if (ge.vec == 2) return gn_launch_vec<MODE, 2>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
+    return gn_launch_vec<MODE, 8>(ge, grid, s, src, dy, lddy, fstats, stats_out, gamma, beta, act, eps, hw, C, G, out, ldo);
 }
 }  // namespace
 }  // namespace leco
@@ -805,9 +864,9 @@ extern "C" int leco_groupnorm_fwd(const void* x0, int64_t ld0, const void* x1, i
     int rc = gn_check(c, groups, c0, x1);
     if (rc) return rc;
     GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
-    const GnGeom ge = gn_geom(hw, c, groups);
     hipStream_t s = (hipStream_t)stream;
-    if (gn_use_block_kernel(ge, batch, hw, c, groups)) {
+    if (gn_use_block_kernel(gn_geom(hw, c, groups), batch, hw, c, groups)) {
+        const GnGeom ge = gn_geom_run(batch, hw, c, groups);
         gn_launch<0>(ge, dim3(groups / ge.gpb, batch), s, src, (const bf16_t*)nullptr, (int64_t)0,
                      (const float*)nullptr, stats, gamma, beta, act, eps, hw, c, groups, (bf16_t*)y, ldy);
         return check_launch("leco_groupnorm_fwd");
@@ -873,9 +932,9 @@ extern "C" int leco_groupnorm_bwd(const void* x0, int64_t ld0, const void* x1, i
     int rc = gn_check(c, groups, c0, x1);
     if (rc) return rc;
     GnSrc src{(const bf16_t*)x0, (const bf16_t*)x1, ld0, ld1, x1 ? c0 : c};
-    const GnGeom ge = gn_geom(hw, c, groups);
     hipStream_t s = (hipStream_t)stream;
-    if (gn_use_block_kernel(ge, batch, hw, c, groups)) {
+    if (gn_use_block_kernel(gn_geom(hw, c, groups), batch, hw, c, groups)) {
+        const GnGeom ge = gn_geom_run(batch, hw, c, groups);
         gn_launch<1>(ge, dim3(groups / ge.gpb, batch), s, src, (const bf16_t*)dy, lddy, stats, bstats,
                      gamma, beta, act, eps, hw, c, groups, (bf16_t*)dx, lddx);
         return check_launch("leco_groupnorm_bwd");

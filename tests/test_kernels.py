@@ -459,7 +459,9 @@ def test_groupnorm_from_channel_statistics(dev, act, B, HW, C0, C1, G, atom):
     (1, 2, 1100, 320, 0, 32),     # 6 pixels per thread: the register-resident forward (one read of the tensor), NVR = 6
     (0, 1, 1024, 640, 320, 32),   # 16 pixels per thread (cg = 30: 68 pixel lanes), NVR = 16, two-source
     (1, 1, 1150, 480, 480, 32),   # 17 pixels per thread: back to two passes
-    (1, 1, 2600, 320, 0, 32)])    # > 200 KB per (sample, group run) on few blocks: pixel-parallel three-launch path
+    (1, 1, 2600, 320, 0, 32),     # > 200 KB per (sample, group run) on few blocks: pixel-parallel three-launch path
+    (1, 2, 300, 640, 0, 32),      # cg = 20, >= 256 pixels, < 128 blocks: 8-byte vectors, one group per block (round 6)
+    (0, 2, 260, 320, 320, 32)])   # the same with the concat split between two of the 4-channel vectors' groups
 def test_groupnorm_fwd_bwd(dev, act, B, HW, C0, C1, G):
     torch.manual_seed(3)
     C = C0 + C1
