@@ -131,7 +131,14 @@ __global__ __launch_bounds__(1024) void gn_block_kernel(GnSrc src, const bf16_t*
                                                          bf16_t* out, int64_t ldo) {
     __shared__ f32x4 red[GN_MAX_WAVES][2];       // per wave: {sum, sumsq} of the block's <= 4 groups
     const int tid = (int)threadIdx.x, NT = (int)blockDim.x;
-    const int b = (int)blockIdx.y, g0 = (int)blockIdx.x * gpb;
+    // XCD-aware walk (round 6): a block's channel run is 20 - 80 bytes of every pixel row, so the 128-byte lines of the tensor
+    // are shared by the blocks of ADJACENT groups.  The hardware places linear workgroup id L on XCD L % 8; handing each XCD
+    // a contiguous run of (sample, group run) items makes neighbours meet in one L2 -- a line is fetched once and its
+    // partial-sector stores merge there, instead of three XCDs each fetching it and writing a piece of it back.
+    const int nbx = (int)gridDim.x, nitems = nbx * (int)gridDim.y;
+    int item = (int)blockIdx.y * nbx + (int)blockIdx.x;
+    if ((nitems & 7) == 0) item = (item & 7) * (nitems >> 3) + (item >> 3);
+    const int b = item / nbx, g0 = (item - b * nbx) * gpb;
     const int cg = C / G, chunkC = gpb * cg, nv = chunkC / VEC, cbase = g0 * cg;
     const int PL = NT / nv;                       // pixel lanes
     const int pl = tid / nv, v = tid - pl * nv;
@@ -570,11 +577,18 @@ __global__ __launch_bounds__(256) void colstats_kernel(const bf16_t* x, int64_t 
         float s1[8], s2[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { s1[i] = 0.f; s2[i] = 0.f; }
-        for (int p = p0; p < p1; ++p) {
-            float xv[8];
-            unpack8(*(const u32x4*)(x + ((int64_t)b * hw + p) * ld + v * 8), xv);
+        for (int p = p0; p < p1; p += 4) {          // four row loads in flight (the rolled loop was one dependent round trip per row)
+            u32x4 raw[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
+            for (int u = 0; u < 4; ++u) raw[u] = *(const u32x4*)(x + ((int64_t)b * hw + (p + u < p1 ? p + u : p)) * ld + v * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p + u >= p1) break;
+                float xv[8];
+                unpack8(raw[u], xv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { s1[i] += xv[i]; s2[i] += xv[i] * xv[i]; }
+            }
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) { csum[(v * 8 + i) * 2] = s1[i]; csum[(v * 8 + i) * 2 + 1] = s2[i]; }
