@@ -33,9 +33,29 @@ struct AttnArgs {
     float* lse;                // [B][H][Sq] natural-log sum-exp of the scaled scores
     int heads, sq, skv;
     float scale_log2;          // scale * log2(e)
+    int xcd_remap;             // 1: walk the (tile, head, sample) grid XCD-contiguously (attn_ids)
 };
 
 constexpr int KT = 64;  // keys per tile
+
+// Workgroup -> (tile along the sequence, head, sample).  The hardware places linear workgroup id L on XCD L % 8 (private
+// 4 MB L2 each).  With the plain (x = tile, y = head, z = sample) decoding the tiles of one (sample, head) are spread over
+// all eight XCDs, so every XCD pulls the K and V of EVERY head through its own L2: 8 x the fill traffic (335 MB instead of
+// 42 MB per level-0 self-attention launch at UNet batch 4).  Round 6: each XCD gets a contiguous run of (sample, head)
+// pairs with all of their tiles -- the K / V of its 4 heads (2.6 MB) stay in its L2.  LECO_ATTN_XCD=0: the plain decoding.
+__device__ __forceinline__ void attn_ids(int remap, int& xi, int& h, int& b) {
+    const int nx = (int)gridDim.x, H = (int)gridDim.y, items = nx * H * (int)gridDim.z;
+    int item = (int)blockIdx.x + nx * ((int)blockIdx.y + H * (int)blockIdx.z);
+    if (remap && (items & 7) == 0) item = (item & 7) * (items >> 3) + (item >> 3);
+    const int hb = item / nx;
+    xi = item - hb * nx;
+    b = hb / H;
+    h = hb - b * H;
+}
+inline int attn_xcd_default() {
+    static const int v = [] { const char* e = getenv("LECO_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    return v;
+}
 
 // Tuning aid (tools/ablate_attn.py): 1 = no exp2, 2 = no K/V staging, 3 = no PV MFMA, 4 = no QK MFMA.
 #ifndef LECO_ATTN_ABLATE
@@ -74,8 +94,9 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int h = (int)blockIdx.y, b = (int)blockIdx.z;
-    const int q0 = (int)blockIdx.x * (64 * QF) + wave * (16 * QF);
+    int bx, h, b;
+    attn_ids(p.xcd_remap, bx, h, b);
+    const int q0 = bx * (64 * QF) + wave * (16 * QF);
 
     const bf16_t* qb = p.q + (int64_t)b * p.bsq + (int64_t)h * D;
     const bf16_t* kb = p.k + (int64_t)b * p.bsk + (int64_t)h * D;
@@ -340,8 +361,9 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
     const int fr = lane & 15, fg = lane >> 4;
-    const int h = (int)blockIdx.y, b = (int)blockIdx.z;
-    const int q0 = (int)blockIdx.x * (64 * QF) + wave * (16 * QF);
+    int bx, h, b;
+    attn_ids(p.xcd_remap, bx, h, b);
+    const int q0 = bx * (64 * QF) + wave * (16 * QF);
     const bf16_t* qb = p.q + (int64_t)b * p.bsq + (int64_t)h * D;
     const bf16_t* kb = p.k + (int64_t)b * p.bsk + (int64_t)h * D;
     const bf16_t* vb = p.v + (int64_t)b * p.bsv + (int64_t)h * D;
@@ -604,6 +626,7 @@ struct AttnBwdArgs {
     int64_t lddq, lddk, lddv, bsdq, bsdk, bsdv;
     int heads, sq, skv;
     float scale, scale_log2;
+    int xcd_remap;
 };
 
 template <int D>
@@ -640,8 +663,9 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(2) void attn_bwd_dq_ke
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int h = (int)blockIdx.y, b = (int)blockIdx.z;
-    const int q0 = (int)blockIdx.x * 64 + wave * 16;
+    int bx, h, b;
+    attn_ids(p.xcd_remap, bx, h, b);
+    const int q0 = bx * 64 + wave * 16;
     const int qrow = q0 + fr;
     const bool qok = qrow < p.sq;
 
@@ -749,8 +773,9 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(2) void attn_bwd_dkv_k
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int h = (int)blockIdx.y, b = (int)blockIdx.z;
-    const int key = (int)blockIdx.x * 64 + wave * 16 + fr;
+    int bx, h, b;
+    attn_ids(p.xcd_remap, bx, h, b);
+    const int key = bx * 64 + wave * 16 + fr;
     const bool kok = key < p.skv;
 
     for (int e = tid; e < 2 * DV * TROW; e += 256) sQt[e] = 0;
@@ -920,7 +945,7 @@ extern "C" int leco_attention_fwd(const void* q, int64_t ldq, int64_t bsq, const
     if (batch <= 0 || heads <= 0 || sq <= 0 || skv <= 0) return fail(-EINVAL, "attention: empty problem");
     if ((ldq | ldk | ldv | ldo | bsq | bsk | bsv | bso) % 8) return fail(-EINVAL, "attention: strides must be multiples of 8 elements");
     AttnArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, ldq, ldk, ldv, bsq, bsk, bsv,
-               (bf16_t*)o, ldo, bso, lse, heads, sq, skv, scale * 1.4426950408889634f};
+               (bf16_t*)o, ldo, bso, lse, heads, sq, skv, scale * 1.4426950408889634f, attn_xcd_default()};
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {
         case 32: return launch_fwd<32>(a, batch, s);
@@ -945,7 +970,7 @@ extern "C" int leco_attention_bwd(const void* q, int64_t ldq, int64_t bsq, const
     AttnBwdArgs a{(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)o, (const bf16_t*)d_o,
                   ldq, ldk, ldv, ldo, lddo, bsq, bsk, bsv, bso, bsdo, lse, delta,
                   (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, lddq, lddk, lddv, bsdq, bsdk, bsdv,
-                  heads, sq, skv, scale, scale * 1.4426950408889634f};
+                  heads, sq, skv, scale, scale * 1.4426950408889634f, attn_xcd_default()};
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {
         case 32: return launch_bwd<32>(a, batch, s);
