@@ -216,8 +216,7 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
                     }
                     mx = fmaxf(mx, acc_s[u][f][r]);
                 }
-            mx = fmaxf(mx, shfl_xor(mx, 16));
-            mx = fmaxf(mx, shfl_xor(mx, 32));
+            mx = rows4_max(mx);
             const float m_new = fmaxf(m_run[u], mx * p.scale_log2);     // scale > 0: max and scale commute
             alpha[u] = fast_exp2(m_run[u] - m_new);
             m_run[u] = m_new;
@@ -278,8 +277,7 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
             l = shfl(acc_o[u][D / 16][D % 4], fr + 16 * ((D % 16) / 4));
         } else {
             l = l_run[u];
-            l += shfl_xor(l, 16);
-            l += shfl_xor(l, 32);
+            l = rows4_sum(l);
         }
         const float inv = 1.f / l;
         const int qrow = q0 + u * 16 + fr;
@@ -517,8 +515,7 @@ __global__ __launch_bounds__(256) LECO_MIN_WAVES_PER_SIMD(D <= 40 ? LECO_ATTN_OC
             for (int f = 0; f < 4; ++f)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, acc_s[u][f][r]);
-            mx = fmaxf(mx, shfl_xor(mx, 16));
-            mx = fmaxf(mx, shfl_xor(mx, 32));
+            mx = rows4_max(mx);
             m_new[u] = fmaxf(m_run[u], mx * p.scale_log2);
             grow |= !(m_new[u] - m_run[u] <= 8.f);
         }

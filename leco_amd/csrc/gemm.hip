@@ -899,6 +899,8 @@ void splitk_finish_launch(const leco_gemm_args& a, const float* ws, int splits, 
 }
 }  // namespace leco
 
+// (round 6) 11 = 128x64: 160 workgroups where 64x64 tiles need 320 on 256 CUs and 128x128 tiles leave two thirds of the chip idle
+// (M = 1024, N = 1280): 28 % fewer operand bytes through the busiest CU's port than the 64x64 tiling.
 // tile: 0 = heuristic (-1: heuristic restricted to the implicit-GEMM kernel), 1 = 128x128 (wave shape by grid size), 2 = 128x160, 3 = 64x64, 4 = 256x128, 5 = 128x128 as
 // 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU; 7..10 = the patch-staged 3x3 / stride-1
 // convolution (conv_patch.hip) on 256x128 / 128x160 / 128x128 / 256x160 tiles -- problems it does not cover (other
@@ -940,7 +942,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         }
     }
     const int bm = tile == 3 ? 64 : ((tile == 4 || tile == 7 || tile == 10) ? 256 : 128);
-    const int bn = tile == 3 ? 64 : ((tile == 2 || tile == 8 || tile == 10) ? 160 : 128);   // 1, 5, 6, 9: 128x128
+    const int bn = (tile == 3 || tile == 11) ? 64 : ((tile == 2 || tile == 8 || tile == 10) ? 160 : 128);   // 1, 5, 6, 9: 128x128; 11: 128x64
     const long tiles = (long)cdiv(m, bm) * cdiv(n, bn);
     if (split_k == 0) {
         split_k = 1;
@@ -1004,6 +1006,7 @@ extern "C" int leco_gemm_ex(const leco_gemm_args* args, int tile, int split_k, v
         case 4: return launch<256, 128>(*args, split_k, (float*)workspace, s);
         case 5: return launch<128, 128>(*args, split_k, (float*)workspace, s, 1);
         case 6: return launch<128, 128>(*args, split_k, (float*)workspace, s, 2);
+        case 11: return launch<128, 64>(*args, split_k, (float*)workspace, s);
         default: return fail(-EINVAL, "leco_gemm: bad tile id %d", tile);
     }
 }

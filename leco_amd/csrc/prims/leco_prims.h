@@ -199,6 +199,31 @@ __device__ __forceinline__ float wave_sum(float v) {
     const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(bits, 48));
     return (r0 + r1) + (r2 + r3);
 }
+// Reductions over the FOUR 16-lane rows of a wave (lanes l, l ^ 16, l ^ 32, l ^ 48 -- the lanes that hold one query row's
+// scores in the swapped-operand MFMA layout) with gfx950's v_permlane16_swap / v_permlane32_swap: a VALU exchange of two
+// registers' rows instead of two ds_bpermute round trips through the LDS pipe per reduction.  With both operands = v,
+// permlane16_swap returns {rows v0 v0 v2 v2, rows v1 v1 v3 v3}, permlane32_swap {lo lo, hi hi}: combining the pair gives
+// both partners the same value.
+// (Inline asm: with `__builtin_amdgcn_permlane16_swap` hipcc 7.2 folds the two results of the swap into one -- max(a0, a1)
+// became a0 and a0 + a1 became a1 + a1 in the ISA -- although they differ lane by lane.  `s_nop 1`: the wait states hipcc
+// itself puts between a VALU write of an operand and the swap.)
+__device__ __forceinline__ void permlane16_swap(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void permlane32_swap(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ float rows4_max(float v) {
+    // (the max rides in the asm block: on asm outputs the compiler would first canonicalise both operands of an fmaxf)
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    float c = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(c));
+    return a;
+}
+__device__ __forceinline__ float rows4_sum(float v) {
+    float a = v, b = v;
+    permlane16_swap(a, b);
+    float c = a + b, d = c;
+    permlane32_swap(c, d);
+    return c + d;
+}
 // two fp32 fused multiply-adds in one instruction (v_pk_fma_f32); true when the predicate holds in any lane of the wave
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }

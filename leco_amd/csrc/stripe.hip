@@ -402,8 +402,7 @@ struct Stripe {
                             s += pass ? d * d : d;
                         }
                     }
-                s += shfl_xor(s, 16);
-                s += shfl_xor(s, 32);
+                s = rows4_sum(s);
                 if (fg == 0) part[(16 * i + fr) * 8 + wave] = s;
             }
             barrier_keep_dma();
@@ -641,8 +640,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
                     }
                     sc[f] = a;
                 }
-                mx = fmaxf(mx, shfl_xor(mx, 16));
-                mx = fmaxf(mx, shfl_xor(mx, 32));
+                mx = rows4_max(mx);
                 const float mneg = mx * p.scale_log2;
                 u32x4 pw[3];
                 float rs = 0.f;
@@ -668,8 +666,7 @@ __global__ __launch_bounds__(512) void xblock_tail_kernel(const XTailArgs p) {
                     l = shfl(o[D / 16][D % 4], fr + 16 * ((D % 16) / 4));
                 } else {
                     l = rs;
-                    l += shfl_xor(l, 16);
-                    l += shfl_xor(l, 32);
+                    l = rows4_sum(l);
                 }
                 const float inv = 1.f / l;
 #pragma unroll

@@ -60,7 +60,7 @@ def candidates(g: GemmArgs, has_ws: bool):
     nk = g.k // 64
     plain = g.a_mode == 0
     geglu = g.act == hip.ACT_GEGLU
-    tiles = [1, 4, 5, 6] if geglu else [1, 2, 3, 4] + ([5, 6] if plain else [])
+    tiles = [1, 4, 5, 6] if geglu else [1, 2, 3, 4] + ([5, 6, 11] if plain else [])
     out = [(0, 0)]                                   # the C heuristic itself
     if g.a_mode in (hip.A_CONV3_S1, hip.A_CONV3_UP2) and not g.t_w:      # (K-extension launches included: conv_patch.hip carries a_ext)
         # patch-staged kernel (conv_patch.hip): tile ids 7..10; K splits are whole 64-channel chunks
@@ -73,7 +73,7 @@ def candidates(g: GemmArgs, has_ws: bool):
             if has_ws and blocks < 256:
                 out += [(t, sp) for sp in (2, 3, 4, 5, 6, 8, 10, 12, 16) if blocks * sp <= 768 and sp <= chunks]
     for t in tiles:
-        bm, bn = {1: (128, 128), 2: (128, 160), 3: (64, 64), 4: (256, 128), 5: (128, 128), 6: (128, 128)}[t]
+        bm, bn = {1: (128, 128), 2: (128, 160), 3: (64, 64), 4: (256, 128), 5: (128, 128), 6: (128, 128), 11: (128, 64)}[t]
         blocks = -(-g.m // bm) * -(-g.n // bn)
         if t == 2 and g.n % 160 and g.n > 160:
             continue

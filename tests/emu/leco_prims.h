@@ -202,6 +202,16 @@ static inline float wave_sum(float v) {
     const float r0 = shfl(v, 0), r1 = shfl(v, 16), r2 = shfl(v, 32), r3 = shfl(v, 48);
     return (r0 + r1) + (r2 + r3);
 }
+// v_permlane16_swap / v_permlane32_swap reductions over the four 16-lane rows (same pairing: rows (0,1), (2,3), then halves)
+static inline float rows4_max(float v) { v = fmaxf(v, shfl_xor(v, 16)); return fmaxf(v, shfl_xor(v, 32)); }
+static inline float rows4_sum(float v) {
+    const float a = shfl_xor(v, 16);
+    const int l = emu::lane();
+    // the hardware adds (even row's value) + (odd row's value), then (lower half) + (upper half): the same operand order here
+    float m = ((l >> 4) & 1) ? a + v : v + a;
+    const float b = shfl_xor(m, 32);
+    return (l >> 5) ? b + m : m + b;
+}
 static inline float fast_exp2(float x) { return exp2f(x); }
 static inline float fast_rcp(float x) { return 1.0f / x; }
 }  // namespace leco

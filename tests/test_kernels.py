@@ -23,7 +23,7 @@ def _sync(dev):
 
 
 @pytest.mark.parametrize("tile,M,N,K", [(3, 100, 72, 128), (1, 300, 136, 192), (2, 200, 320, 64), (0, 70, 64, 64),
-                                        (1, 128, 128, 64), (2, 256, 160, 128)])
+                                        (1, 128, 128, 64), (2, 256, 160, 128), (11, 300, 136, 192), (11, 128, 64, 64)])
 def test_gemm_plain_full_epilogue(dev, tile, M, N, K):
     torch.manual_seed(0)
     a = torch.randn(M, K).to(bf).to(dev); w = (torch.randn(N, K) / K ** 0.5).to(bf).to(dev)
@@ -40,7 +40,7 @@ def test_gemm_plain_full_epilogue(dev, tile, M, N, K):
     assert rel_err(out, ref) < TOLBF
 
 
-@pytest.mark.parametrize("tile,split", [(1, 3), (3, 4), (2, 2), (0, 0), (4, 2), (4, 1)])
+@pytest.mark.parametrize("tile,split", [(1, 3), (3, 4), (2, 2), (0, 0), (4, 2), (4, 1), (11, 2)])
 def test_gemm_split_k_with_epilogue_and_lora_tile(dev, tile, split):
     torch.manual_seed(11)
     M, N, K = 200, 320, 1152
@@ -59,6 +59,7 @@ def test_gemm_split_k_with_epilogue_and_lora_tile(dev, tile, split):
 @pytest.mark.parametrize("tile,t_rows,split,M,N,K", [
     (1, 16, 1, 300, 256, 320), (1, 32, 1, 300, 256, 320), (2, 16, 1, 200, 320, 192), (2, 32, 1, 200, 320, 192),
     (3, 16, 1, 77, 64, 128), (3, 32, 1, 150, 72, 128), (4, 16, 1, 520, 256, 256), (4, 32, 1, 300, 128, 256),
+    (11, 16, 1, 300, 136, 320), (11, 32, 1, 300, 128, 256),      # 128 x 64 tile (round 6)
     (1, 16, 1, 2600, 640, 128),      # > 384 workgroups: the 2-buffer variant
     (0, 16, 0, 256, 256, 2048),      # heuristic wants split-K: falls back to the separate projection
     (0, 32, 0, 130, 200, 64)])
