@@ -157,7 +157,8 @@ int leco_lora_wgrad_grouped(const leco_wgrad_problem* problems, int32_t nproblem
                             int32_t max_rank, leco_stream_t stream);
 
 /* same as leco_gemm with an explicit tile choice: 0 heuristic, 1 = 128x128 (wave shape by grid size), 2 = 128x160,
- * 3 = 64x64, 4 = 256x128, 5 = 128x128 as 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU
+ * 3 = 64x64, 4 = 256x128, 5 = 128x128 as 4-wave workgroups (two per CU), 6 = 128x128 as one 8-wave workgroup per CU,
+ * 11 = 128x64 (7..10: the patch-staged 3x3 convolution kernels, conv_patch.hip)
  * (tests / the launch-shape tuner leco_amd/tune.py). */
 int leco_gemm_tile(const leco_gemm_args* args, int tile, leco_stream_t stream);
 /* full form: additionally split_k (0 = heuristic, 1 = none, n = that many K slices) with a
