@@ -640,7 +640,7 @@ def main():
     # --strict_reference): reported beside the headline, never as the headline -- the headline executes the reference's own
     # k + 3 + 1 CFG-doubled passes.  Two untimed steps first (plan build + graph capture).
     dedup_out = None
-    if not args.no_dedup and not args.dominant_only and not emu:
+    if not args.no_dedup and not args.dominant_only:
         fused.dedup = True
         for i in range(min(2, args.warmup + args.steps)):
             one(i)

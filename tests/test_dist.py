@@ -4,6 +4,7 @@ gradient slab.  Afterwards the parameters must be identical on both ranks and eq
 run that averages the two ranks' gradients."""
 import contextlib
 import io
+import math
 import os
 import sys
 
@@ -194,6 +195,8 @@ def test_bench_multi_gpu_launch_path_dry_run():
     assert len(lines) == 1, r.stdout[-2000:]          # rank 0 only, one line
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    # the second timed loop (de-duplicated pass structure) ran on both ranks too: same collectives, its own line
+    assert out["dedup"]["distinct_frozen_prompts"] == 2 and math.isfinite(out["dedup"]["loss"]) and out["dedup"]["value"] > 0
     assert out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
     assert out["config"]["collectives_per_step"] == 1.0 and out["config"]["k_identical_across_ranks"] is True
     assert abs(out["value"] - 2 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-6 * out["value"]
