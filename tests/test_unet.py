@@ -226,6 +226,46 @@ def test_dedup_step_equals_the_faithful_step(dev, same_prompts, bs):
         assert rel_err(d["params"], GOLD["step.params_after"]) < 1e-2
 
 
+def test_plans_shared_by_shape_survive_foreign_writers_and_second_drivers(dev):
+    """Plans are shared through `Engine.plans` by shape (round-5 advisor findings).  (1) `Plan.set_ctx` is the one writer of the
+    prompt-context buffer: an anonymous write between two steps of the same prompt pair invalidates the identity token, so the
+    next step copies the pair's context again instead of keeping the foreign rows.  (2) A second FusedStep on the same engine
+    with another `max_denoising_steps` gets the SAME denoising plan object: its per-pass list and timestep table must not leak
+    into the first one's steps."""
+    m = hip_unet(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = LoRANetwork(m, rank=4, multiplier=1.0, alpha=1.0)
+    load_lora(net)
+    emb = _golden_emb()
+    settings = prompt_util.PromptSettings(target="t", positive="p", neutral="n", unconditional="u", guidance_scale=2.0,
+                                          batch_size=BS, resolution=128, action="erase")
+    pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["target"], emb["positive"], emb["unconditional"],
+                                        emb["neutral"], settings)
+    fa = FusedStep(m, net, create_noise_scheduler("ddim"), N_STEPS, lr=0.0, weight_decay=0.0)
+    l0 = fa.step(pair, K, GOLD["latents"].clone()).item()
+    x0 = fa._state[(BS, 16, 16)]["x"].clone()
+    st = fa._state[(BS, 16, 16)]
+    want = st["dplan"].ctx.clone()
+    # (1) a foreign, anonymous writer
+    for pl in (st["dplan"], st["plan"], st["fplan"]):
+        pl.set_ctx(torch.full_like(pl.ctx, 3.0))
+        assert pl.ctx_src is None
+    l1 = fa.step(pair, K, GOLD["latents"].clone()).item()
+
+    def same(la, xa):      # bitwise on the emulator; on the GPU the producer-side GroupNorm statistics are fp32 atomics (DESIGN 4)
+        if dev.type == "cpu":
+            return la == l0 and torch.equal(xa, x0)
+        return abs(la - l0) / l0 < 3e-2 and rel_err(xa, x0) < 1e-2
+    assert torch.equal(st["dplan"].ctx, want) and same(l1, fa._state[(BS, 16, 16)]["x"])
+    # (2) a second driver of the same plans, with another schedule length
+    fb = FusedStep(m, net, create_noise_scheduler("ddim"), 2 * N_STEPS, lr=0.0, weight_decay=0.0)
+    assert fb._bucket(BS, 16, 16)["dplan"] is st["dplan"]
+    lb = fb.step(pair, K, GOLD["latents"].clone()).item()
+    assert abs(lb - l0) / l0 > 5e-2                             # (a different timestep table: a different denoising chain)
+    l2 = fa.step(pair, K, GOLD["latents"].clone()).item()
+    assert same(l2, fa._state[(BS, 16, 16)]["x"])
+
+
 def test_c3lier_conv_and_time_emb_lora_forward_backward(dev):
     """network.type = c3lier (BASELINE config 4): LoRA on ResnetBlock2D conv1/conv2/conv_shortcut/time_emb_proj and the
     Down/Upsample2D convs (3x3 conv lora_down, stride 2 and nearest-2x variants included) + the transformer linears."""
