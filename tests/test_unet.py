@@ -910,6 +910,18 @@ def test_single_file_checkpoint_runs_through_the_hip_unet(dev, tmp_path):
     y1 = loaded(x, torch.tensor(500), encoder_hidden_states=ctx).sample.float().cpu()
     assert loaded.cfg.attention_head_dim == cfg.attention_head_dim and loaded.cfg.use_linear_projection
     assert torch.equal(y0, y1) and torch.isfinite(y1).all() and float(y1.abs().mean()) > 1e-3
+    # ... and not only "the HIP path against itself" (round-5 verdict): the fp32 ORACLE, holding the state dict the converter
+    # produced from the FILE, gives the same prediction up to the bf16 error of the oracle graph itself
+    from leco_amd import ckpt_convert as cc2
+    sd_file = cc2.read_checkpoint(path)
+    rcfg = R.UNetConfig(**{k: getattr(loaded.cfg, k) for k in R.UNetConfig.__dataclass_fields__ if hasattr(loaded.cfg, k)})
+    ref = R.UNet2DConditionModel(rcfg)
+    missing, unexpected = ref.load_state_dict(cc2.convert_ldm_unet(sd_file, loaded.cfg), strict=False)
+    assert not missing and not unexpected
+    with torch.no_grad():
+        gold = ref(x.float().cpu(), torch.tensor(500), encoder_hidden_states=ctx.float().cpu()).sample
+        cal = rel_err(ref.to(bf)(x.cpu(), torch.tensor(500), encoder_hidden_states=ctx.cpu()).sample, gold)
+    assert rel_err(y1, gold) <= 1.25 * cal, (rel_err(y1, gold), cal)
     with contextlib.redirect_stdout(io.StringIO()):
         net = LoRANetwork(loaded, rank=4, multiplier=1.0, alpha=1.0)
     with contextlib.redirect_stdout(io.StringIO()):
