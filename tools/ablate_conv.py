@@ -47,19 +47,42 @@ def run_case():
         e1.record()
         e1.synchronize()
         us = e0.elapsed_time(e1) / 30 * 1e3
-        print(f"{name:32s} {us:7.1f} us  {2.0 * m * cout * k / us / 1e6:7.1f} TFLOP/s", flush=True)
+        extra = ""
+        if os.environ.get("LECO_CONV_STAMPS"):       # a build with LECO_CONV_ABLATE & 32: workgroup 0's shader-clock stamps
+            torch.cuda.synchronize()
+            pro, loop, epi, rt = y.view(torch.int64).flatten()[:4].tolist()
+            extra = (f"   wg0: prologue {pro} / tap loop {loop} / epilogue {epi} shader cycles, {rt / 100.0:.1f} us wall"
+                     f" -> {(pro + loop + epi) / max(rt, 1) * 0.1:.2f} GHz")
+        print(f"{name:32s} {us:7.1f} us  {2.0 * m * cout * k / us / 1e6:7.1f} TFLOP/s{extra}", flush=True)
+
+
+WHAT = {0: "product build", 1: "no LDS fragment reads", 2: "no MFMAs", 4: "no wait for the weight DMA", 8: "no barrier in the tap step",
+        16: "no steady-state DMA", 32: "clock stamps"}
+
+
+def describe(v):
+    return " + ".join(WHAT[b] for b in (1, 2, 4, 8, 16, 32) if v & b) or WHAT[0]
 
 
 if __name__ == "__main__":
     if "--build" in sys.argv:
-        for v in (1, 2):
-            print(build_variant(v))
+        i = sys.argv.index("--build")
+        vs = [int(x) for x in sys.argv[i + 1].split(",")] if len(sys.argv) > i + 1 else [1, 2]
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(4) as ex:
+            for out in ex.map(build_variant, vs):
+                print(out)
     elif "--case" in sys.argv:
         run_case()
     else:
-        for v, what in ((0, "product build"), (1, "no LDS fragment reads"), (2, "no MFMAs")):
-            env = dict(os.environ)
-            if v:
-                env["LECO_HIP_LIB"] = os.path.join(ROOT, "tools", "_ablate", f"libleco_convablate{v}.so")
-            print(f"# {what}", flush=True)
-            subprocess.run([sys.executable, os.path.abspath(__file__), "--case"], env=env)
+        d = os.path.join(ROOT, "tools", "_ablate")
+        have = sorted(int(f[len("libleco_convablate"):-3]) for f in os.listdir(d) if f.startswith("libleco_convablate"))
+        for ks2 in ("0", "1"):
+            for v in [0] + have:
+                env = dict(os.environ, LECO_CONV_KS2=ks2)
+                if v:
+                    env["LECO_HIP_LIB"] = os.path.join(d, f"libleco_convablate{v}.so")
+                if v & 32:
+                    env["LECO_CONV_STAMPS"] = "1"
+                print(f"# LECO_CONV_KS2={ks2}  {v}: {describe(v)}", flush=True)
+                subprocess.run([sys.executable, os.path.abspath(__file__), "--case"], env=env)
