@@ -51,9 +51,6 @@ constexpr int BK = 64;
 #ifndef LECO_CONV_ABLATE
 #define LECO_CONV_ABLATE 0
 #endif
-#ifndef LECO_CONV_KS2_BP
-#define LECO_CONV_KS2_BP 0
-#endif
 
 struct PatchRt {
     int tiles_n, tiles_x, tiles_g;   // grid.x = tiles_g * tiles_x * tiles_n
@@ -86,23 +83,25 @@ struct PatchCfg {
 // tap (kh, kw) of output pixel (y, x) reads input pixel ((y + kh - 1) >> 1, (x + kw - 1) >> 1); -1 and H_in are the same
 // zero separator rows.
 //
-// KS2: the workgroup's 8 waves are 2 (M) x 2 (N) x 2 K-GROUPS instead of 4 (M) x 2 (N): a wave owns a (BM / 2) x (BN / 2)
-// tile (64 x 80 at 128 x 160) of ONE 32-channel half (ks = its group) of every 64-channel tap step.  Same MFMA count per
-// wave and step, but (FM + FN) fragment reads per step where the 4 x 2 layout needs 2 (FM / 2 + FN): 9 against 14 at
-// 128 x 160 -- the LDS -> register traffic is what bounds the tap loop (profiles/r05_ablate_conv.txt).  Price: the two groups'
-// partial sums meet once, through the epilogue's staging tile.  One fragment set per tap, the two sets alternate by tap
-// parity; 9 taps per chunk is odd, so the chunk loop is unrolled twice to keep the parity a compile-time constant.
-template <int BM, int BN, int NSW, bool UP2, bool KS2 = false>
-__global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p, const PatchRt rt) {
+// LW = 8: LOADER WAVES.  The workgroup gets 8 more waves (16 = 4 per SIMD) that do nothing but the LDS-DMA: a DMA instruction
+// holds its wave for ~100-150 cycles, and with the DMA in the MFMA waves' instruction streams those cycles come out of the
+// tap step (profiles/r06_ablate_conv.txt: the step costs 973 shader cycles against 655 with MFMAs alone).  Loader wave l owns
+// exactly the pieces MFMA wave l owns in the LW = 0 layout; per step it issues them, waits for weight tile t + 1 and joins the
+// step's barrier.  It leaves before the epilogue (a terminated wave no longer counts at s_barrier).
+template <int BM, int BN, int NSW, bool UP2, int LW = 0>
+__global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_gemm_args p, const PatchRt rt) {
+    static_assert(LW == 0 || LW == PatchCfg<BM, BN, NSW>::NW, "loader wave l takes over the pieces of MFMA wave l");
     using Cf = PatchCfg<BM, BN, NSW>;
     constexpr int NW = Cf::NW, NT = NW * 64;
-    constexpr int WM = KS2 ? BM / 2 : BM / 4, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int WM = BM / 4, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int APW = Cf::APW, GW = Cf::GW, GWT = Cf::GWT;
     constexpr bool RAGW = Cf::RAGW;
     constexpr int WTILE = Cf::WTILE, PBUF = Cf::PBUF, OFF_A = Cf::OFF_A, OFF_DUMP = Cf::OFF_DUMP;
     unsigned char* lds = dyn_lds();
-    unsigned long long clk[4] = {}, rtc[2] = {};     // (LECO_CONV_ABLATE & 32: shader-clock / 100 MHz stamps of workgroup 0)
-    if (LECO_CONV_ABLATE & 32) { clk[0] = __builtin_amdgcn_s_memtime(); rtc[0] = __builtin_amdgcn_s_memrealtime(); }
+#if LECO_CONV_ABLATE & 32
+    unsigned long long clk[4] = {}, rtc[2] = {};     // shader-clock / 100 MHz stamps of workgroup 0
+    clk[0] = __builtin_amdgcn_s_memtime(); rtc[0] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // ---- work decomposition: XCD-aware bijective remap (hardware places linear workgroup id b on XCD b % 8), split
     // major; inside a split the LARGER operand is what an XCD keeps to itself (N > M: m-fastest walk, an XCD owns a
@@ -119,8 +118,9 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     const int tile_g = tile_m / rt.tiles_x, tile_x = tile_m - tile_g * rt.tiles_x;
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-    const int kg = KS2 ? wave >> 2 : 0, kx = kg << 6;                // K group of this wave; its fragment reads flip bit 6
-    const int wave_m = KS2 ? (wave >> 1) & 1 : wave >> 1, wave_n = wave & 1;
+    const bool loader = LW > 0 && wave >= NW;                          // wave-uniform
+    const int dw = LW > 0 ? wave - NW : wave;                           // owner index of this wave's DMA pieces
+    const int wave_m = wave >> 1, wave_n = wave & 1;
     const int st_row = lane >> 3, st_pos = lane & 7;
     const int fr = lane & 15, fg = lane >> 4;
 
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     unsigned wvoff[GW];
 #pragma unroll
     for (int i = 0; i < GW; ++i) {
-        const int rl = (wave + NW * i) * 8 + st_row;
+        const int rl = (dw + NW * i) * 8 + st_row;
         const int n = n0 + rl;
         wvoff[i] = (rl < BN && n < N) ? (unsigned)n * (unsigned)p.ldw * 2u + cpos : DMA_OOB;
     }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
         const unsigned soff = (unsigned)(first ? cch : cch - k_split) * 2u;
         const unsigned dead = cabs < chunk_end ? 0u : DMA_OOB;
         const unsigned voff = (mul24(ppix[j], ld) * 2u + cpos) | (ppix[j] & DMA_OOB) | dead;
-        glds16_buf(first ? ra0 : ra1, voff, soff, lds + OFF_A + pb * PBUF + (wave + NW * j) * (8 * BK * 2));
+        glds16_buf(first ? ra0 : ra1, voff, soff, lds + OFF_A + pb * PBUF + (dw + NW * j) * (8 * BK * 2));
     };
     // weight tile of (chunk cabs, tap) into ring slot `slot`
     auto issue_w = [&](int cabs, int tap, int slot) {
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
         const unsigned dead = live ? 0u : DMA_OOB;
 #pragma unroll
         for (int i = 0; i < GW; ++i) {
-            const bool real = !RAGW || i < GW - 1 || (wave + NW * i) < GWT;     // wave-uniform
-            unsigned char* dst = real ? lds + slot * WTILE + (wave + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
+            const bool real = !RAGW || i < GW - 1 || (dw + NW * i) < GWT;     // wave-uniform
+            unsigned char* dst = real ? lds + slot * WTILE + (dw + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
             glds16_buf(rw, wvoff[i] | dead | (real ? 0u : DMA_OOB), soff, dst);
         }
     };
@@ -188,8 +188,8 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     auto issue_w1 = [&](int cabs, int tap, int slot, int i) {      // piece i of that tile
         const bool live = cabs < chunk_end;
         const unsigned soff = live ? (unsigned)(tap * cin + cabs * BK) * 2u : 0u;
-        const bool real = !RAGW || i < GW - 1 || (wave + NW * i) < GWT;         // wave-uniform
-        unsigned char* dst = real ? lds + slot * WTILE + (wave + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
+        const bool real = !RAGW || i < GW - 1 || (dw + NW * i) < GWT;         // wave-uniform
+        unsigned char* dst = real ? lds + slot * WTILE + (dw + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
         glds16_buf(rw, wvoff[i] | (live ? 0u : DMA_OOB) | (real ? 0u : DMA_OOB), soff, dst);
     };
 
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
         for (int i = 0; i < FM; ++i) {
             const int P = UP2 ? rp[UP2 ? i : 0][0] + cq[0] : abase[i] + dtap;
             aoff[i] = (P << 7) + ((fg ^ (P & 7)) << 4);
-            af[i] = lds_read16_async(base + (aoff[i] ^ kx));
+            af[i] = lds_read16_async(base + aoff[i]);
         }
     };
     auto read_a1 = [&](int pb, bf16x8 (&af)[FM]) {
@@ -262,13 +262,13 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     // float reciprocal (operands < 2^18, validated on the host): a 32-bit division is ~40 instructions, and the table
     // needs 2 APW of them per lane.
     auto divf = [](int a, float rcp) { return (int)(((float)a + 0.5f) * rcp); };
-    if (chunk_begin < chunk_end) {
+    if (chunk_begin < chunk_end && (LW == 0 || loader)) {
 #pragma unroll
         for (int s_ = 0; s_ < NSW - 1; ++s_) issue_w(chunk_begin, s_, s_);
         const float rpw = 1.0f / (float)PW, rh1 = 1.0f / (float)(HD + 1);
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
-            const int q = (wave + NW * j) * 8 + st_row;
+            const int q = (dw + NW * j) * 8 + st_row;
             const int srow = divf(q, rpw), scol = q - srow * PW;
             const int v = VLO + srow;
             const int vb = v >= 0 ? divf(v, rh1) : 0, vy = v - vb * (HD + 1);
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             // for an out-of-range LDS-DMA lane or skips the lane
             if (!ok) {
                 const u32x4 z = {0u, 0u, 0u, 0u};
-                unsigned char* d = lds + OFF_A + (wave + NW * j) * (8 * BK * 2) + lane * 16;
+                unsigned char* d = lds + OFF_A + (dw + NW * j) * (8 * BK * 2) + lane * 16;
                 *(u32x4*)d = z;
                 *(u32x4*)(d + PBUF) = z;
             }
@@ -288,15 +288,84 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
 #pragma unroll
         for (int j = 0; j < APW; ++j) issue_a(j, chunk_begin, 0);
         wait_vmcnt<0>();
+    }
+    // K-extension operands (see below) into patch buffer 0 / ring slot 0
+    auto issue_ext = [&]() {
+        const buf_rsrc rax = make_rsrc(p.a_ext, rt.ax_bytes), rwx = make_rsrc(p.w_ext, rt.wx_bytes);
+        const unsigned xk_bytes = (unsigned)p.ext_k * 2u;
+#pragma unroll
+        for (int j = 0; j < BM / 64; ++j) {
+            const int r = (dw + NW * j) * 8 + st_row;                         // tile row = patch entry
+            const int g = g0 + (r >> TWl), xx = x0 + (r & (TW - 1));
+            const bool ok = g < GROWS && xx < W && cpos < xk_bytes;
+            const unsigned voff = ok ? (unsigned)(g * W + xx) * (unsigned)p.ld_aext * 2u + cpos : DMA_OOB;
+            glds16_buf(rax, voff, 0u, lds + OFF_A + (dw + NW * j) * (8 * BK * 2));
+        }
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            const int rl = (dw + NW * i) * 8 + st_row, n = n0 + rl;
+            const bool real = !RAGW || i < GW - 1 || (dw + NW * i) < GWT;     // wave-uniform
+            const bool ok = real && rl < BN && n < N && cpos < xk_bytes;
+            unsigned char* dst = real ? lds + (dw + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
+            glds16_buf(rwx, ok ? (unsigned)n * (unsigned)p.ld_wext * 2u + cpos : DMA_OOB, 0u, dst);
+        }
+        wait_vmcnt<0>();
+    };
+    if (LW > 0 && loader) {
+        // ---- the loader waves' whole life: the prologue DMA above, then per tap step the pieces of weight tile t + NSW - 1 (and
+        // of the next chunk's patch), the wait for tile t + 1 and the step's barrier
+        if (chunk_begin < chunk_end) barrier_only();
+        int slot = 0, pb = 0;
+        for (int c = chunk_begin; c < chunk_end; ++c) {
+            auto lstep = [&](auto tap_c) {
+                constexpr int tap = decltype(tap_c)::value;
+                constexpr int D = NSW - 1;
+                constexpr int tn = (tap + D) % 9, cn = (tap + D) / 9;
+                // DMAs younger than weight tile t + 1 (issued in step t + 1 - D) at this step's wait: steps t + 2 - D .. t
+                constexpr int younger = [] {
+                    int n = 0;
+                    for (int d = 0; d <= D - 2; ++d) n += GW + ((((tap - d) % 9 + 9) % 9) < APW ? 1 : 0);
+                    return n;
+                }();
+                const int sfill = slot == 0 ? NSW - 1 : slot - 1;
+                if (tap < APW) issue_a(tap, c + 1, pb ^ 1);
+#pragma unroll
+                for (int i = 0; i < GW; ++i) issue_w1(c + cn, tn, sfill, i);
+                wait_vmcnt<younger>();
+                barrier_only();
+                slot = slot + 1 == NSW ? 0 : slot + 1;
+            };
+            lstep(std::integral_constant<int, 0>{});
+            lstep(std::integral_constant<int, 1>{});
+            lstep(std::integral_constant<int, 2>{});
+            lstep(std::integral_constant<int, 3>{});
+            lstep(std::integral_constant<int, 4>{});
+            lstep(std::integral_constant<int, 5>{});
+            lstep(std::integral_constant<int, 6>{});
+            lstep(std::integral_constant<int, 7>{});
+            lstep(std::integral_constant<int, 8>{});
+            pb ^= 1;
+        }
+        wait_vmcnt<0>();
+        if (p.a_ext && split == 0) {
+            barrier_only();
+            issue_ext();
+            barrier_only();
+        }
+        return;
+    }
+    if (chunk_begin < chunk_end) {
         barrier_keep_dma();
         read_a0(0, 0, afA);
-        read_w(0, kg, wfA);
+        read_w(0, 0, wfA);
         lds_wait<0>();
         landed(afA, wfA);
     }
-    if (LECO_CONV_ABLATE & 32) clk[1] = __builtin_amdgcn_s_memtime();
+#if LECO_CONV_ABLATE & 32
+    clk[1] = __builtin_amdgcn_s_memtime();
+#endif
     int slot = 0, pb = 0;
-    for (int c = chunk_begin; c < chunk_end; c += KS2 ? 2 : 1) {
+    for (int c = chunk_begin; c < chunk_end; ++c) {
         // the tap offsets are loop invariant: without this the compiler hoists the fragment addresses of all 9 taps x FM
         // fragments (x 2 patch buffers) out of the loop and spills; recomputing them costs 5 VALU per read beside 2 FN MFMAs
 #pragma unroll
@@ -307,7 +376,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
         // out anywhere in the step.  They are spread evenly over the step's 2 FM FN MFMAs: a vector-memory instruction
         // occupies its wave for ~100-150 cycles (MI355X probe: ~14 GB/s of LDS-DMA per wave whatever the depth), and the two
         // waves of a SIMD run this stream in lockstep behind the barrier -- back-to-back pieces stall both, the matrix pipe idles.
-        auto step1 = [&](auto tap_c, const int c) {
+        auto step = [&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
             constexpr int D = NSW - 1;
             constexpr int tn = (tap + D) % 9, cn = (tap + D) / 9;                // the weight tile this step issues
@@ -352,7 +421,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
                 const int mm = m < P ? m : m - P, i = mm / FN, j = mm % FN;
                 if (m == P) {
                     sched_fence();
-                    if (!(LECO_CONV_ABLATE & 4)) wait_vmcnt<younger>();    // weight tile t + 1 (and, at tap 8, the next chunk's patch) landed
+                    if (LW == 0 && !(LECO_CONV_ABLATE & 4)) wait_vmcnt<younger>();    // weight tile t + 1 (and, at tap 8, the next chunk's patch) landed
                     if (!(LECO_CONV_ABLATE & 8)) barrier_keep_dma();       // ... for every wave; all waves are done with tile t's slot (completes set B)
                     else lds_wait<0>();
                     landed(afB, wfB);
@@ -372,7 +441,7 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
                 for (int d = 0; d < ND; ++d)
                     if (dpos(d, ND) == m) {
                         sched_fence();
-                        if (LECO_CONV_ABLATE & 16) {}
+                        if (LW > 0 || (LECO_CONV_ABLATE & 16)) {}
                         else if (tap < APW && d == 0) issue_a(tap, c + 1, pb ^ 1);
                         else issue_w1(c + cn, tn, sfill, d - (tap < APW ? 1 : 0));
                         sched_fence();
@@ -381,132 +450,23 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             sched_fence();
             slot = snext;
         };
-        // The KS2 step.  `par` = which fragment set holds this tap's operands (0: A, 1: B); the other set receives the next
-        // tap's.  A wave reads FN + FM fragments per step (its K half of weight tile t + 1 and of the patch), and what bounds the
-        // 4 x 2 layout is the LDS pipe (14 reads per wave and step = 112 KB per workgroup at 128 x 160 against 640 cycles of
-        // MFMA), so the reads must not come as one burst behind the barrier: the barrier sits at the START of the step (every
-        // wave's reads of tile t - 1 finished a step ago; tile t + 1 has landed) and the next set's reads are spread over the
-        // step's FM FN MFMAs.  The last of them may still be in flight when the next step begins: row i of the MFMA block waits
-        // for af[i] only (counted lgkmcnt waits; the LDS queue completes in order).
-        auto step2 = [&](auto tap_c, auto par_c, const int c) {
-            constexpr int tap = decltype(tap_c)::value, par = decltype(par_c)::value;
-            constexpr int D = NSW - 1;
-            constexpr int tn = (tap + D) % 9, cn = (tap + D) / 9;                // the weight tile this step issues
-            constexpr int ND = GW + (tap < APW ? 1 : 0), MF = FM * FN, NR = FN + FM;
-            constexpr int BP = LECO_CONV_KS2_BP;                                  // MFMA index the barrier sits in front of
-            // read r of the next set (weights first, then the activation fragments in row order) goes out in front of MFMA rpos(r)
-            constexpr auto rpos = [](int r) { return BP + (r * (MF - BP)) / NR; };
-            // DMA piece d goes out behind MFMA dpos(d) -- not in the last MFMAs before the next step's barrier, nor before this one's
-            constexpr auto dpos = [](int d, int nd) {
-                const int x = BP + ((2 * d + 1) * (MF - BP)) / (2 * nd) - 1;
-                return x > MF - 5 ? MF - 5 : (x < BP ? BP : x);
-            };
-            // DMAs younger than weight tile t + 1 (issued in step t + 1 - D) at this step's wait: steps t + 2 - D .. t - 1
-            constexpr int younger = [] {
-                int n = 0;
-                for (int d = 1; d <= D - 2; ++d) n += GW + ((((tap - d) % 9 + 9) % 9) < APW ? 1 : 0);
-                return n;
-            }();
-            const int dnext = ((tap + 1) % 9 / 3) * PW + (tap + 1) % 9 % 3;      // patch offset of the next step's tap
-            const int sfill = slot == 0 ? NSW - 1 : slot - 1;                    // slot of tile t - 1 = of tile t + NSW - 1
-            const int snext = slot + 1 == NSW ? 0 : slot + 1;
-            const int pbn = tap == 8 ? pb ^ 1 : pb;
-            const unsigned char* abuf = lds + OFF_A + pbn * PBUF;
-            const unsigned char* wbuf = lds + snext * WTILE + (wl0 ^ kx);
-            bf16x8 (&afC)[FM] = par ? afB : afA;
-            bf16x8 (&wfC)[FN] = par ? wfB : wfA;
-            bf16x8 (&afN)[FM] = par ? afA : afB;
-            bf16x8 (&wfN)[FN] = par ? wfA : wfB;
-            constexpr int khn = (tap + 1) % 9 / 3, kwn = (tap + 1) % 9 % 3;
-#pragma unroll
-            for (int q = 0; q < FM; ++q) {
-                const int Pq = UP2 ? rp[UP2 ? q : 0][khn] + cq[kwn] : abase[q] + dnext;
-                aoff[q] = ((Pq << 7) + ((fg ^ (Pq & 7)) << 4)) ^ kx;
-            }
-#pragma unroll
-            for (int m = 0; m < MF; ++m) {
-                const int i = m / FN, j = m % FN;
-                if (m == BP) {
-                    sched_fence();
-                    if (!(LECO_CONV_ABLATE & 4)) wait_vmcnt<younger>();    // weight tile t + 1 (and, at tap 8, the next chunk's patch) landed
-                    if (!(LECO_CONV_ABLATE & 8)) barrier_only();            // ... for every wave (this wave's fragment reads stay in flight)
-                    sched_fence();
-                }
-                if (j == 0) {                 // row i: this tap's weight fragments (i = 0) and af[i] have landed
-                    constexpr auto issued = [rpos](int mm) { int n = 0; for (int r = 0; r < NR; ++r) n += rpos(r) < mm ? 1 : 0; return n; };
-                    sched_fence();
-                    lds_wait_n(FM - 1 - i + issued(m));
-                    if (i == 0) {
-#pragma unroll
-                        for (int q = 0; q < FN; ++q) lds_tie(wfC[q]);
-                    }
-                    lds_tie(afC[i]);
-                    sched_fence();
-                }
-                if (!(LECO_CONV_ABLATE & 1)) {
-#pragma unroll
-                    for (int r = 0; r < NR; ++r)
-                        if (rpos(r) == m) {
-                            if (r < FN) wfN[r] = lds_read16_async(wbuf + r * (16 * BK * 2));
-                            else afN[r - FN] = lds_read16_async(abuf + aoff[r - FN]);
-                        }
-                }
-                if (LECO_CONV_ABLATE & 2) { if (m == 0) acc[i][j][0] += __uint_as_float((unsigned)(wfC[j][0] ^ afC[i][0])); }
-                else acc[i][j] = mfma16(wfC[j], afC[i], acc[i][j]);
-#pragma unroll
-                for (int d = 0; d < ND; ++d)
-                    if (dpos(d, ND) == m) {
-                        sched_fence();
-                        if (LECO_CONV_ABLATE & 16) {}
-                        else if (tap < APW && d == 0) issue_a(tap, c + 1, pb ^ 1);
-                        else issue_w1(c + cn, tn, sfill, d - (tap < APW ? 1 : 0));
-                        sched_fence();
-                    }
-            }
-            sched_fence();
-            slot = snext;
-        };
-        auto step = [&](auto tap_c, auto par_c, const int c) {
-            if constexpr (KS2) step2(tap_c, par_c, c);
-            else step1(tap_c, c);
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        step(std::integral_constant<int, 0>{}, I0{}, c);
-        step(std::integral_constant<int, 1>{}, I1{}, c);
-        step(std::integral_constant<int, 2>{}, I0{}, c);
-        step(std::integral_constant<int, 3>{}, I1{}, c);
-        step(std::integral_constant<int, 4>{}, I0{}, c);
-        step(std::integral_constant<int, 5>{}, I1{}, c);
-        step(std::integral_constant<int, 6>{}, I0{}, c);
-        step(std::integral_constant<int, 7>{}, I1{}, c);
-        step(std::integral_constant<int, 8>{}, I0{}, c);
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+        step(std::integral_constant<int, 8>{});
         pb ^= 1;
-        lds_wait<0>();                        // the set in flight complete before the back edge / the loop exit / a branch
-        if (KS2) landed(afB, wfB);
-        else landed(afA, wfA);
-        if constexpr (KS2) {
-            if (c + 1 < chunk_end) {          // the odd chunk: same steps, the fragment sets swapped
-#pragma unroll
-                for (int i = 0; i < FM; ++i) opaque(abase[i]);
-                if (UP2) { opaque(cq[0]); opaque(cq[1]); opaque(cq[2]); }
-                step(std::integral_constant<int, 0>{}, I1{}, c + 1);
-                step(std::integral_constant<int, 1>{}, I0{}, c + 1);
-                step(std::integral_constant<int, 2>{}, I1{}, c + 1);
-                step(std::integral_constant<int, 3>{}, I0{}, c + 1);
-                step(std::integral_constant<int, 4>{}, I1{}, c + 1);
-                step(std::integral_constant<int, 5>{}, I0{}, c + 1);
-                step(std::integral_constant<int, 6>{}, I1{}, c + 1);
-                step(std::integral_constant<int, 7>{}, I0{}, c + 1);
-                step(std::integral_constant<int, 8>{}, I1{}, c + 1);
-                pb ^= 1;
-                lds_wait<0>();
-                landed(afA, wfA);
-            }
-        }
+        lds_wait<0>();                        // set A complete before the back edge / the loop exit
+        landed(afA, wfA);
     }
     wait_vmcnt<0>();                          // the out-of-range DMAs issued past the end of the K range
-    if (LECO_CONV_ABLATE & 32) clk[2] = __builtin_amdgcn_s_memtime();
+#if LECO_CONV_ABLATE & 32
+    clk[2] = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- K-extension (leco_gemm_args.a_ext / w_ext: the LoRA up-projection of a c3lier convolution, lora.py:102-106; its
     // 3x3 down-projection T = conv(x, down) is a skinny launch of its own): one more step whose activation rows are the
@@ -515,32 +475,13 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     // rows, slot ^= entry & 7) in patch buffer 0, W in ring slot 0 -- so the fragment reads are the main loop's.  Split-K:
     // the first split carries it.
     if (p.a_ext && split == 0) {
-        const buf_rsrc rax = make_rsrc(p.a_ext, rt.ax_bytes), rwx = make_rsrc(p.w_ext, rt.wx_bytes);
-        const unsigned xk_bytes = (unsigned)p.ext_k * 2u;
         barrier_keep_dma();                   // every wave has issued (and completed) its last fragment reads of the main loop
-#pragma unroll
-        for (int j = 0; j < BM / 64; ++j) {
-            const int r = (wave + NW * j) * 8 + st_row;                       // tile row = patch entry
-            const int g = g0 + (r >> TWl), xx = x0 + (r & (TW - 1));
-            const bool ok = g < GROWS && xx < W && cpos < xk_bytes;
-            const unsigned voff = ok ? (unsigned)(g * W + xx) * (unsigned)p.ld_aext * 2u + cpos : DMA_OOB;
-            glds16_buf(rax, voff, 0u, lds + OFF_A + (wave + NW * j) * (8 * BK * 2));
-        }
-#pragma unroll
-        for (int i = 0; i < GW; ++i) {
-            const int rl = (wave + NW * i) * 8 + st_row, n = n0 + rl;
-            const bool real = !RAGW || i < GW - 1 || (wave + NW * i) < GWT;   // wave-uniform
-            const bool ok = real && rl < BN && n < N && cpos < xk_bytes;
-            unsigned char* dst = real ? lds + (wave + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
-            glds16_buf(rwx, ok ? (unsigned)n * (unsigned)p.ld_wext * 2u + cpos : DMA_OOB, 0u, dst);
-        }
-        wait_vmcnt<0>();
+        if (LW == 0) issue_ext();
         barrier_keep_dma();
         const unsigned char* abase0 = lds + OFF_A;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             if (ks * 32 >= p.ext_k) break;
-            if (KS2 && ks != kg) continue;
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int r = wave_m * WM + i * 16 + fr;
@@ -566,33 +507,10 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
     bf16_t* cp = (bf16_t*)p.c;
     const bf16_t* res = (const bf16_t*)p.residual;
     float* wsp = rt.split_k > 1 ? rt.ws + (int64_t)split * M * N : nullptr;
-    if constexpr (KS2) {
-        // the two K groups hold partial sums of the same (BM / 2) x (BN / 2) wave tiles: group 1 parks its accumulators in the
-        // staging tile, group 0 adds them (same lane, same address) and is the group that stages the result below
-        static_assert(RR == BM, "KS2: the whole tile must fit the staging area");
-        barrier_keep_dma();
-        if (kg == 1) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    *(f32x4*)(stg + (wave_m * WM + i * 16 + fr) * SROW + wave_n * WN + j * 16 + 4 * fg) = acc[i][j];
-        }
-        barrier_keep_dma();
-        if (kg == 0) {
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) {
-                    const f32x4 o = *(const f32x4*)(stg + (wave_m * WM + i * 16 + fr) * SROW + wave_n * WN + j * 16 + 4 * fg);
-                    acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
-                }
-        }
-    }
 #pragma unroll
     for (int h = 0; h < BM / RR; ++h) {
         barrier_keep_dma();
-        if ((wave_m * WM) / RR == h && kg == 0) {
+        if ((wave_m * WM) / RR == h) {
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int rl = (wave_m * WM) % RR + i * 16 + fr;
@@ -733,14 +651,14 @@ __global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p,
             }
         }
     }
-    if (LECO_CONV_ABLATE & 32) {              // stamps of workgroup 0 over the start of its own output (timing builds only)
-        __syncthreads();
-        if (wg == 0 && tid == 0) {
-            clk[3] = __builtin_amdgcn_s_memtime(); rtc[1] = __builtin_amdgcn_s_memrealtime();
-            unsigned long long* o = (unsigned long long*)p.c;
-            o[0] = clk[1] - clk[0]; o[1] = clk[2] - clk[1]; o[2] = clk[3] - clk[2]; o[3] = rtc[1] - rtc[0];
-        }
+#if LECO_CONV_ABLATE & 32
+    __syncthreads();                          // stamps of workgroup 0 over the start of its own output (timing builds only)
+    if (wg == 0 && tid == 0) {
+        clk[3] = __builtin_amdgcn_s_memtime(); rtc[1] = __builtin_amdgcn_s_memrealtime();
+        unsigned long long* o = (unsigned long long*)p.c;
+        o[0] = clk[1] - clk[0]; o[1] = clk[2] - clk[1]; o[2] = clk[3] - clk[2]; o[3] = rtc[1] - rtc[0];
     }
+#endif
 }
 
 // tile geometry of one (BM, problem): TW, tile counts, and whether every tile's patch fits the capacity
@@ -765,7 +683,7 @@ PatchGeom patch_geometry(const leco_gemm_args& a, int bm, int pcap) {
     return g;
 }
 
-template <int BM, int BN, int NSW, bool UP2, bool KS2 = false>
+template <int BM, int BN, int NSW, bool UP2, int LW = 0>
 int launch_patch_m(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, char* describe, int describe_len) {
     using Cf = PatchCfg<BM, BN, NSW>;
     const PatchGeom g = patch_geometry(a, BM, Cf::PCAP);
@@ -786,31 +704,30 @@ int launch_patch_m(const leco_gemm_args& a, int split_k, float* ws, hipStream_t 
     if (describe) {
         const int used = (int)strlen(describe);
         snprintf(describe + used, describe_len - used, "%sconv_patch_kernel<%d, %d, %d, %s%s> grid=%u split=%d", used ? " ; " : "",
-                 BM, BN, NSW, UP2 ? "true" : "false", KS2 ? ", true" : "", grid.x, split_k);
+                 BM, BN, NSW, UP2 ? "true" : "false", LW ? ", 8" : "", grid.x, split_k);
         return 0;
     }
     static bool attr_set[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<BM, BN, NSW, UP2, KS2>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<BM, BN, NSW, UP2, LW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
-    hipLaunchKernelGGL((conv_patch_kernel<BM, BN, NSW, UP2, KS2>), grid, dim3(512), Cf::LDS_BYTES, s, a, rt);
+    hipLaunchKernelGGL((conv_patch_kernel<BM, BN, NSW, UP2, LW>), grid, dim3(512 + 64 * LW), Cf::LDS_BYTES, s, a, rt);
     return 0;
 }
-template <int BM, int BN, int NSW, bool KS2 = false>
+template <int BM, int BN, int NSW, int LW = 0>
 int launch_patch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, char* describe, int describe_len) {
-    if (a.a_mode == LECO_A_CONV3_UP2) return launch_patch_m<BM, BN, NSW, true, KS2>(a, split_k, ws, s, describe, describe_len);
-    return launch_patch_m<BM, BN, NSW, false, KS2>(a, split_k, ws, s, describe, describe_len);
+    if (a.a_mode == LECO_A_CONV3_UP2) return launch_patch_m<BM, BN, NSW, true, LW>(a, split_k, ws, s, describe, describe_len);
+    return launch_patch_m<BM, BN, NSW, false, LW>(a, split_k, ws, s, describe, describe_len);
 }
-// LECO_CONV_KS2=1: the 128-row tiles run as two K groups of 64-row wave tiles (measurement switch, read once)
-bool conv_ks2() {
-    static const bool on = [] { const char* e = getenv("LECO_CONV_KS2"); return e && atoi(e) != 0; }();
+// LECO_CONV_LW=1: the 128-row tiles run with 8 loader waves (measurement switch, read once)
+bool conv_lw() {
+    static const bool on = [] { const char* e = getenv("LECO_CONV_LW"); return e && atoi(e) != 0; }();
     return on;
 }
-
 bool patch_applicable(const leco_gemm_args& a) {
     if (a.t_w || a.act == LECO_ACT_GEGLU) return false;
     if (a.a_ext && (!a.w_ext || (a.ext_k != 32 && a.ext_k != 64))) return false;
@@ -831,10 +748,10 @@ int conv_patch_try(const leco_gemm_args& a, int variant, int split_k, float* ws,
     switch (variant) {
         case 7: return launch_patch<256, 128, 4>(a, split_k, ws, s, describe, describe_len);
         case 8:
-            if (conv_ks2()) return launch_patch<128, 160, 4, true>(a, split_k, ws, s, describe, describe_len);
+            if (conv_lw()) return launch_patch<128, 160, 4, 8>(a, split_k, ws, s, describe, describe_len);
             return launch_patch<128, 160, 4>(a, split_k, ws, s, describe, describe_len);
         case 9:
-            if (conv_ks2()) return launch_patch<128, 128, 4, true>(a, split_k, ws, s, describe, describe_len);
+            if (conv_lw()) return launch_patch<128, 128, 4, 8>(a, split_k, ws, s, describe, describe_len);
             return launch_patch<128, 128, 4>(a, split_k, ws, s, describe, describe_len);
         case 10: return launch_patch<256, 160, 3>(a, split_k, ws, s, describe, describe_len);
         default: return 1;

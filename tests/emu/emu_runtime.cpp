@@ -98,6 +98,7 @@ struct Runner {
     unsigned long events = 0;        // completed rendezvous + finished work-items (progress, for the greedy schedules)
     unsigned long rng = 0x9E3779B97F4A7C15ul;
     int block_arrived = 0;
+    int finished = 0;                // work-items of this block that have returned: a terminated wave no longer counts at s_barrier
     unsigned block_gen = 0;
     int wave_arrived[kMaxThreads / 64] = {};
     unsigned wave_gen[kMaxThreads / 64] = {};
@@ -144,6 +145,11 @@ void trampoline() {
     (*r->body)();
     r->fibers[r->cur].done = true;
     ++r->events;
+    ++r->finished;
+    if (r->block_arrived > 0 && r->block_arrived == r->n - r->finished) {     // the others were only waiting for this one
+        r->block_arrived = 0;
+        ++r->block_gen;
+    }
 #if LECO_EMU_ASAN
     __sanitizer_start_switch_fiber(nullptr, r->sched_bottom, r->sched_size);      // nullptr: this work-item's stack dies
 #endif
@@ -212,6 +218,7 @@ void run_block(Runner* r, dim3 block, const std::function<void()>& body) {
     r->bdim = block;
     r->body = &body;
     r->block_arrived = 0;
+    r->finished = 0;
     for (int w = 0; w < kMaxThreads / 64; ++w) r->wave_arrived[w] = 0;
     for (int i = 0; i < r->n; ++i) make_fiber(r, i);
 #if LECO_EMU_TSAN
@@ -364,7 +371,7 @@ Pool& pool() { static Pool p; return p; }
 void sync_block() {
     Runner* r = tl_runner;
     unsigned g = r->block_gen;
-    if (++r->block_arrived == r->n) {
+    if (++r->block_arrived == r->n - r->finished) {
         r->block_arrived = 0;
         r->block_gen = g + 1;
         ++r->events;

@@ -77,12 +77,12 @@ if __name__ == "__main__":
     else:
         d = os.path.join(ROOT, "tools", "_ablate")
         have = sorted(int(f[len("libleco_convablate"):-3]) for f in os.listdir(d) if f.startswith("libleco_convablate"))
-        for ks2 in ("0", "1"):
+        for lw in ("0", "1"):
             for v in [0] + have:
-                env = dict(os.environ, LECO_CONV_KS2=ks2)
+                env = dict(os.environ, LECO_CONV_LW=lw)
                 if v:
                     env["LECO_HIP_LIB"] = os.path.join(d, f"libleco_convablate{v}.so")
                 if v & 32:
                     env["LECO_CONV_STAMPS"] = "1"
-                print(f"# LECO_CONV_KS2={ks2}  {v}: {describe(v)}", flush=True)
+                print(f"# LECO_CONV_LW={lw}  {v}: {describe(v)}", flush=True)
                 subprocess.run([sys.executable, os.path.abspath(__file__), "--case"], env=env)
