@@ -82,15 +82,8 @@ struct PatchCfg {
 // at INPUT resolution ((TH / 2 + 2) x (TW / 2 + 2) entries for a TH x TW output block: a quarter of the stride-1 patch) and
 // tap (kh, kw) of output pixel (y, x) reads input pixel ((y + kh - 1) >> 1, (x + kw - 1) >> 1); -1 and H_in are the same
 // zero separator rows.
-//
-// LW = 8: LOADER WAVES.  The workgroup gets 8 more waves (16 = 4 per SIMD) that do nothing but the LDS-DMA: a DMA instruction
-// holds its wave for ~100-150 cycles, and with the DMA in the MFMA waves' instruction streams those cycles come out of the
-// tap step (profiles/r06_ablate_conv.txt: the step costs 973 shader cycles against 655 with MFMAs alone).  Loader wave l owns
-// exactly the pieces MFMA wave l owns in the LW = 0 layout; per step it issues them, waits for weight tile t + 1 and joins the
-// step's barrier.  It leaves before the epilogue (a terminated wave no longer counts at s_barrier).
-template <int BM, int BN, int NSW, bool UP2, int LW = 0>
-__global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_gemm_args p, const PatchRt rt) {
-    static_assert(LW == 0 || LW == PatchCfg<BM, BN, NSW>::NW, "loader wave l takes over the pieces of MFMA wave l");
+template <int BM, int BN, int NSW, bool UP2>
+__global__ __launch_bounds__(512) void conv_patch_kernel(const leco_gemm_args p, const PatchRt rt) {
     using Cf = PatchCfg<BM, BN, NSW>;
     constexpr int NW = Cf::NW, NT = NW * 64;
     constexpr int WM = BM / 4, WN = BN / 2, FM = WM / 16, FN = WN / 16;
@@ -118,8 +111,6 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
     const int tile_g = tile_m / rt.tiles_x, tile_x = tile_m - tile_g * rt.tiles_x;
 
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
-    const bool loader = LW > 0 && wave >= NW;                          // wave-uniform
-    const int dw = LW > 0 ? wave - NW : wave;                           // owner index of this wave's DMA pieces
     const int wave_m = wave >> 1, wave_n = wave & 1;
     const int st_row = lane >> 3, st_pos = lane & 7;
     const int fr = lane & 15, fg = lane >> 4;
@@ -158,7 +149,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
     unsigned wvoff[GW];
 #pragma unroll
     for (int i = 0; i < GW; ++i) {
-        const int rl = (dw + NW * i) * 8 + st_row;
+        const int rl = (wave + NW * i) * 8 + st_row;
         const int n = n0 + rl;
         wvoff[i] = (rl < BN && n < N) ? (unsigned)n * (unsigned)p.ldw * 2u + cpos : DMA_OOB;
     }
@@ -170,7 +161,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
         const unsigned soff = (unsigned)(first ? cch : cch - k_split) * 2u;
         const unsigned dead = cabs < chunk_end ? 0u : DMA_OOB;
         const unsigned voff = (mul24(ppix[j], ld) * 2u + cpos) | (ppix[j] & DMA_OOB) | dead;
-        glds16_buf(first ? ra0 : ra1, voff, soff, lds + OFF_A + pb * PBUF + (dw + NW * j) * (8 * BK * 2));
+        glds16_buf(first ? ra0 : ra1, voff, soff, lds + OFF_A + pb * PBUF + (wave + NW * j) * (8 * BK * 2));
     };
     // weight tile of (chunk cabs, tap) into ring slot `slot`
     auto issue_w = [&](int cabs, int tap, int slot) {
@@ -179,8 +170,8 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
         const unsigned dead = live ? 0u : DMA_OOB;
 #pragma unroll
         for (int i = 0; i < GW; ++i) {
-            const bool real = !RAGW || i < GW - 1 || (dw + NW * i) < GWT;     // wave-uniform
-            unsigned char* dst = real ? lds + slot * WTILE + (dw + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
+            const bool real = !RAGW || i < GW - 1 || (wave + NW * i) < GWT;     // wave-uniform
+            unsigned char* dst = real ? lds + slot * WTILE + (wave + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
             glds16_buf(rw, wvoff[i] | dead | (real ? 0u : DMA_OOB), soff, dst);
         }
     };
@@ -188,8 +179,8 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
     auto issue_w1 = [&](int cabs, int tap, int slot, int i) {      // piece i of that tile
         const bool live = cabs < chunk_end;
         const unsigned soff = live ? (unsigned)(tap * cin + cabs * BK) * 2u : 0u;
-        const bool real = !RAGW || i < GW - 1 || (dw + NW * i) < GWT;         // wave-uniform
-        unsigned char* dst = real ? lds + slot * WTILE + (dw + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
+        const bool real = !RAGW || i < GW - 1 || (wave + NW * i) < GWT;         // wave-uniform
+        unsigned char* dst = real ? lds + slot * WTILE + (wave + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
         glds16_buf(rw, wvoff[i] | (live ? 0u : DMA_OOB) | (real ? 0u : DMA_OOB), soff, dst);
     };
 
@@ -262,13 +253,13 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
     // float reciprocal (operands < 2^18, validated on the host): a 32-bit division is ~40 instructions, and the table
     // needs 2 APW of them per lane.
     auto divf = [](int a, float rcp) { return (int)(((float)a + 0.5f) * rcp); };
-    if (chunk_begin < chunk_end && (LW == 0 || loader)) {
+    if (chunk_begin < chunk_end) {
 #pragma unroll
         for (int s_ = 0; s_ < NSW - 1; ++s_) issue_w(chunk_begin, s_, s_);
         const float rpw = 1.0f / (float)PW, rh1 = 1.0f / (float)(HD + 1);
 #pragma unroll
         for (int j = 0; j < APW; ++j) {
-            const int q = (dw + NW * j) * 8 + st_row;
+            const int q = (wave + NW * j) * 8 + st_row;
             const int srow = divf(q, rpw), scol = q - srow * PW;
             const int v = VLO + srow;
             const int vb = v >= 0 ? divf(v, rh1) : 0, vy = v - vb * (HD + 1);
@@ -280,7 +271,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
             // for an out-of-range LDS-DMA lane or skips the lane
             if (!ok) {
                 const u32x4 z = {0u, 0u, 0u, 0u};
-                unsigned char* d = lds + OFF_A + (dw + NW * j) * (8 * BK * 2) + lane * 16;
+                unsigned char* d = lds + OFF_A + (wave + NW * j) * (8 * BK * 2) + lane * 16;
                 *(u32x4*)d = z;
                 *(u32x4*)(d + PBUF) = z;
             }
@@ -288,73 +279,6 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
 #pragma unroll
         for (int j = 0; j < APW; ++j) issue_a(j, chunk_begin, 0);
         wait_vmcnt<0>();
-    }
-    // K-extension operands (see below) into patch buffer 0 / ring slot 0
-    auto issue_ext = [&]() {
-        const buf_rsrc rax = make_rsrc(p.a_ext, rt.ax_bytes), rwx = make_rsrc(p.w_ext, rt.wx_bytes);
-        const unsigned xk_bytes = (unsigned)p.ext_k * 2u;
-#pragma unroll
-        for (int j = 0; j < BM / 64; ++j) {
-            const int r = (dw + NW * j) * 8 + st_row;                         // tile row = patch entry
-            const int g = g0 + (r >> TWl), xx = x0 + (r & (TW - 1));
-            const bool ok = g < GROWS && xx < W && cpos < xk_bytes;
-            const unsigned voff = ok ? (unsigned)(g * W + xx) * (unsigned)p.ld_aext * 2u + cpos : DMA_OOB;
-            glds16_buf(rax, voff, 0u, lds + OFF_A + (dw + NW * j) * (8 * BK * 2));
-        }
-#pragma unroll
-        for (int i = 0; i < GW; ++i) {
-            const int rl = (dw + NW * i) * 8 + st_row, n = n0 + rl;
-            const bool real = !RAGW || i < GW - 1 || (dw + NW * i) < GWT;     // wave-uniform
-            const bool ok = real && rl < BN && n < N && cpos < xk_bytes;
-            unsigned char* dst = real ? lds + (dw + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
-            glds16_buf(rwx, ok ? (unsigned)n * (unsigned)p.ld_wext * 2u + cpos : DMA_OOB, 0u, dst);
-        }
-        wait_vmcnt<0>();
-    };
-    if (LW > 0 && loader) {
-        // ---- the loader waves' whole life: the prologue DMA above, then per tap step the pieces of weight tile t + NSW - 1 (and
-        // of the next chunk's patch), the wait for tile t + 1 and the step's barrier
-        if (chunk_begin < chunk_end) barrier_only();
-        int slot = 0, pb = 0;
-        for (int c = chunk_begin; c < chunk_end; ++c) {
-            auto lstep = [&](auto tap_c) {
-                constexpr int tap = decltype(tap_c)::value;
-                constexpr int D = NSW - 1;
-                constexpr int tn = (tap + D) % 9, cn = (tap + D) / 9;
-                // DMAs younger than weight tile t + 1 (issued in step t + 1 - D) at this step's wait: steps t + 2 - D .. t
-                constexpr int younger = [] {
-                    int n = 0;
-                    for (int d = 0; d <= D - 2; ++d) n += GW + ((((tap - d) % 9 + 9) % 9) < APW ? 1 : 0);
-                    return n;
-                }();
-                const int sfill = slot == 0 ? NSW - 1 : slot - 1;
-                if (tap < APW) issue_a(tap, c + 1, pb ^ 1);
-#pragma unroll
-                for (int i = 0; i < GW; ++i) issue_w1(c + cn, tn, sfill, i);
-                wait_vmcnt<younger>();
-                barrier_only();
-                slot = slot + 1 == NSW ? 0 : slot + 1;
-            };
-            lstep(std::integral_constant<int, 0>{});
-            lstep(std::integral_constant<int, 1>{});
-            lstep(std::integral_constant<int, 2>{});
-            lstep(std::integral_constant<int, 3>{});
-            lstep(std::integral_constant<int, 4>{});
-            lstep(std::integral_constant<int, 5>{});
-            lstep(std::integral_constant<int, 6>{});
-            lstep(std::integral_constant<int, 7>{});
-            lstep(std::integral_constant<int, 8>{});
-            pb ^= 1;
-        }
-        wait_vmcnt<0>();
-        if (p.a_ext && split == 0) {
-            barrier_only();
-            issue_ext();
-            barrier_only();
-        }
-        return;
-    }
-    if (chunk_begin < chunk_end) {
         barrier_keep_dma();
         read_a0(0, 0, afA);
         read_w(0, 0, wfA);
@@ -421,7 +345,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
                 const int mm = m < P ? m : m - P, i = mm / FN, j = mm % FN;
                 if (m == P) {
                     sched_fence();
-                    if (LW == 0 && !(LECO_CONV_ABLATE & 4)) wait_vmcnt<younger>();    // weight tile t + 1 (and, at tap 8, the next chunk's patch) landed
+                    if (!(LECO_CONV_ABLATE & 4)) wait_vmcnt<younger>();    // weight tile t + 1 (and, at tap 8, the next chunk's patch) landed
                     if (!(LECO_CONV_ABLATE & 8)) barrier_keep_dma();       // ... for every wave; all waves are done with tile t's slot (completes set B)
                     else lds_wait<0>();
                     landed(afB, wfB);
@@ -441,7 +365,7 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
                 for (int d = 0; d < ND; ++d)
                     if (dpos(d, ND) == m) {
                         sched_fence();
-                        if (LW > 0 || (LECO_CONV_ABLATE & 16)) {}
+                        if (LECO_CONV_ABLATE & 16) {}
                         else if (tap < APW && d == 0) issue_a(tap, c + 1, pb ^ 1);
                         else issue_w1(c + cn, tn, sfill, d - (tap < APW ? 1 : 0));
                         sched_fence();
@@ -475,8 +399,26 @@ __global__ __launch_bounds__(512 + 64 * LW) void conv_patch_kernel(const leco_ge
     // rows, slot ^= entry & 7) in patch buffer 0, W in ring slot 0 -- so the fragment reads are the main loop's.  Split-K:
     // the first split carries it.
     if (p.a_ext && split == 0) {
+        const buf_rsrc rax = make_rsrc(p.a_ext, rt.ax_bytes), rwx = make_rsrc(p.w_ext, rt.wx_bytes);
+        const unsigned xk_bytes = (unsigned)p.ext_k * 2u;
         barrier_keep_dma();                   // every wave has issued (and completed) its last fragment reads of the main loop
-        if (LW == 0) issue_ext();
+#pragma unroll
+        for (int j = 0; j < BM / 64; ++j) {
+            const int r = (wave + NW * j) * 8 + st_row;                       // tile row = patch entry
+            const int g = g0 + (r >> TWl), xx = x0 + (r & (TW - 1));
+            const bool ok = g < GROWS && xx < W && cpos < xk_bytes;
+            const unsigned voff = ok ? (unsigned)(g * W + xx) * (unsigned)p.ld_aext * 2u + cpos : DMA_OOB;
+            glds16_buf(rax, voff, 0u, lds + OFF_A + (wave + NW * j) * (8 * BK * 2));
+        }
+#pragma unroll
+        for (int i = 0; i < GW; ++i) {
+            const int rl = (wave + NW * i) * 8 + st_row, n = n0 + rl;
+            const bool real = !RAGW || i < GW - 1 || (wave + NW * i) < GWT;   // wave-uniform
+            const bool ok = real && rl < BN && n < N && cpos < xk_bytes;
+            unsigned char* dst = real ? lds + (wave + NW * i) * (8 * BK * 2) : lds + OFF_DUMP;
+            glds16_buf(rwx, ok ? (unsigned)n * (unsigned)p.ld_wext * 2u + cpos : DMA_OOB, 0u, dst);
+        }
+        wait_vmcnt<0>();
         barrier_keep_dma();
         const unsigned char* abase0 = lds + OFF_A;
 #pragma unroll
@@ -683,7 +625,7 @@ PatchGeom patch_geometry(const leco_gemm_args& a, int bm, int pcap) {
     return g;
 }
 
-template <int BM, int BN, int NSW, bool UP2, int LW = 0>
+template <int BM, int BN, int NSW, bool UP2>
 int launch_patch_m(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, char* describe, int describe_len) {
     using Cf = PatchCfg<BM, BN, NSW>;
     const PatchGeom g = patch_geometry(a, BM, Cf::PCAP);
@@ -703,30 +645,25 @@ int launch_patch_m(const leco_gemm_args& a, int split_k, float* ws, hipStream_t 
     dim3 grid((unsigned)(g.tiles_g * g.tiles_x * tn), (unsigned)split_k);
     if (describe) {
         const int used = (int)strlen(describe);
-        snprintf(describe + used, describe_len - used, "%sconv_patch_kernel<%d, %d, %d, %s%s> grid=%u split=%d", used ? " ; " : "",
-                 BM, BN, NSW, UP2 ? "true" : "false", LW ? ", 8" : "", grid.x, split_k);
+        snprintf(describe + used, describe_len - used, "%sconv_patch_kernel<%d, %d, %d, %s> grid=%u split=%d", used ? " ; " : "",
+                 BM, BN, NSW, UP2 ? "true" : "false", grid.x, split_k);
         return 0;
     }
     static bool attr_set[64] = {};
     int dev_id = 0;
     (void)hipGetDevice(&dev_id);
     if (dev_id < 0 || dev_id >= 64 || !attr_set[dev_id]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<BM, BN, NSW, UP2, LW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<BM, BN, NSW, UP2>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, Cf::LDS_BYTES);
         if (dev_id >= 0 && dev_id < 64) attr_set[dev_id] = true;
     }
-    hipLaunchKernelGGL((conv_patch_kernel<BM, BN, NSW, UP2, LW>), grid, dim3(512 + 64 * LW), Cf::LDS_BYTES, s, a, rt);
+    hipLaunchKernelGGL((conv_patch_kernel<BM, BN, NSW, UP2>), grid, dim3(512), Cf::LDS_BYTES, s, a, rt);
     return 0;
 }
-template <int BM, int BN, int NSW, int LW = 0>
+template <int BM, int BN, int NSW>
 int launch_patch(const leco_gemm_args& a, int split_k, float* ws, hipStream_t s, char* describe, int describe_len) {
-    if (a.a_mode == LECO_A_CONV3_UP2) return launch_patch_m<BM, BN, NSW, true, LW>(a, split_k, ws, s, describe, describe_len);
-    return launch_patch_m<BM, BN, NSW, false, LW>(a, split_k, ws, s, describe, describe_len);
-}
-// LECO_CONV_LW=1: the 128-row tiles run with 8 loader waves (measurement switch, read once)
-bool conv_lw() {
-    static const bool on = [] { const char* e = getenv("LECO_CONV_LW"); return e && atoi(e) != 0; }();
-    return on;
+    if (a.a_mode == LECO_A_CONV3_UP2) return launch_patch_m<BM, BN, NSW, true>(a, split_k, ws, s, describe, describe_len);
+    return launch_patch_m<BM, BN, NSW, false>(a, split_k, ws, s, describe, describe_len);
 }
 bool patch_applicable(const leco_gemm_args& a) {
     if (a.t_w || a.act == LECO_ACT_GEGLU) return false;
@@ -747,12 +684,8 @@ int conv_patch_try(const leco_gemm_args& a, int variant, int split_k, float* ws,
     if (split_k < 1) split_k = 1;
     switch (variant) {
         case 7: return launch_patch<256, 128, 4>(a, split_k, ws, s, describe, describe_len);
-        case 8:
-            if (conv_lw()) return launch_patch<128, 160, 4, 8>(a, split_k, ws, s, describe, describe_len);
-            return launch_patch<128, 160, 4>(a, split_k, ws, s, describe, describe_len);
-        case 9:
-            if (conv_lw()) return launch_patch<128, 128, 4, 8>(a, split_k, ws, s, describe, describe_len);
-            return launch_patch<128, 128, 4>(a, split_k, ws, s, describe, describe_len);
+        case 8: return launch_patch<128, 160, 4>(a, split_k, ws, s, describe, describe_len);
+        case 9: return launch_patch<128, 128, 4>(a, split_k, ws, s, describe, describe_len);
         case 10: return launch_patch<256, 160, 3>(a, split_k, ws, s, describe, describe_len);
         default: return 1;
     }

@@ -140,29 +140,6 @@ template <int N>
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
 }
-// ... with a count that is a compile-time constant only after unrolling (the switch folds to one s_waitcnt)
-__device__ __forceinline__ void lds_wait_n(int n) {
-    switch (n) {
-        case 0: lds_wait<0>(); break;
-        case 1: lds_wait<1>(); break;
-        case 2: lds_wait<2>(); break;
-        case 3: lds_wait<3>(); break;
-        case 4: lds_wait<4>(); break;
-        case 5: lds_wait<5>(); break;
-        case 6: lds_wait<6>(); break;
-        case 7: lds_wait<7>(); break;
-        case 8: lds_wait<8>(); break;
-        case 9: lds_wait<9>(); break;
-        case 10: lds_wait<10>(); break;
-        case 11: lds_wait<11>(); break;
-        case 12: lds_wait<12>(); break;
-        case 13: lds_wait<13>(); break;
-        case 14: lds_wait<14>(); break;
-        default: break;           // lgkmcnt is a 4-bit counter: 15 = no wait
-    }
-}
-// workgroup barrier alone: neither LDS-DMA nor this wave's asynchronous LDS reads are drained
-__device__ __forceinline__ void barrier_only() { __builtin_amdgcn_s_barrier(); }
 __device__ __forceinline__ void lds_tie(bf16x8& v) { asm volatile("" : "+v"(v)); }
 // makes a value opaque to the optimiser at this point (no instruction is emitted): stops loop-invariant code motion
 // from hoisting -- and spilling -- whole tables of addresses derived from it

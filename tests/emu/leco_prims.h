@@ -152,8 +152,6 @@ static inline u32x2 lds_read_tr16_at(unsigned addr) { return lds_read_tr16(dyn_l
 static inline void lds_tie2(u32x2&) {}
 template <int N>
 static inline void lds_wait() {}
-static inline void lds_wait_n(int) {}
-static inline void barrier_only() { emu::sync_block(); }
 static inline void lds_tie(bf16x8&) {}
 static inline void opaque(int&) {}
 static inline void sched_fence() {}
