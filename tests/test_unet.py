@@ -242,7 +242,7 @@ def test_plans_shared_by_shape_survive_foreign_writers_and_second_drivers(dev):
     pair = prompt_util.PromptEmbedsPair(torch.nn.MSELoss(), emb["target"], emb["positive"], emb["unconditional"],
                                         emb["neutral"], settings)
     fa = FusedStep(m, net, create_noise_scheduler("ddim"), N_STEPS, lr=0.0, weight_decay=0.0)
-    l0 = fa.step(pair, K, GOLD["latents"].clone()).item()
+    l0 = fa.step(pair, 1, GOLD["latents"].clone()).item()
     x0 = fa._state[(BS, 16, 16)]["x"].clone()
     st = fa._state[(BS, 16, 16)]
     want = st["dplan"].ctx.clone()
@@ -250,7 +250,7 @@ def test_plans_shared_by_shape_survive_foreign_writers_and_second_drivers(dev):
     for pl in (st["dplan"], st["plan"], st["fplan"]):
         pl.set_ctx(torch.full_like(pl.ctx, 3.0))
         assert pl.ctx_src is None
-    l1 = fa.step(pair, K, GOLD["latents"].clone()).item()
+    l1 = fa.step(pair, 1, GOLD["latents"].clone()).item()
 
     def same(la, xa):      # bitwise on the emulator; on the GPU the producer-side GroupNorm statistics are fp32 atomics
         if dev.type == "cpu":
@@ -260,9 +260,9 @@ def test_plans_shared_by_shape_survive_foreign_writers_and_second_drivers(dev):
     # (2) a second driver of the same plans, with another schedule length
     fb = FusedStep(m, net, create_noise_scheduler("ddim"), 2 * N_STEPS, lr=0.0, weight_decay=0.0)
     assert fb._bucket(BS, 16, 16)["dplan"] is st["dplan"]
-    lb = fb.step(pair, K, GOLD["latents"].clone()).item()
+    lb = fb.step(pair, 1, GOLD["latents"].clone()).item()
     assert abs(lb - l0) / l0 > 5e-2                             # (a different timestep table: a different denoising chain)
-    l2 = fa.step(pair, K, GOLD["latents"].clone()).item()
+    l2 = fa.step(pair, 1, GOLD["latents"].clone()).item()
     assert same(l2, fa._state[(BS, 16, 16)]["x"])
 
 
