@@ -61,6 +61,21 @@ __global__ void cross_block_kernel(unsigned* word, int atomic) {
     }
 }
 
+// Waves 2 and 3 return before the second barrier (the way a loader wave leaves a kernel before its epilogue): on the hardware
+// a terminated wave no longer counts at s_barrier, so waves 0 and 1 must get through -- under every schedule.
+__global__ void early_exit_kernel(int* out) {
+    __shared__ int slot[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) slot[wave] = 10 + wave;
+    __syncthreads();
+    if (wave >= 2) return;
+    const int got = slot[wave + 2];
+    __syncthreads();                                               // two waves only
+    if (lane == 0) slot[wave] = got;
+    __syncthreads();
+    if (lane == 0) out[wave] = slot[wave ^ 1];
+}
+
 int main(int argc, char** argv) {
     if (argc > 2 && !strcmp(argv[1], "cross")) {
         unsigned word = 0;
@@ -91,6 +106,10 @@ int main(int argc, char** argv) {
     unsigned* pp = probe;
     hipLaunchKernelGGL(lds_probe_kernel, dim3(4), dim3(64), 0, 0, pp);
     printf("lds: %x %x %x %x\n", probe[0], probe[1], probe[2], probe[3]);
+    int early[2] = {0, 0};
+    int* pe = early;
+    hipLaunchKernelGGL(early_exit_kernel, dim3(1), dim3(256), 0, 0, pe);
+    printf("early: %d %d\n", early[0], early[1]);
     unsigned bcnt = 0;
     int border[6] = {-1, -1, -1, -1, -1, -1};
     unsigned* pbc = &bcnt;

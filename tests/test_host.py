@@ -299,6 +299,9 @@ def test_emulator_schedules_order_the_waves_and_expose_a_missing_barrier():
         r = subprocess.run([exe], env=dict(os.environ, LECO_EMU_THREADS="1", **env), capture_output=True, text=True, timeout=60)
         return [l for l in r.stdout.splitlines() if l.startswith(key)][0]
     assert line("lds") == "lds: 0 1 1 1" and line("lds", LECO_EMU_LDS="poison") == "lds: 7fc0 7fc0 7fc0 7fc0"
+    # a returned wave leaves the workgroup barrier (loader waves that end before the epilogue): no deadlock, under every order
+    for mode in ("rr", "reverse", "greedy", "greedy_reverse", "random"):
+        assert line("early", LECO_EMU_SCHED=mode) == "early: 13 12"
     # LECO_EMU_BLOCKS: workgroup dispatch order (ascending like the hardware's by default; reversed; a fixed permutation)
     assert line("blocks") == "blocks: 0 1 2 3 4 5" and line("blocks", LECO_EMU_BLOCKS="reverse") == "blocks: 5 4 3 2 1 0"
     perm = [int(x) for x in line("blocks", LECO_EMU_BLOCKS="random").split()[1:]]
