@@ -307,7 +307,7 @@ def hbm_bound_launches(groups, top_n=6):
                     "one bf16 write of the tensor; these launches are latency-, not bandwidth-bound at UNet batch 4 (DESIGN 8.000)"}
 
 
-def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
+def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None, headline_workload=True):
     """Times every distinct launch of a step in isolation (HIP events on the compute stream, L2-warm repeats), attributes
     each to its kernel instantiation, picks the instantiation with the largest share of the step and reports its
     launch-weighted average duration and algorithmic FLOPs per launch.  MFMA-busy and HBM traffic per launch come from the
@@ -345,7 +345,10 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
         a[3][key] = (w, us, fl)
         a[4] += w * by       # algorithmic operand bytes per step
     total_us = sum(a[1] for a in per_name.values())
+    # the committed trace and counter passes are of the HEADLINE workload's command: another configuration (--arch / --res / --bs /
+    # --rank / --c3lier / --v-pred) ranks its kernels live and carries no trace or counter figures
     cur = kernel_sources_hash()
+    ref = cur if headline_workload else None          # what a quoted trace / counter summary must have been taken on
     ranked = sorted(per_name.items(), key=lambda kv: -kv[1][1])
     live_name = ranked[0][0]
     # The dominant kernel is the top row of the committed kernel trace of this very command WHEN that trace was taken on
@@ -353,9 +356,9 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
     # that row's launches) and this line then describe the same kernel.  Two instantiations within a percent of each other
     # can swap places between the trace (launches in step order) and the isolated live timing; without a current trace the
     # live ranking decides.
-    name = top["name"] if (top and top["name"] in per_name and _summary_hash(PROFILE_STATS) == cur) else live_name
+    name = top["name"] if (top and top["name"] in per_name and _summary_hash(PROFILE_STATS) == ref) else live_name
 
-    trace_current = bool(top and top["name"] in per_name and _summary_hash(PROFILE_STATS) == cur)
+    trace_current = bool(top and top["name"] in per_name and _summary_hash(PROFILE_STATS) == ref)
 
     def describe_kernel(nm):
         n, us, fl, shapes, by = per_name[nm]
@@ -368,7 +371,8 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
                 "heaviest_shape": {"key": [str(x) for x in heavy[0][1:9]], "launches_per_step": heavy[1][0], "us": heavy[1][1],
                                    "tflops": heavy[1][2] / heavy[1][1] / 1e6 if heavy[1][1] else 0.0}}
     out = describe_kernel(name)
-    out.update({"profile_top_row": top, "live_top": live_name, "agrees_with_profile": bool(top and top["name"] == name)})
+    out.update({"profile_top_row": top if headline_workload else None, "live_top": live_name,
+                "agrees_with_profile": bool(top and top["name"] == name) if headline_workload else None})
     # The headline fraction is measured LIVE in this run: algorithmic FLOPs per launch / the kernel's launch-weighted average
     # duration, HIP events on the compute stream around its launches (every distinct shape, weighted by how often a step
     # issues it).  The committed kernel trace of the same command (launches in step order) is the cross-check: when it was
@@ -406,7 +410,7 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
         if nm == name:
             continue
         d = describe_kernel(nm)
-        row = _pmc_row(PMC_MFMA, nm) if _summary_hash(PMC_MFMA) == cur else None
+        row = _pmc_row(PMC_MFMA, nm) if _summary_hash(PMC_MFMA) == ref else None
         if row and row.get("GRBM_GUI_ACTIVE"):
             d["mfma_busy"] = row.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (row["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         d.pop("heaviest_shape")
@@ -414,8 +418,8 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
     # counter passes are separate rocprofv3 runs (tools/gpu_round_run.sh); their summaries are only quoted when they were
     # taken on THESE kernel sources (hash in the header) and every number names the file it comes from
     out["kernel_sources"] = cur
-    fetch = _pmc_row(PMC_FETCH, name) if _summary_hash(PMC_FETCH) == cur else None
-    mfma = _pmc_row(PMC_MFMA, name) if _summary_hash(PMC_MFMA) == cur else None
+    fetch = _pmc_row(PMC_FETCH, name) if _summary_hash(PMC_FETCH) == ref else None
+    mfma = _pmc_row(PMC_MFMA, name) if _summary_hash(PMC_MFMA) == ref else None
     if fetch and fetch.get("calls"):
         # FETCH_SIZE is in KB and counts a wide coalesced read at half its bytes on gfx950 (MI355X_MICROARCH.md, HBM)
         out["traffic"] = fetch.get("FETCH_SIZE", 0.0) * 1024.0 * 2.0 / fetch["calls"]
@@ -424,7 +428,8 @@ def dominant_kernel_roofline(st, k_mean, only_replay=False, dump_shapes=None):
     else:
         out["traffic"] = None
         out["traffic_note"] = (f"no counter pass on kernel sources {cur} ({os.path.relpath(PMC_FETCH, ROOT)} has "
-                               f"{_summary_hash(PMC_FETCH)}): not quoted")
+                               f"{_summary_hash(PMC_FETCH)}): not quoted" if headline_workload else
+                               "the committed counter passes are of the headline workload's command; none was taken for this configuration")
     if mfma and mfma.get("GRBM_GUI_ACTIVE"):
         out["mfma_busy"] = mfma.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (mfma["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         out["mfma_busy_note"] = f"SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) from {os.path.relpath(PMC_MFMA, ROOT)}"
@@ -750,7 +755,9 @@ def main():
         if tele:
             tele.start(args.telemetry_hz)
         try:
-            dom = dominant_kernel_roofline(st, sum(timed_ks) / len(timed_ks), dump_shapes=args.dump_shapes)
+            dom = dominant_kernel_roofline(st, sum(timed_ks) / len(timed_ks), dump_shapes=args.dump_shapes,
+                                           headline_workload=(args.arch == "sd15" and args.bs == 2 and args.res == 512 and args.rank == 4
+                                                              and not args.c3lier and not args.v_pred))
         finally:
             if tele:   # clocks while the launches were timed in isolation (bursts): the reference point for the loop's clocks
                 out["telemetry"]["during_isolated_launch_timing"] = Telemetry.summarize(tele.stop())

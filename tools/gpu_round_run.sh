@@ -78,6 +78,18 @@ except Exception as e: print(sys.argv[1], 'FAILED', e)
 PY
 done
 fi
+if [ "$what" = "configs_bench" ]; then      # BASELINE configs 3-5, 20 timed steps, full accounting, the committed launch-shape table (no re-tuning)
+( timeout 400 python bench.py --arch sd21 --res 768 --v-pred --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 ) > $O/${RN}_bench_sd21_768.json
+( timeout 600 python bench.py --arch sdxl --res 1024 --bs 1 --rank 16 --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 ) > $O/${RN}_bench_sdxl_1024.json
+( timeout 400 python bench.py --bs 4 --rank 8 --c3lier --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 ) > $O/${RN}_bench_sd15_c3lier_bs4.json
+for f in ${RN}_bench_sd21_768 ${RN}_bench_sdxl_1024 ${RN}_bench_sd15_c3lier_bs4; do python - $O/$f.json <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read()); print(sys.argv[1].split('/')[-1], round(d['value'],3),'steps/s', round(d['ms_per_step'],1),'ms dedup', round(d['dedup']['value'],3), 'k_mean',d['config']['k_mean'],'whole-step frac',round(d['roofline']['whole_step']['frac'],3),'loss',d['config']['loss'], 'dom', d['roofline']['kernel'].get('name'), round(d['roofline'].get('frac',0),3), d['roofline'].get('kernel_sources'))
+except Exception as e: print(sys.argv[1], 'FAILED', e)
+PY
+done
+fi
 if [ "$what" = "configs_quick" ]; then      # BASELINE configs 3-5 with the committed launch-shape table (no re-tuning)
 ( timeout 200 python bench.py --arch sd21 --res 768 --v-pred --steps 6 --warmup 2 --no-cpu-baseline --no-dominant 2>/dev/null | tail -1 ) > $O/${RN}_bench_sd21_768.json
 ( timeout 300 python bench.py --arch sdxl --res 1024 --bs 1 --rank 16 --steps 6 --warmup 2 --no-cpu-baseline --no-dominant 2>/dev/null | tail -1 ) > $O/${RN}_bench_sdxl_1024.json
