@@ -133,6 +133,22 @@ def _dominant_accounting(bench, monkeypatch):
     assert iso["launches"]["denoise"] == n_den and iso["per_denoise_pass"] >= 5.0 * n_den
     assert abs(iso["fixed"] + iso["per_denoise_pass"] - sum(iso["by_list"].values())) < 1e-6 * iso["fixed"]
     assert d["timing_source"].startswith("live") and "frac_trace" not in d
+    # a committed trace on the running kernel sources names the dominant kernel of the HEADLINE workload only: another
+    # configuration's line (BASELINE configs 3 - 5) ranks its kernels live and quotes no trace / counter figure
+    import tempfile
+    runner_up = d["next_kernels"][0]["name"]
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as fh:
+        fh.write(f"# csrc_sha1={bench.kernel_sources_hash()}\n     %    calls   total_ms    avg_us   min_us    max_us  kernel\n"
+                 f" 50.00      100     1.00      10.0      9.0      11.0  {runner_up}\n")
+    monkeypatch.setattr(bench, "PROFILE_STATS", fh.name)
+    try:
+        h = bench.dominant_kernel_roofline(st, 3.0, headline_workload=True)
+        assert h["name"] == runner_up and h["agrees_with_profile"] and h["us_per_launch_trace"] == 10.0 and h["live_top"] == d["name"]
+        o = bench.dominant_kernel_roofline(st, 3.0, headline_workload=False)
+        assert o["name"] == d["name"] and o["profile_top_row"] is None and o["agrees_with_profile"] is None and "frac_trace" not in o
+        assert o["traffic"] is None and "headline workload" in o["traffic_note"]
+    finally:
+        os.unlink(fh.name)
 
 
 def test_gpu_telemetry_degrades_to_fields_and_summarises():
